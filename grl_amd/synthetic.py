@@ -1,0 +1,112 @@
+"""Deterministic synthetic weights and MARS-shaped clips.
+
+There is no network in the build/GPU environment (no ImageNet checkpoint,
+no MARS), so parity fixtures and the benchmark use a build-owned generator
+that is a pure function of (tensor name, shape, seed).  The same bytes are
+regenerated in the survey container (where they are loaded into the imported
+reference to make golden vectors) and on the GPU box.
+
+BatchNorm buffers get *non-trivial* running statistics so that eval-mode
+folding (scale = gamma/sqrt(var+eps), shift = beta - mean*scale) is actually
+exercised by the parity tests.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # reid/data/dataloader.py:51
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+# gains chosen so that, with these synthetic weights, the trunk output stays
+# O(1) and both sigmoids on the path (GCE map, TRL channel attention) sit in
+# their non-saturated range -- otherwise x*(1-map) is pure cancellation noise
+# and the parity fixtures would pin nothing.
+_BN3_GAMMA = (0.25,0.5)
+_GAIN_GCE_CONV = 1.0
+_GAIN_CH_MLP = 0.3
+
+
+def _rng(name, seed):
+    return np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
+
+
+def synth_tensor(name, shape, seed=0, is_bn=False):
+    """One tensor of the schema; rules keyed on the leaf name and rank
+    (``is_bn``: the parent module owns running statistics)."""
+    g = _rng(name, seed)
+    shape = tuple(shape)
+    leaf = name.rsplit('.', 1)[-1]
+    parent = name.rsplit('.', 1)[0] if '.' in name else ''
+    if leaf == 'num_batches_tracked':
+        return torch.zeros(shape, dtype=torch.long)
+    if leaf == 'running_mean':
+        return torch.from_numpy(g.normal(0.0, 0.1, shape).astype(np.float32))
+    if leaf == 'running_var':
+        return torch.from_numpy(g.uniform(0.5, 1.5, shape).astype(np.float32))
+    if len(shape) == 4:                                     # conv weight
+        fan_in = shape[1] * shape[2] * shape[3]
+        gain = _GAIN_GCE_CONV if 'corr_atte' in name else 1.0
+        w = g.normal(0.0, gain * np.sqrt(2.0 / fan_in), shape)
+        if 'corr_atte.5' in name:       # zero-sum taps: inputs are post-ReLU (positive mean)
+            w -= w.mean(axis=(1, 2, 3), keepdims=True)
+        return torch.from_numpy(w.astype(np.float32))
+    if len(shape) == 2:                                     # linear weight
+        gain = _GAIN_CH_MLP if 'channel_atte' in name else 1.0
+        w = g.normal(0.0, gain * np.sqrt(1.0 / shape[1]), shape)
+        if 'channel_atte' in name:      # zero-sum rows: inputs are squares / post-ReLU
+            w -= w.mean(axis=1, keepdims=True)
+        return torch.from_numpy(w.astype(np.float32))
+    # 1-D: BN gamma/beta or a conv/linear bias
+    if leaf == 'weight':
+        lo, hi = (0.5, 1.5)
+        if parent.endswith('bn3') or parent.endswith('downsample.1'):
+            lo, hi = _BN3_GAMMA          # keep the residual stream O(1)
+        return torch.from_numpy(g.uniform(lo, hi, shape).astype(np.float32))
+    if leaf == 'bias':
+        if is_bn:
+            return torch.from_numpy(g.uniform(-0.2, 0.2, shape).astype(np.float32))
+        return torch.from_numpy(g.uniform(-0.05, 0.05, shape).astype(np.float32))
+    raise ValueError('no synthetic rule for %s %s' % (name, shape))
+
+
+def synth_state_dict(module_or_spec, seed=0, prefix=''):
+    """Synthetic state_dict for an nn.Module (or a {name: shape} mapping)."""
+    if hasattr(module_or_spec, 'state_dict'):
+        spec = {k: tuple(v.shape) for k, v in module_or_spec.state_dict().items()}
+    else:
+        spec = dict(module_or_spec)
+    bn_parents = {k.rsplit('.', 1)[0] for k in spec if k.endswith('.running_mean')}
+    return {k: synth_tensor(prefix + k, shp, seed, k.rsplit('.', 1)[0] in bn_parents)
+            for k, shp in spec.items()}
+
+
+def synth_clips(b, t, seed=0, h=256, w=128):
+    """u8 ~ U{0..255} (PCG64(seed)) -> ToTensor -> Normalize(ImageNet), fp32
+    [b,t,3,h,w]; value range ~[-2.12, 2.64] (seqtransforms.py:187-213)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    u8 = g.integers(0, 256, size=(b, t, 3, h, w), dtype=np.uint8)
+    x = torch.from_numpy(u8).to(torch.float32).div_(255.0)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(1, 1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(1, 1, 3, 1, 1)
+    return x.sub_(mean).div_(std)
+
+
+def synth_eval_features(nq, ng, seed=1, dim=6144, n_ids=626, n_cams=6, noise=2.0):
+    """Evaluator inputs shaped like attevaluator.py:112 features: each row is
+    three independently L2-normalised 2048-blocks.  Rows of one identity share
+    a per-identity centre (plus ``noise`` x N(0,1)) so CMC/mAP are non-trivial.
+    The first nq gallery rows are the query rows (attevaluator.py:143).
+    Returns qf, gf (query prepended), q_pids, q_cams, g_pids, g_cams."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    blk = dim // 3
+    centres = g.standard_normal((n_ids, 3, blk)).astype(np.float32)
+    pids = g.integers(0, n_ids, ng)
+    cams = g.integers(0, n_cams, ng)
+    x = centres[pids] + noise * g.standard_normal((ng, 3, blk)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=2, keepdims=True)
+    gf = np.ascontiguousarray(x.reshape(ng, dim))
+    qf = gf[:nq].copy()
+    return (torch.from_numpy(qf), torch.from_numpy(gf),
+            pids[:nq].copy(), cams[:nq].copy(), pids, cams)

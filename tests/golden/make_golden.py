@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE itself (imported from
+/root/reference, CPU, fp32) on the build's deterministic synthetic weights and
+clips.  Runs only in the build container (the reference does not exist on the
+GPU box); its outputs -- plain data, < 1 MB -- are committed next to this
+script and consumed by tests/test_oracle_golden.py (oracle pin) and the
+``-m gpu`` parity tests.
+
+The reference needs three import-time stubs here (torchvision, tensorboardX,
+cv2 are not installed) and ``model_zoo.load_url`` patched (no network); none of
+them touch the math being pinned.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    tv = _stub('torchvision')
+    tv.models = _stub('torchvision.models', resnet18=None, resnet34=None, resnet50=None,
+                      resnet101=None, resnet152=None)
+    tv.utils = _stub('torchvision.utils', save_image=lambda *a, **k: None)
+    _stub('tensorboardX', SummaryWriter=lambda *a, **k: None)
+    _stub('cv2')
+    sys.path.insert(0, REF)
+    import reid.models.resnets1 as r1            # noqa: the reference's package
+    full = r1.ResNet(r1.Bottleneck, [3, 4, 6, 3]).state_dict()
+    r1.model_zoo.load_url = lambda *a, **k: full
+    from reid import models as ref_models
+    from reid.evaluator import attevaluator, eva_functions
+    from reid.loss import pairloss, triplet
+    return ref_models, attevaluator, eva_functions, pairloss, triplet
+
+
+def sample(t, n=256):
+    """Strided sample + checksums of a big tensor."""
+    f = t.detach().reshape(-1).double()
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return dict(sum=f.sum().item(), abssum=f.abs().sum().item(),
+                idx=idx.numpy(), val=f[idx].float().numpy(), shape=np.array(t.shape))
+
+
+def pack(prefix, d, out):
+    for k, v in d.items():
+        out['%s.%s' % (prefix, k)] = np.asarray(v)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REPO)
+    from grl_amd.synthetic import synth_state_dict, synth_clips, synth_eval_features
+    ref_models, attev, evaf, pairloss, triplet = import_reference()
+
+    B, T = 2, 4
+    cnn = ref_models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625)
+    sd = synth_state_dict(cnn, seed=0)
+    cnn.load_state_dict(sd, strict=True)          # also proves the key schema matches
+    siam = ref_models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    ssd = synth_state_dict(siam, seed=0, prefix='siamese.')
+    siam.load_state_dict(ssd, strict=True)
+    siamv = ref_models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    svd = synth_state_dict(siamv, seed=0, prefix='siamese_video.')
+    siamv.load_state_dict(svd, strict=True)
+    clips = synth_clips(B, T, seed=0)
+
+    # ---------------- (A) eval forward + clip features -----------------
+    out = {}
+    taps = {}
+    hooks = []
+    base = cnn.backbone.base
+    for name, mod in (('stem', base[2]), ('pool', base[3]), ('layer1', base[4]),
+                      ('layer2', base[5]), ('layer3', base[6]), ('layer4', base[7])):
+        hooks.append(mod.register_forward_hook(
+            lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone())))
+    trl = cnn.temporal_learning_block
+    catte = {'fwd': [], 'bwd': []}
+    hooks.append(trl.channel_atte_foreward_corr.register_forward_hook(
+        lambda m, i, o: catte['fwd'].append(o.detach().clone())))
+    hooks.append(trl.channel_atte_backward_corr.register_forward_hook(
+        lambda m, i, o: catte['bwd'].append(o.detach().clone())))
+    trl_out = {}
+    hooks.append(trl.register_forward_hook(
+        lambda m, i, o: trl_out.update(f_uncorr=o[0].detach().clone(), f_corr=o[1].detach().clone())))
+    bb_out = {}
+    hooks.append(cnn.backbone.register_forward_hook(
+        lambda m, i, o: bb_out.update(corr_map=o[2].detach().clone())))
+    cnn.eval(); siam.eval(); siamv.eval()
+    with torch.no_grad():
+        xu, xc = cnn(clips)
+        pooled = siam.self_attention(xc)
+        feat = torch.cat((xu, pooled, xc.mean(dim=1)), dim=1)   # attevaluator.py:109-112
+    for h in hooks:
+        h.remove()
+    out['meta.B'] = np.array(B); out['meta.T'] = np.array(T)
+    out['x_uncorr'] = xu.numpy(); out['x_corr'] = xc.numpy(); out['feat'] = feat.numpy()
+    out['corr_map'] = bb_out['corr_map'].numpy()
+    out['f_uncorr'] = trl_out['f_uncorr'].numpy(); out['f_corr'] = trl_out['f_corr'].numpy()
+    for k, v in taps.items():
+        pack('tap.' + k, sample(v), out)
+    for d in ('fwd', 'bwd'):
+        out['catte.' + d] = torch.stack(catte[d], 0)[:, :, ::16].numpy()   # [T,B,128]
+    np.savez_compressed(os.path.join(HERE, 'grl_eval_b2t4.npz'), **out)
+    print('eval golden: |x_uncorr|', xu.norm(dim=1), 'map range',
+          bb_out['corr_map'].min().item(), bb_out['corr_map'].max().item())
+
+    # ---------------- (B) train forward + backward ----------------------
+    cnn.load_state_dict(sd, strict=True)
+    cnn.train()
+    g = np.random.Generator(np.random.PCG64(7))
+    r1 = torch.from_numpy(g.standard_normal((B, 2048)).astype(np.float32))
+    r2 = torch.from_numpy(g.standard_normal((B, T, 2048)).astype(np.float32))
+    x_in = clips.clone().requires_grad_(True)
+    xu, xc = cnn(x_in)
+    loss = (xu * r1).sum() + (xc * r2).sum()
+    loss.backward()
+    out = {'x_uncorr': xu.detach().numpy(), 'x_corr': xc.detach().numpy(),
+           'loss': np.array(loss.item())}
+    named = dict(cnn.named_parameters())
+    for k in ('backbone.base.0.weight', 'backbone.base.1.weight', 'backbone.base.1.bias',
+              'backbone.base.4.0.conv2.weight', 'backbone.base.5.0.downsample.0.weight',
+              'backbone.base.7.2.conv3.weight', 'backbone.base.7.2.bn3.weight',
+              'backbone.glo_fc.0.weight', 'backbone.glo_fc.1.bias',
+              'backbone.corr_atte.0.weight', 'backbone.corr_atte.5.weight', 'backbone.corr_atte.6.weight',
+              'temporal_learning_block.forward_f1.0.weight', 'temporal_learning_block.forward_f1.0.bias',
+              'temporal_learning_block.backward_f2.0.weight',
+              'temporal_learning_block.channel_atte_foreward_corr.0.weight',
+              'temporal_learning_block.channel_atte_backward_corr.2.weight',
+              'temporal_learning_block.uncorr_memo_forward.conv1.weight',
+              'temporal_learning_block.uncorr_memo_backward.bn3.weight',
+              'corr_bn.weight', 'uncorr_bn.bias'):
+        pack('grad.' + k, sample(named[k].grad), out)
+    pack('grad.input', sample(x_in.grad), out)
+    st = cnn.state_dict()
+    for k in ('backbone.base.1.running_mean', 'backbone.base.1.running_var',
+              'backbone.base.7.2.bn3.running_var', 'backbone.glo_fc.1.running_mean',
+              'backbone.corr_atte.6.running_var',
+              'temporal_learning_block.uncorr_memo_forward.bn1.running_mean',
+              'temporal_learning_block.uncorr_memo_forward.bn1.running_var',
+              'temporal_learning_block.uncorr_memo_forward.bn1.num_batches_tracked',
+              'temporal_learning_block.uncorr_memo_backward.bn3.running_var',
+              'corr_bn.running_mean', 'uncorr_bn.running_var', 'corr_bn.num_batches_tracked'):
+        out['stat.' + k] = st[k].numpy()
+    np.savez_compressed(os.path.join(HERE, 'grl_train_b2t4.npz'), **out)
+    print('train golden: loss', loss.item())
+
+    # ---------------- (C) Siamese heads ---------------------------------
+    g = np.random.Generator(np.random.PCG64(11))
+    xs = g.standard_normal((4, T, 2048)).astype(np.float32)
+    xs /= np.linalg.norm(xs, axis=2, keepdims=True)
+    xs = torch.from_numpy(xs)
+    out = {'x': xs.numpy()}
+    siam.eval(); siamv.eval()
+    with torch.no_grad():
+        out['eval.attn'] = siam.self_attention(xs).numpy()
+        cls, so = siam(xs)
+        out['eval.cls'] = cls.numpy(); out['eval.out'] = so.numpy()
+        cls, so = siamv(xs[:, 0])
+        out['eval.v_cls'] = cls.numpy(); out['eval.v_out'] = so.numpy()
+    siam.load_state_dict(ssd); siam.train()
+    xg = xs.clone().requires_grad_(True)
+    cls, so = siam(xg)
+    rr = torch.from_numpy(g.standard_normal(tuple(so.shape)).astype(np.float32))
+    rc = torch.from_numpy(g.standard_normal(tuple(cls.shape)).astype(np.float32))
+    ((so * rr).sum() + (cls * rc).sum()).backward()
+    out['train.cls'] = cls.detach().numpy(); out['train.out'] = so.detach().numpy()
+    out['train.rr'] = rr.numpy(); out['train.rc'] = rc.numpy()
+    out['train.grad_x'] = xg.grad.numpy()
+    out['train.grad_featQ_w'] = siam.featQ.weight.grad[:, ::64].numpy()
+    out['train.grad_cls_w'] = siam.classifierlinear.weight.grad.numpy()
+    out['train.featQ_bn_rm'] = siam.featQ_bn.running_mean.numpy()
+    np.savez_compressed(os.path.join(HERE, 'siamese_b4t4.npz'), **out)
+
+    # ---------------- (D) evaluator -------------------------------------
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    dist = attev.cosin_dist(qf, gf).numpy()
+    cmc, mAP = evaf.evaluate(dist, qp, gp, qc, gc)
+    euc = attev.pairwise_distance_tensor(qf, qf).numpy()
+    # non-unit-norm rows (dense test_all.py mode averages clips: attevaluator.py:84,95)
+    qd = (qf.view(20, 2, -1).mean(1)); gd = torch.cat((qd, gf[40:240]), 0)
+    dist_d = attev.cosin_dist(qd, gd).numpy()
+    euc_d = attev.pairwise_distance_tensor(qd, gd).numpy()
+    np.savez_compressed(os.path.join(HERE, 'evaluator_q40_g400.npz'),
+                        dist=dist, indices=np.argsort(dist, axis=1).astype(np.int32),
+                        cmc=cmc[:20], mAP=np.array(mAP), euclid_qq=euc,
+                        dist_dense=dist_d, euclid_dense=euc_d,
+                        idx_dense=np.argsort(dist_d, axis=1).astype(np.int32),
+                        idx_dense_euclid=np.argsort(euc_d, axis=1).astype(np.int32))
+    print('evaluator golden: mAP %.4f rank1 %.4f' % (mAP, cmc[0]))
+
+    # ---------------- (E) losses that still run on this torch -----------
+    g = np.random.Generator(np.random.PCG64(13))
+    feat = torch.from_numpy(g.standard_normal((8, 2048)).astype(np.float32))
+    feat = feat / feat.norm(dim=1, keepdim=True)
+    ids = torch.tensor([3, 3, 9, 9, 4, 4, 3, 3])
+    torch.Tensor.__xor__  # noqa
+    # TripletLoss uses `bool ^ 1` / byte eye, which modern torch rejects; emulate the
+    # two masks exactly as triplet.py:30-34 defines them and call its cdist.
+    tl = triplet.TripletLoss('soft', True)
+    dist_t = tl.cdist(feat, feat)
+    same = ids.unsqueeze(1).eq(ids.unsqueeze(0))
+    eye = torch.eye(8).bool()
+    max_pos = (dist_t * (same ^ eye).float()).max(1)[0]
+    min_neg = (dist_t + 1e5 * same.float()).min(1)[0]
+    tri = torch.log(1 + torch.exp(max_pos - min_neg))
+    score = torch.from_numpy(g.uniform(0.05, 0.95, (4, 4)).astype(np.float32))
+    tp = torch.tensor([3, 9, 4, 3]); tg = torch.tensor([3, 9, 4, 3])
+    pl, prec = pairloss.PairLoss()(score, tp, tg)
+    np.savez_compressed(os.path.join(HERE, 'losses.npz'), feat=feat.numpy(), ids=ids.numpy(),
+                        triplet=tri.numpy(), score=score.numpy(), tp=tp.numpy(), tg=tg.numpy(),
+                        pair_loss=np.array(pl.item()), pair_prec=np.array(float(prec)))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,121 @@
+"""Pin the oracle (oracle/grl_oracle.py) against vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import grl_oracle as O
+from grl_amd.synthetic import synth_clips, synth_eval_features
+
+TOL = 1e-5
+
+
+def _state(mod):
+    return {k: v.clone() for k, v in mod.state_dict().items()}
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    denom = max(np.abs(b).max(), 1e-30)
+    assert np.abs(a - b).max() / denom <= tol, (np.abs(a - b).max(), denom)
+
+
+def _check_sample(t, g, key, tol=TOL):
+    f = t.detach().reshape(-1).double()
+    assert tuple(t.shape) == tuple(g[key + '.shape'])
+    _close(f[torch.from_numpy(g[key + '.idx'])].numpy(), g[key + '.val'], tol)
+    assert abs(f.sum().item() - g[key + '.sum']) <= tol * max(g[key + '.abssum'], 1.0)
+    assert abs(f.abs().sum().item() - g[key + '.abssum']) <= tol * max(g[key + '.abssum'], 1.0)
+
+
+def test_eval_forward_matches_reference(golden, synth_models):
+    cnn, siam, _ = synth_models
+    g = golden('grl_eval_b2t4.npz')
+    sd, ssd = _state(cnn), _state(siam)
+    clips = synth_clips(2, 4, seed=0)
+    taps = {}
+    with torch.no_grad():
+        xu, xc = O.grl_forward(sd, clips, train=False, taps=taps)
+    _close(xu, g['x_uncorr']); _close(xc, g['x_corr'])
+    _close(taps['corr_map'], g['corr_map'])
+    _close(taps['f_uncorr'], g['f_uncorr']); _close(taps['f_corr'], g['f_corr'])
+    for k in ('stem', 'pool', 'layer1', 'layer2', 'layer3', 'layer4'):
+        _check_sample(taps[k], g, 'tap.' + k)
+    _close(torch.stack(taps['fwd_catte'])[:, :, ::16], g['catte.fwd'])
+    _close(torch.stack(taps['bwd_catte'])[:, :, ::16], g['catte.bwd'])
+    _close(O.extract_features(sd, ssd, clips), g['feat'])
+
+
+def test_train_forward_backward_matches_reference(golden, synth_models):
+    cnn, _, _ = synth_models
+    g = golden('grl_train_b2t4.npz')
+    sd = _state(cnn)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and 'running' not in k:
+            v.requires_grad_(True)
+    rg = np.random.Generator(np.random.PCG64(7))
+    r1 = torch.from_numpy(rg.standard_normal((2, 2048)).astype(np.float32))
+    r2 = torch.from_numpy(rg.standard_normal((2, 4, 2048)).astype(np.float32))
+    x = synth_clips(2, 4, seed=0).requires_grad_(True)
+    xu, xc = O.grl_forward(sd, x, train=True)
+    loss = (xu * r1).sum() + (xc * r2).sum()
+    loss.backward()
+    _close(xu.detach(), g['x_uncorr']); _close(xc.detach(), g['x_corr'])
+    keys = sorted({k[5:].rsplit('.', 1)[0] for k in g.files if k.startswith('grad.')})
+    for k in keys:
+        t = x.grad if k == 'input' else sd[k].grad
+        _check_sample(t, g, 'grad.' + k, tol=2e-4)
+    for k in [k for k in g.files if k.startswith('stat.')]:
+        _close(sd[k[5:]].detach().double(), g[k])
+
+
+def test_siamese_heads_match_reference(golden, synth_models):
+    _, siam, siamv = synth_models
+    g = golden('siamese_b4t4.npz')
+    x = torch.from_numpy(g['x'])
+    ssd, svd = _state(siam), _state(siamv)
+    with torch.no_grad():
+        _close(O.self_attention(ssd, x), g['eval.attn'])
+        cls, out = O.siamese_forward(ssd, x)
+        _close(cls, g['eval.cls']); _close(out, g['eval.out'])
+        cls, out = O.siamese_video_forward(svd, x[:, 0])
+        _close(cls, g['eval.v_cls']); _close(out, g['eval.v_out'])
+    ssd = _state(siam)
+    for k, v in ssd.items():
+        if v.dtype.is_floating_point and 'running' not in k:
+            v.requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    cls, out = O.siamese_forward(ssd, xg, train=True)
+    ((out * torch.from_numpy(g['train.rr'])).sum() + (cls * torch.from_numpy(g['train.rc'])).sum()).backward()
+    _close(cls.detach(), g['train.cls']); _close(out.detach(), g['train.out'])
+    _close(xg.grad, g['train.grad_x'], 1e-4)
+    _close(ssd['featQ.weight'].grad[:, ::64], g['train.grad_featQ_w'], 1e-4)
+    _close(ssd['classifierlinear.weight'].grad, g['train.grad_cls_w'], 1e-4)
+    _close(ssd['featQ_bn.running_mean'].detach(), g['train.featQ_bn_rm'])
+
+
+def test_evaluator_matches_reference(golden):
+    g = golden('evaluator_q40_g400.npz')
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    dist = O.cosin_dist(qf, gf).numpy()
+    _close(dist, g['dist'])
+    cmc, mAP, idx = O.evaluate(dist, qp, gp, qc, gc)
+    assert np.array_equal(idx.astype(np.int32), g['indices'])       # ranking bit-exact
+    _close(cmc[:20], g['cmc']); assert abs(mAP - float(g['mAP'])) < 1e-9
+    # the q-q diagonal is sqrt of pure cancellation noise: compare squared distances
+    _close(O.pairwise_distance(qf, qf).numpy() ** 2, g['euclid_qq'] ** 2, 1e-5)
+    qd = qf.view(20, 2, -1).mean(1); gd = torch.cat((qd, gf[40:240]), 0)
+    _close(O.cosin_dist(qd, gd).numpy(), g['dist_dense'])
+    _close(O.pairwise_distance(qd, gd).numpy(), g['euclid_dense'], 1e-5)
+    # fma-chain model of the HIP GEMM ranks identically on this (tie-free) case
+    chain = -O.fma_chain_dot(qf.numpy(), gf.numpy())
+    assert np.array_equal(np.argsort(chain, axis=1).astype(np.int32), g['indices'])
+
+
+def test_losses_match_reference(golden):
+    g = golden('losses.npz')
+    tri = O.triplet_soft_batch_hard(torch.from_numpy(g['feat']), torch.from_numpy(g['ids']))
+    _close(tri, g['triplet'])
+    loss, prec = O.pair_loss(torch.from_numpy(g['score']), torch.from_numpy(g['tp']), torch.from_numpy(g['tg']))
+    assert abs(loss.item() - float(g['pair_loss'])) < 1e-6
+    assert abs(float(prec) - float(g['pair_prec'])) < 1e-6

@@ -106,7 +106,7 @@ def test_evaluator_matches_reference(golden):
     _close(O.pairwise_distance(qf, qf).numpy() ** 2, g['euclid_qq'] ** 2, 1e-5)
     qd = qf.view(20, 2, -1).mean(1); gd = torch.cat((qd, gf[40:240]), 0)
     _close(O.cosin_dist(qd, gd).numpy(), g['dist_dense'])
-    _close(O.pairwise_distance(qd, gd).numpy(), g['euclid_dense'], 1e-5)
+    _close(O.pairwise_distance(qd, gd).numpy() ** 2, g['euclid_dense'] ** 2, 1e-5)
     # fma-chain model of the HIP GEMM ranks identically on this (tie-free) case
     chain = -O.fma_chain_dot(qf.numpy(), gf.numpy())
     assert np.array_equal(np.argsort(chain, axis=1).astype(np.int32), g['indices'])

@@ -107,9 +107,14 @@ def test_evaluator_matches_reference(golden):
     qd = qf.view(20, 2, -1).mean(1); gd = torch.cat((qd, gf[40:240]), 0)
     _close(O.cosin_dist(qd, gd).numpy(), g['dist_dense'])
     _close(O.pairwise_distance(qd, gd).numpy() ** 2, g['euclid_dense'] ** 2, 1e-5)
-    # fma-chain model of the HIP GEMM ranks identically on this (tie-free) case
+    # fma-chain model of the HIP GEMM: a different summation order than the
+    # reference's BLAS, so the two rankings may swap neighbours whose reference
+    # distances differ by less than fp32 rounding noise -- and only those.
     chain = -O.fma_chain_dot(qf.numpy(), gf.numpy())
-    assert np.array_equal(np.argsort(chain, axis=1).astype(np.int32), g['indices'])
+    _close(chain, g['dist'], 2e-5)
+    resorted = np.take_along_axis(g['dist'], np.argsort(chain, axis=1), 1)
+    assert (resorted[:, :-1] - resorted[:, 1:]).max() <= 3e-5
+    assert (np.argsort(chain, axis=1) != g['indices']).mean() < 1e-3
 
 
 def test_losses_match_reference(golden):

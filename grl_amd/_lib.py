@@ -1,0 +1,108 @@
+"""ctypes binding of libgrl_hip.so (C ABI: include/grl_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails this
+module raises.  Tensors cross the boundary as raw device pointers
+(``tensor.data_ptr()``) plus sizes; the stream is torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
+
+EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID = 0, 1, 2
+
+_fp = C.c_void_p      # device float*
+_i32 = C.c_int32
+_i64 = C.c_int64
+
+
+class GrlGemm(C.Structure):
+    _fields_ = [(n, _fp) for n in ('a', 'w', 'y', 'scale', 'shift', 'res', 'gbias', 'rowscale',
+                                   'rnorm', 'cnorm', 'stats')] + \
+               [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
+                                    'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
+                                    'kw', 'stride', 'pad')]
+
+
+_SIGNATURES = {
+    'grl_abi_version': ([], C.c_int),
+    'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
+    'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
+    'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),
+    'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_maxpool3x3s2': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_group_mean': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp], C.c_int),
+    'grl_gce_gate': ([_fp] * 8 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_temporal_mean': ([_fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_sqdiff_mean': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_channel_atte': ([_fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, C.c_int, C.c_int, C.c_int,
+                          C.c_int, _fp], C.c_int),
+    'grl_add_strided': ([_fp, _fp, _fp, C.c_int, _i64, _i64, _fp], C.c_int),
+    'grl_affine_l2norm': ([_fp, _fp, _fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_siamese_attn': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_mean_T': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_pair_verify': ([_fp] * 7 + [C.c_int] * 4 + [_fp], C.c_int),
+    'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+}
+
+_lib = None
+
+
+class GrlHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgrl_hip.so (built in-tree by ``__graft_entry__.build()`` /
+    ``make -C grl_amd/csrc``).  Raises if it is absent -- no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise GrlHipError(
+            'libgrl_hip.so not found at %s: build it with `python -c "import '
+            '__graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). '
+            'grl_amd has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.grl_last_error.restype = C.c_char_p
+    lib.grl_last_error.argtypes = []
+    for name, (args, res) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError = header/library mismatch
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return ['grl_last_error'] + sorted(_SIGNATURES)
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().grl_last_error().decode('utf-8', 'replace')
+        raise GrlHipError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def require_device(t, what='input'):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise GrlHipError(
+            '%s must live on a HIP device (got %s): grl_amd executes on MI355X only and '
+            'has no CPU path' % (what, getattr(t, 'device', type(t))))
+    if t.dtype != torch.float32:
+        raise GrlHipError('%s must be float32 (got %s)' % (what, t.dtype))

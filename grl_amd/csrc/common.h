@@ -1,0 +1,29 @@
+// Shared helpers for the libgrl_hip.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+int grl_fail(int code, const char* fmt, ...);          // sets the thread-local message
+int grl_check_launch(const char* what);                 // hipGetLastError -> GRL_ELAUNCH
+
+static inline int grl_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// wave64 sum (all lanes receive the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum for <= 16 waves; `red` is >= 16 floats of LDS. All threads get the total.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

@@ -1,0 +1,314 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   Y[M][N] = epilogue( A[M][K] . W[N][K]^T )
+//
+// A is either a dense K-contiguous matrix or gathered on the fly from a
+// channels-last image tensor (1x1 / 3x3, stride 1 / 2, zero padding).  Both
+// operands are K-contiguous, so a lane can fetch FOUR consecutive k of its row
+// with one ds_read_b128 and feed four v_mfma_f32_32x32x2_f32 from it: the k a
+// lane half supplies to one MFMA is arbitrary as long as A and B agree, so lane
+// half h takes k = 8q + 4h + s at step s of 8-wide chunk q.
+//
+// Accumulation order (documented for the bit-exact oracle): for K-stage j
+// (32 wide), chunk q = 0..3, step s = 0..3 the accumulator receives
+//   acc = fma(a[k0], b[k0], acc);  acc = fma(a[k1], b[k1], acc)
+// with k0 = 32j + 8q + s, k1 = k0 + 4.
+//
+// Tile: BM x BN x 32 per workgroup of 4 waves (2 x 2), each wave
+// (BM/2) x (BN/2) as MT x NT MFMA tiles of 32 x 32.  LDS holds two stages of
+// A and B tiles as [row][32 floats] with the 16-byte chunk index XOR-swizzled by
+// (row >> 1) & 7, which makes both the ds_write_b128 of the staging pass and
+// the ds_read_b128 of the fragment reads bank-conflict free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+
+struct RowInfo {          // per staged A row: where it comes from
+    int64_t base;         // dense: m*lda ; conv: image base offset (img*H*W*C)
+    int iy0, ix0;         // conv: top-left input coordinate of the window
+};
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
+                                                           const int num_tiles) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
+    constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM*32]
+    float* Bs = smem + 2 * BM * BK;       // [2][BN*32]
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch);
+    // give each XCD a contiguous run of tiles so that the W panel / A panel re-reads
+    // of neighbouring tiles hit that XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int q = num_tiles >> 3, r = num_tiles & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+
+    // ---- per-thread staging rows --------------------------------------------
+    RowInfo ai[A_ITEMS];
+#pragma unroll
+    for (int i = 0; i < A_ITEMS; ++i) {
+        int m = m0 + ld_row + 32 * i;
+        m = m < p.M ? m : p.M - 1;                    // clamp: edge rows are never stored
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            ai[i].base = (int64_t)img * p.H * p.W * p.C;
+            ai[i].iy0 = oy * p.stride - p.pad;
+            ai[i].ix0 = ox * p.stride - p.pad;
+        } else {
+            ai[i].base = (int64_t)m * p.lda;
+            ai[i].iy0 = ai[i].ix0 = 0;
+        }
+    }
+    int64_t bofs[B_ITEMS];
+#pragma unroll
+    for (int i = 0; i < B_ITEMS; ++i) {
+        int n = n0 + ld_row + 32 * i;
+        n = n < p.N ? n : p.N - 1;
+        bofs[i] = (int64_t)n * p.ldw;
+    }
+
+    f32x4 areg[A_ITEMS], breg[B_ITEMS];
+    auto load_stage = [&](int ks) {
+        const int k0 = ks * BK;
+        if (CONV) {
+            const int tap = k0 / p.C, c0 = k0 - tap * p.C;          // wave-uniform
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int iy = ai[i].iy0 + ky, ix = ai[i].ix0 + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok)
+                    v = *reinterpret_cast<const f32x4*>(
+                        p.a + ai[i].base + ((int64_t)iy * p.W + ix) * p.C + c0 + ld_chunk * 4);
+                areg[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i)
+                areg[i] = *reinterpret_cast<const f32x4*>(p.a + ai[i].base + k0 + ld_chunk * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i)
+            breg[i] = *reinterpret_cast<const f32x4*>(p.w + bofs[i] + k0 + ld_chunk * 4);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ITEMS; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK +
+                                      ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK +
+                                      ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = breg[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_stage(ks + 1);
+        const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
+        const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = i * 32 + frow;
+                // (wm*WTM) is a multiple of 32, so (row>>1)&7 equals the tile-local swizzle
+                af[i] = *reinterpret_cast<const f32x4*>(
+                    Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int row = j * 32 + frow;
+                bf[j] = *reinterpret_cast<const f32x4*>(
+                    Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------
+    // acc[i][j][r] is Y[row][col] with row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31
+    const int col_l = lane & 31;
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + col_l;
+        const bool n_ok = n < p.N;
+        const int nn = n_ok ? n : p.N - 1;
+        const float sc = p.scale ? p.scale[nn] : 1.f;
+        const float sh = p.shift ? p.shift[nn] : 0.f;
+        const float cn = (p.epilogue == GRL_EPI_EUCLID) ? p.cnorm[nn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.epilogue == GRL_EPI_AFFINE) {
+                    if (p.rowscale) v *= p.rowscale[m];
+                    if (p.gbias) v += p.gbias[(int64_t)(m / p.rows_per_group) * p.N + nn];
+                    if (p.stats) { csum[j] += v; csq[j] += v * v; }
+                    v = v * sc + sh;
+                    if (p.res && n_ok) v += p.res[(int64_t)m * p.ldres + n];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                } else if (p.epilogue == GRL_EPI_NEGDOT) {
+                    v = -v;
+                } else {
+                    v = p.rnorm[m] + cn - 2.f * v;
+                    v = sqrtf(v > 1e-12f ? v : 1e-12f);
+                }
+                if (n_ok) p.y[(int64_t)m * p.ldy + n] = v;
+            }
+        }
+    }
+
+    if (p.stats) {
+        // per-channel sum / sum-of-squares of the raw conv output over this tile's
+        // rows (rows >= M contribute nothing: they were skipped above).  Combine the
+        // two lane halves, then the two wave rows through LDS, and write one
+        // deterministic partial per (tile_m, n): stats[tile_m][0|1][n].
+        __syncthreads();                       // tiles in LDS are dead now
+        float* red = smem;                     // [2 wm][2][BN]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32);
+            float q2 = csq[j] + __shfl_xor(csq[j], 32);
+            if (fhalf == 0) {
+                const int c = wn * WTN + j * 32 + col_l;
+                red[(wm * 2 + 0) * BN + c] = s;
+                red[(wm * 2 + 1) * BN + c] = q2;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            const int n = n0 + c;
+            if (n < p.N) {
+                p.stats[((int64_t)tile_m * 2 + 0) * p.N + n] = red[0 * BN + c] + red[2 * BN + c];
+                p.stats[((int64_t)tile_m * 2 + 1) * p.N + n] = red[1 * BN + c] + red[3 * BN + c];
+            }
+        }
+    }
+}
+
+struct TileChoice { int bm, bn; };
+
+TileChoice choose_tile(const GrlGemm& d) {
+    // Prefer the 128x128 tile; fall back to smaller tiles when the grid would not
+    // give every CU (256 of them, 2 resident workgroups each) something to do.
+    auto tiles = [&](int bm, int bn) {
+        return (int64_t)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
+    };
+    if (d.N <= 64) return tiles(128, 64) >= 512 ? TileChoice{128, 64} : TileChoice{64, 64};
+    if (tiles(128, 128) >= 448) return {128, 128};
+    if (tiles(128, 64) >= 448) return {128, 64};
+    return {64, 64};
+}
+
+template <int BM, int BN>
+int launch(const GrlGemm& d, hipStream_t s) {
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    const int num_tiles = tiles_m * tiles_n;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    if (d.conv) {
+        auto k = gemm_f32_kernel<BM, BN, true>;
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles);
+    } else {
+        auto k = gemm_f32_kernel<BM, BN, false>;
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles);
+    }
+    return grl_check_launch("grl_conv_gemm_f32");
+}
+
+int validate(const GrlGemm& d) {
+    if (!d.a || !d.w || !d.y) return grl_fail(GRL_EINVAL, "gemm: null operand");
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) return grl_fail(GRL_EINVAL, "gemm: empty shape");
+    if (d.K % BK) return grl_fail(GRL_EINVAL, "gemm: K must be a multiple of 32");
+    if (d.ldw % 4 || ((uintptr_t)d.w & 15) || ((uintptr_t)d.a & 15))
+        return grl_fail(GRL_EINVAL, "gemm: operands must be 16-byte aligned with ld % 4 == 0");
+    if (d.conv) {
+        if (d.C % BK) return grl_fail(GRL_EINVAL, "conv: C must be a multiple of 32");
+        if (d.K != d.kh * d.kw * d.C) return grl_fail(GRL_EINVAL, "conv: K != kh*kw*C");
+        if (d.M % (d.Ho * d.Wo)) return grl_fail(GRL_EINVAL, "conv: M must be nimg*Ho*Wo");
+    } else if (d.lda % 4) {
+        return grl_fail(GRL_EINVAL, "gemm: lda % 4 != 0");
+    }
+    if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
+        return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
+    if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");
+    return GRL_OK;
+}
+
+}  // namespace
+
+extern "C" int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc) {
+    if (!desc) return grl_fail(GRL_EINVAL, "null desc");
+    const TileChoice t = choose_tile(*desc);
+    return (desc->M + t.bm - 1) / t.bm;
+}
+
+extern "C" int grl_conv_gemm_f32(const GrlGemm* desc, void* stream) {
+    if (!desc) return grl_fail(GRL_EINVAL, "null desc");
+    const GrlGemm& d = *desc;
+    if (int e = validate(d)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const TileChoice t = choose_tile(d);
+    if (t.bm == 128 && t.bn == 128) return launch<128, 128>(d, s);
+    if (t.bm == 128 && t.bn == 64) return launch<128, 64>(d, s);
+    return launch<64, 64>(d, s);
+}

@@ -1,0 +1,564 @@
+// Bandwidth-bound kernels of the GRL path for gfx950: stem conv, pooling, the GCE
+// gate, the TRL reductions / channel attention, BN folding, L2-normalisation and the
+// Siamese temporal attention.  All tensors are channels-last fp32; every kernel moves
+// 16 bytes per lane per access (float4) with consecutive lanes on consecutive
+// addresses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+// ---------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                        int N, int C, int taps) {
+    // out[n][t][c] = w[n][c][t]
+    const int64_t total = (int64_t)N * C * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const int t = (i / C) % taps;
+        const int n = i / ((int64_t)C * taps);
+        out[i] = w[((int64_t)n * C + c) * taps + t];
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean,
+                               const float* var, const float* bias, float eps, float* scale,
+                               float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f;
+    // same operation order as ATen's eval batch_norm: invstd = 1/sqrt(var+eps)
+    const float s = var ? g * (1.f / sqrtf(var[c] + eps)) : g;
+    if (scale) scale[c] = s;
+    shift[c] = b - mu * s + (bias ? bias[c] * s : 0.f);
+}
+
+// ---------------------------------------------------------------------------------
+// Stem: 7x7/s2/p3 conv, Cin = 3 (K = 147 is too thin and too ragged for the MFMA
+// path), folded BN + ReLU.  One workgroup = 16x16 output pixels x 64 channels; the
+// 37x37x3 input patch is staged in LDS, each lane owns one pixel and keeps its 64
+// channel accumulators in VGPRs; weights/scale/shift are wave-uniform and come
+// through the scalar cache (s_load), so the inner loop is one LDS read per 64 FMAs.
+constexpr int ST = 16;                 // output tile edge
+constexpr int SP = 2 * ST + 5;         // input patch edge (37)
+
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ y, int H, int W) {
+    __shared__ float patch[3][SP][SP + 1];
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int img = blockIdx.z, oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    for (int i = threadIdx.x; i < 3 * SP * SP; i += 256) {
+        const int c = i / (SP * SP), r = (i / SP) % SP, q = i % SP;
+        const int iy = iy0 + r, ix = ix0 + q;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = xi[((int64_t)c * H + iy) * W + ix];
+        patch[c][r][q] = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    float acc[64];
+#pragma unroll
+    for (int o = 0; o < 64; ++o) acc[o] = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float v = patch[c][2 * ty + ky][2 * tx + kx];
+                const float* wk = w + (c * 7 + ky) * 7 + kx;      // w[o][c][ky][kx], o-stride 147
+#pragma unroll
+                for (int o = 0; o < 64; ++o) acc[o] = fmaf(v, wk[o * 147], acc[o]);
+            }
+        }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < Ho && ox < Wo) {
+        float* yo = y + (((int64_t)img * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+        for (int o = 0; o < 64; o += 4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = acc[o + e] * scale[o + e] + shift[o + e];
+                v[e] = t > 0.f ? t : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(yo + o) = v;
+        }
+    }
+}
+
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                    int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
+    const int64_t total = (int64_t)n * Ho * Wo * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = i % C4;
+        int64_t r = i / C4;
+        const int ox = r % Wo; r /= Wo;
+        const int oy = r % Ho;
+        const int img = r / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(
+                    x + (((int64_t)img * H + iy) * W + ix) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// y[g][c] (+)= out_scale/rows * sum_r x[g][r][c].  One workgroup per (group, 256-channel
+// slab): 64 lanes x float4 cover the slab, the 4 waves split the rows.
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ y, int rows, int C,
+                                                         int ldy, float mul, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int g = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int wave = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float* xp = x + (int64_t)g * rows * C + c;
+        for (int r = wave; r < rows; r += 4) s += *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C);
+    }
+    red[wave][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        t *= mul;
+        float* yp = y + (int64_t)g * ldy + c;
+        if (accumulate) t += *reinterpret_cast<const f32x4*>(yp);
+        *reinterpret_cast<f32x4*>(yp) = t;
+    }
+}
+
+// d[b][c] = mean_r (f1[b][r][c] - f2[b*stride + r*C + c])^2
+__global__ __launch_bounds__(256) void sqdiff_mean_kernel(const float* __restrict__ f1,
+                                                          const float* __restrict__ f2,
+                                                          float* __restrict__ d, int rows, int C,
+                                                          int64_t f2_stride) {
+    __shared__ f32x4 red[4][64];
+    const int g = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int wave = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float* p1 = f1 + (int64_t)g * rows * C + c;
+        const float* p2 = f2 + (int64_t)g * f2_stride + c;
+        for (int r = wave; r < rows; r += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p1 + (int64_t)r * C) -
+                            *reinterpret_cast<const f32x4*>(p2 + (int64_t)r * C);
+            s += t * t;
+        }
+    }
+    red[wave][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        t *= 1.f / rows;
+        *reinterpret_cast<f32x4*>(d + (int64_t)g * C + c) = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// GCE gate: one wave per pixel row.
+__global__ __launch_bounds__(256) void gce_gate_kernel(
+    const float* __restrict__ h, const float* __restrict__ w3, const float* __restrict__ bsc,
+    const float* __restrict__ bsh, const float* __restrict__ x, float* __restrict__ cmap,
+    float* __restrict__ xc, float* __restrict__ xu, int M, int Ch, int C) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = lane * 4; k < Ch; k += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(h + (int64_t)m * Ch + k);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w3 + k);
+        s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    s = wave_sum(s);
+    const float g = sigmoidf_(s * bsc[0] + bsh[0]);
+    if (lane == 0 && cmap) cmap[m] = g;
+    const float gu = 1.f - g;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)m * C + c);
+        *reinterpret_cast<f32x4*>(xc + (int64_t)m * C + c) = v * g;
+        *reinterpret_cast<f32x4*>(xu + (int64_t)m * C + c) = v * gu;
+    }
+}
+
+__global__ void temporal_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                     int64_t inner4, int64_t total4) {
+    const float inv = 1.f / T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / inner4, r = i - b * inner4;
+        const f32x4* xp = reinterpret_cast<const f32x4*>(x) + b * T * inner4 + r;
+        f32x4 s = xp[0];
+        for (int t = 1; t < T; ++t) s += xp[t * inner4];
+        reinterpret_cast<f32x4*>(y)[i] = s * inv;
+    }
+}
+
+__global__ void add_strided_kernel(const float* __restrict__ a, const float* __restrict__ bsrc,
+                                   float* __restrict__ y, int64_t inner4, int64_t bstride4,
+                                   int64_t total4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / inner4, r = i - b * inner4;
+        reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(a)[i] +
+                                         reinterpret_cast<const f32x4*>(bsrc)[b * bstride4 + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Channel attention of one TRL step, one workgroup per clip.
+//   hid = relu(W1 d)  (W1 [Hd][C], one wave per hidden unit, lanes stride C)
+//   c   = sigmoid(W2 hid) (W2T [Hd][C]: lanes stride the output channel)
+//   fstep (+)= (1 + c) * gap
+__global__ __launch_bounds__(256) void channel_atte_kernel(
+    const float* __restrict__ d, const float* __restrict__ w1, const float* __restrict__ w2t,
+    const float* __restrict__ gap, int64_t gap_stride, float* __restrict__ catte,
+    float* __restrict__ fstep, int64_t fstep_stride, int accumulate, int C, int Hd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ds = sm;            // [C]
+    float* hid = sm + C;       // [Hd]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x * 4; c < C; c += 1024)
+        *reinterpret_cast<f32x4*>(ds + c) = *reinterpret_cast<const f32x4*>(d + (int64_t)b * C + c);
+    __syncthreads();
+    for (int j = wave; j < Hd; j += 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (int64_t)j * C + c);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ds + c);
+            s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
+        }
+        s = wave_sum(s);
+        if (lane == 0) hid[j] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Hd; ++j)
+            s += *reinterpret_cast<const f32x4*>(w2t + (int64_t)j * C + c) * hid[j];
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = sigmoidf_(s[e]);
+        if (catte) *reinterpret_cast<f32x4*>(catte + (int64_t)b * C + c) = a;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gap + (int64_t)b * gap_stride + c);
+        // reference: mean(x*c + x) == gap*c + gap
+        f32x4 o = g * a + g;
+        float* fp = fstep + (int64_t)b * fstep_stride + c;
+        if (accumulate) o += *reinterpret_cast<const f32x4*>(fp);
+        *reinterpret_cast<f32x4*>(fp) = o;
+    }
+}
+
+// y[row] = v / max(|v|, 1e-12), v = x[row]*scale + shift   (one workgroup per row)
+__global__ __launch_bounds__(256) void affine_l2norm_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            float* __restrict__ y, int C,
+                                                            int64_t ldy) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)row * C + c);
+        if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = block_sum(ss, red);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.f / (nrm > 1e-12f ? nrm : 1e-12f);
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)row * C + c);
+        if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+        *reinterpret_cast<f32x4*>(y + (int64_t)row * ldy + c) = v * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Siamese temporal attention, one workgroup (4 waves) per clip.  qk rows hold the
+// BN-folded Q (first D) and K (next D) projections of the T frames.
+//   q_i, k_j L2-normalised; S = q k^T (T x T); P = softmax_j(S);
+//   pooled = sum_i sum_j P_ij x_j = sum_j (sum_i P_ij) x_j ; pooled /= |pooled|
+constexpr int ATT_TMAX = 16;
+__global__ __launch_bounds__(256) void siamese_attn_kernel(const float* __restrict__ qk,
+                                                           const float* __restrict__ x,
+                                                           float* __restrict__ pooled, int T,
+                                                           int D, int C, int64_t ldy) {
+    __shared__ float inv_norm[2 * ATT_TMAX];
+    __shared__ float S[ATT_TMAX][ATT_TMAX];
+    __shared__ float colw[ATT_TMAX];
+    __shared__ float red[16];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = qk + (int64_t)b * T * 2 * D;
+    // row norms of Q_i (index i) and K_j (index T + j)
+    for (int r = wave; r < 2 * T; r += 4) {
+        const float* p = base + (int64_t)(r % T) * 2 * D + (r / T) * D;
+        float s = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + k);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        s = wave_sum(s);
+        if (lane == 0) inv_norm[r] = 1.f / sqrtf(s);
+    }
+    __syncthreads();
+    for (int ij = wave; ij < T * T; ij += 4) {
+        const int i = ij / T, j = ij - i * T;
+        const float* q = base + (int64_t)i * 2 * D;
+        const float* k = base + (int64_t)j * 2 * D + D;
+        float s = 0.f;
+        for (int e = lane * 4; e < D; e += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(q + e);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(k + e);
+            s += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+        s = wave_sum(s);
+        if (lane == 0) S[i][j] = s * inv_norm[i] * inv_norm[T + j];
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {                      // softmax of row i, in place
+        const int i = threadIdx.x;
+        float mx = S[i][0];
+        for (int j = 1; j < T; ++j) mx = S[i][j] > mx ? S[i][j] : mx;
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float e = expf(S[i][j] - mx); S[i][j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < T; ++j) S[i][j] *= inv;
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+        float s = 0.f;
+        for (int i = 0; i < T; ++i) s += S[i][threadIdx.x];
+        colw[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const float* xb = x + (int64_t)b * T * C;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T; ++j) acc += *reinterpret_cast<const f32x4*>(xb + (int64_t)j * C + c) * colw[j];
+        ss += acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3];
+        *reinterpret_cast<f32x4*>(pooled + (int64_t)b * ldy + c) = acc;
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.f / sqrtf(ss);
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float* p = pooled + (int64_t)b * ldy + c;
+        *reinterpret_cast<f32x4*>(p) = *reinterpret_cast<const f32x4*>(p) * inv;   // own element
+    }
+}
+
+__global__ void mean_T_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int C,
+                              int64_t ldy, int64_t total4) {
+    const int C4 = C >> 2;
+    const float inv = 1.f / T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / C4;
+        const int c = (i - b * C4) * 4;
+        const float* xp = x + b * T * C + c;
+        f32x4 s = *reinterpret_cast<const f32x4*>(xp);
+        for (int t = 1; t < T; ++t) s += *reinterpret_cast<const f32x4*>(xp + (int64_t)t * C);
+        *reinterpret_cast<f32x4*>(y + b * ldy + c) = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, int K, int ld) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    float ss = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)row * ld + k);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) out[row] = ss;
+}
+
+// Pair verification head (Siamese.py:127-140), eval mode:
+//   out[i][j][c] = bias[c] + sum_k W[c][k] * (scale[k]*(p[i][k]-g[j][k])^2 + shift[k])
+// one wave per (i, j) pair; ncls <= 4.
+__global__ __launch_bounds__(256) void pair_verify_kernel(
+    const float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int np, int ng, int K, int ncls) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= np * ng) return;
+    const int i = pair / ng, j = pair - i * ng;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)i * K + k);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(g + (int64_t)j * K + k);
+        f32x4 d = a - b;
+        d = d * d;
+        if (scale) d = d * *reinterpret_cast<const f32x4*>(scale + k) + *reinterpret_cast<const f32x4*>(shift + k);
+        for (int c = 0; c < ncls; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)c * K + k);
+            acc[c] += d[0] * wv[0] + d[1] * wv[1] + d[2] * wv[2] + d[3] * wv[3];
+        }
+    }
+    for (int c = 0; c < ncls; ++c) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0) out[(int64_t)pair * ncls + c] = s + (bias ? bias[c] : 0.f);
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_pack_conv_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream) {
+    GRL_REQUIRE(w && out && N > 0 && C > 0 && kh > 0 && kw > 0, "pack_conv_weight: bad args");
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for((int64_t)N * C * kh * kw)), dim3(256), 0,
+                       (hipStream_t)stream, w, out, N, C, kh * kw);
+    return grl_check_launch("grl_pack_conv_weight");
+}
+
+extern "C" int grl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                           const float* bias, float eps, float* scale, float* shift, int C, void* stream) {
+    GRL_REQUIRE(shift && C > 0, "bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(grl_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, mean, var, bias, eps, scale, shift, C);
+    return grl_check_launch("grl_bn_fold");
+}
+
+extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* scale, const float* shift,
+                                float* y, int n, int H, int W, void* stream) {
+    GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem: null/empty");
+    GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grl_ceil_div(Wo, ST), grl_ceil_div(Ho, ST), n), dim3(256), 0,
+                       (hipStream_t)stream, x, w, scale, shift, y, H, W);
+    return grl_check_launch("grl_stem_conv7x7");
+}
+
+extern "C" int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream) {
+    GRL_REQUIRE(x && y && n > 0 && C % 4 == 0, "maxpool: bad args");
+    const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, C);
+    return grl_check_launch("grl_maxpool3x3s2");
+}
+
+extern "C" int grl_group_mean(const float* x, float* y, int groups, int rows, int C, int ldy, float out_scale,
+                              int accumulate, void* stream) {
+    GRL_REQUIRE(x && y && groups > 0 && rows > 0 && C % 4 == 0 && ldy % 4 == 0, "group_mean: bad args");
+    hipLaunchKernelGGL(group_mean_kernel, dim3(grl_ceil_div(C, 256), groups), dim3(256), 0, (hipStream_t)stream,
+                       x, y, rows, C, ldy, out_scale / rows, accumulate);
+    return grl_check_launch("grl_group_mean");
+}
+
+extern "C" int grl_gce_gate(const float* h, const float* w3, const float* bn_scale, const float* bn_shift,
+                            const float* x, float* corr_map, float* x_corr, float* x_uncorr, int M, int Ch, int C,
+                            void* stream) {
+    GRL_REQUIRE(h && w3 && bn_scale && bn_shift && x && x_corr && x_uncorr, "gce_gate: null");
+    GRL_REQUIRE(M > 0 && Ch % 4 == 0 && C % 4 == 0, "gce_gate: bad shape");
+    hipLaunchKernelGGL(gce_gate_kernel, dim3(grl_ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream, h, w3, bn_scale,
+                       bn_shift, x, corr_map, x_corr, x_uncorr, M, Ch, C);
+    return grl_check_launch("grl_gce_gate");
+}
+
+extern "C" int grl_temporal_mean(const float* x, float* y, int b, int T, int64_t inner, void* stream) {
+    GRL_REQUIRE(x && y && b > 0 && T > 0 && inner % 4 == 0, "temporal_mean: bad args");
+    const int64_t total4 = (int64_t)b * inner / 4;
+    hipLaunchKernelGGL(temporal_mean_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, T,
+                       inner / 4, total4);
+    return grl_check_launch("grl_temporal_mean");
+}
+
+extern "C" int grl_sqdiff_mean(const float* f1, const float* f2, float* d, int b, int rows, int C,
+                               int64_t f2_clip_stride, void* stream) {
+    GRL_REQUIRE(f1 && f2 && d && b > 0 && rows > 0 && C % 4 == 0 && f2_clip_stride % 4 == 0, "sqdiff_mean: bad args");
+    hipLaunchKernelGGL(sqdiff_mean_kernel, dim3(grl_ceil_div(C, 256), b), dim3(256), 0, (hipStream_t)stream, f1, f2,
+                       d, rows, C, f2_clip_stride);
+    return grl_check_launch("grl_sqdiff_mean");
+}
+
+extern "C" int grl_channel_atte(const float* d, const float* w1, const float* w2t, const float* gap,
+                                int64_t gap_stride, float* catte, float* fstep, int64_t fstep_stride, int accumulate,
+                                int b, int C, int Hd, void* stream) {
+    GRL_REQUIRE(d && w1 && w2t && gap && fstep && b > 0, "channel_atte: null");
+    GRL_REQUIRE(C % 4 == 0 && gap_stride % 4 == 0 && fstep_stride % 4 == 0, "channel_atte: alignment");
+    const size_t lds = (size_t)(C + Hd) * sizeof(float);
+    hipLaunchKernelGGL(channel_atte_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, d, w1, w2t, gap,
+                       gap_stride, catte, fstep, fstep_stride, accumulate, C, Hd);
+    return grl_check_launch("grl_channel_atte");
+}
+
+extern "C" int grl_add_strided(const float* a, const float* b, float* y, int nb, int64_t inner, int64_t b_clip_stride,
+                               void* stream) {
+    GRL_REQUIRE(a && b && y && nb > 0 && inner % 4 == 0 && b_clip_stride % 4 == 0, "add_strided: bad args");
+    const int64_t total4 = (int64_t)nb * inner / 4;
+    hipLaunchKernelGGL(add_strided_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                       inner / 4, b_clip_stride / 4, total4);
+    return grl_check_launch("grl_add_strided");
+}
+
+extern "C" int grl_affine_l2norm(const float* x, const float* scale, const float* shift, float* y, int rows, int C,
+                                 int64_t ldy, void* stream) {
+    GRL_REQUIRE(x && y && rows > 0 && C % 4 == 0 && ldy % 4 == 0, "affine_l2norm: bad args");
+    GRL_REQUIRE((scale == nullptr) == (shift == nullptr), "affine_l2norm: scale/shift come together");
+    hipLaunchKernelGGL(affine_l2norm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, C, ldy);
+    return grl_check_launch("grl_affine_l2norm");
+}
+
+extern "C" int grl_siamese_attn(const float* qk, const float* x, float* pooled, int b, int T, int D, int C,
+                                int64_t ldy, void* stream) {
+    GRL_REQUIRE(qk && x && pooled && b > 0, "siamese_attn: null");
+    GRL_REQUIRE(T >= 1 && T <= ATT_TMAX && D % 4 == 0 && C % 4 == 0 && ldy % 4 == 0, "siamese_attn: bad shape (T<=16)");
+    hipLaunchKernelGGL(siamese_attn_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, qk, x, pooled, T, D, C, ldy);
+    return grl_check_launch("grl_siamese_attn");
+}
+
+extern "C" int grl_mean_T(const float* x, float* y, int b, int T, int C, int64_t ldy, void* stream) {
+    GRL_REQUIRE(x && y && b > 0 && T > 0 && C % 4 == 0 && ldy % 4 == 0, "mean_T: bad args");
+    const int64_t total4 = (int64_t)b * C / 4;
+    hipLaunchKernelGGL(mean_T_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, T, C, ldy, total4);
+    return grl_check_launch("grl_mean_T");
+}
+
+extern "C" int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* stream) {
+    GRL_REQUIRE(x && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "row_sqnorm: bad args");
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, out, K, ld);
+    return grl_check_launch("grl_row_sqnorm");
+}
+
+extern "C" int grl_pair_verify(const float* p, const float* g, const float* scale, const float* shift,
+                               const float* w, const float* bias, float* out, int np, int ng, int K, int ncls,
+                               void* stream) {
+    GRL_REQUIRE(p && g && w && out && np > 0 && ng > 0, "pair_verify: null/empty");
+    GRL_REQUIRE(K % 4 == 0 && ncls >= 1 && ncls <= 4, "pair_verify: K % 4, ncls <= 4");
+    GRL_REQUIRE((scale == nullptr) == (shift == nullptr), "pair_verify: scale/shift come together");
+    hipLaunchKernelGGL(pair_verify_kernel, dim3(grl_ceil_div((int64_t)np * ng, 4)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, scale, shift, w, bias, out, np, ng, K, ncls);
+    return grl_check_launch("grl_pair_verify");
+}

@@ -1,0 +1,427 @@
+"""Host-side orchestration of the GRL hot path on MI355X.
+
+Python here only owns device memory (torch tensors), weight packing caches and
+the launch order; every FLOP is issued through the C ABI in include/grl_hip.h
+(libgrl_hip.so, hand-written HIP for gfx950).  Activations are channels-last
+row-major matrices [N*H*W][C] from the stem to the TRL head.
+
+Reference call sites (relative to /root/reference):
+  grl_forward             reid/models/grl_model.py:211-228
+    trunk                 reid/models/resnets1.py:73-93,101-109
+    GCE                   reid/models/basebranch.py:52-68
+    TRL                   reid/models/grl_model.py:131-180
+  siamese_self_attention  reid/models/Siamese.py:79-106
+  extract_features        reid/evaluator/attevaluator.py:100-112
+  cosin_dist/pairwise     reid/evaluator/attevaluator.py:33-46
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, check, ptr, require_device
+
+BN_EPS = 1e-5
+PIX = 128            # 16 x 8 feature map of layer4 (basebranch.py:59 hard-codes it)
+
+
+# ----------------------------------------------------------------------------
+# thin launch wrappers
+# ----------------------------------------------------------------------------
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
+         ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
+         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None):
+    """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
+    (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution."""
+    d = GrlGemm()
+    d.a, d.w, d.y = ptr(a), ptr(w), ptr(y)
+    d.scale, d.shift, d.res = ptr(scale), ptr(shift), ptr(res)
+    d.gbias, d.rowscale = ptr(gbias), ptr(rowscale)
+    d.rnorm, d.cnorm, d.stats = ptr(rnorm), ptr(cnorm), ptr(stats)
+    d.M, d.N, d.K = M, N, K
+    d.lda = lda or K
+    d.ldw = ldw or K
+    d.ldy = ldy or N
+    d.ldres = ldres or N
+    d.rows_per_group = rows_per_group
+    d.relu = 1 if relu else 0
+    d.epilogue = epilogue
+    if conv is not None:
+        d.conv = 1
+        (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
+    check(_lib.load().grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+    return y
+
+
+def _call(name, *args):
+    check(getattr(_lib.load(), name)(*args, _lib.stream()), name)
+
+
+# ----------------------------------------------------------------------------
+# packed parameters
+# ----------------------------------------------------------------------------
+class _Conv(object):
+    """A conv (or linear) with its eval-folded affine."""
+    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin')
+
+
+def _state_key(module):
+    return tuple((t.data_ptr(), t._version) for t in
+                 list(module.parameters()) + list(module.buffers()))
+
+
+class EvalPlan(object):
+    """Device-side packing of a model's parameters for the eval forward:
+    3x3 weights re-laid tap-major, BatchNorm folded to scale/shift, Q|K weights
+    concatenated.  Rebuilt whenever a parameter/buffer changes (version
+    counters), so load_state_dict / optimizer steps are picked up."""
+
+    def __init__(self, module):
+        self.key = _state_key(module)
+        self.dev = next(module.parameters()).device
+        self._vecs = []
+
+    # -- helpers ---------------------------------------------------------------
+    def fold(self, bn=None, bias=None, n=None):
+        """(scale, shift) of eval BN (optionally after a biased layer)."""
+        n = n if n is not None else (bn.num_features if bn is not None else bias.numel())
+        scale = torch.empty(n, dtype=torch.float32, device=self.dev)
+        shift = torch.empty(n, dtype=torch.float32, device=self.dev)
+        if bn is not None:
+            _call('grl_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                  ptr(bn.running_var), ptr(bias), C.c_float(bn.eps), ptr(scale), ptr(shift), n)
+        else:
+            _call('grl_bn_fold', None, None, None, None, ptr(bias), C.c_float(0.0), ptr(scale),
+                  ptr(shift), n)
+        return scale, shift
+
+    def conv(self, conv, bn=None, bias_only=False):
+        c = _Conv()
+        w = conv.weight.detach()
+        c.N, c.cin = w.shape[0], w.shape[1]
+        c.k = w.shape[2] if w.dim() == 4 else 1
+        c.stride = conv.stride[0] if hasattr(conv, 'stride') else 1
+        if c.k == 1:
+            c.w = w.contiguous().view(c.N, c.cin)
+        else:
+            c.w = torch.empty(c.N, c.k * c.k * c.cin, dtype=torch.float32, device=self.dev)
+            _call('grl_pack_conv_weight', ptr(w.contiguous()), ptr(c.w), c.N, c.cin, c.k, c.k)
+        c.K = c.w.shape[1]
+        c.ldw = c.K
+        bias = getattr(conv, 'bias', None)
+        if bn is not None:
+            c.scale, c.shift = self.fold(bn, bias.detach() if bias is not None else None)
+        elif bias is not None:
+            c.scale, c.shift = None, bias.detach()
+        else:
+            c.scale, c.shift = None, None
+        return c
+
+
+class GrlEvalPlan(EvalPlan):
+    def __init__(self, model):
+        super().__init__(model)
+        bb = model.backbone
+        base = bb.base
+        self.stem_w = base[0].weight.detach().contiguous()
+        self.stem_scale, self.stem_shift = self.fold(base[1])
+        self.blocks = []
+        for li in (4, 5, 6, 7):
+            for blk in base[li]:
+                e = dict(c1=self.conv(blk.conv1, blk.bn1), c2=self.conv(blk.conv2, blk.bn2),
+                         c3=self.conv(blk.conv3, blk.bn3), down=None, stride=blk.stride)
+                if blk.downsample is not None:
+                    e['down'] = self.conv(blk.downsample[0], blk.downsample[1])
+                self.blocks.append(e)
+        # GCE (basebranch.py:38-50)
+        self.glo_fc = self.conv(bb.glo_fc[0], bb.glo_fc[1])
+        self.corr0 = self.conv(bb.corr_atte[0], bb.corr_atte[1])        # [1024][3072]
+        self.corr2 = self.conv(bb.corr_atte[2], bb.corr_atte[3])
+        self.corr5_w = bb.corr_atte[5].weight.detach().contiguous().view(-1)
+        self.corr6_scale, self.corr6_shift = self.fold(bb.corr_atte[6])
+        # TRL (grl_model.py:93-128)
+        trl = model.temporal_learning_block
+        self.dirs = []
+        for f1, f2, mlp, memo in (
+                (trl.forward_f1, trl.forward_f2, trl.channel_atte_foreward_corr, trl.uncorr_memo_forward),
+                (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward)):
+            self.dirs.append(dict(
+                f1=self.conv(f1[0]), f2=self.conv(f2[0]),
+                w1=mlp[0].weight.detach().contiguous(),
+                w2t=mlp[2].weight.detach().t().contiguous(),
+                c1=self.conv(memo.conv1, memo.bn1), c2=self.conv(memo.conv2, memo.bn2),
+                c3=self.conv(memo.conv3, memo.bn3)))
+        self.corr_bn = self.fold(model.corr_bn)
+        self.uncorr_bn = self.fold(model.uncorr_bn)
+
+
+class SiameseEvalPlan(EvalPlan):
+    def __init__(self, siam):
+        super().__init__(siam)
+        self.D = siam.featQ.out_features
+        self.wqk = torch.cat((siam.featQ.weight.detach(), siam.featK.weight.detach()), 0).contiguous()
+        sq, hq = self.fold(siam.featQ_bn, siam.featQ.bias.detach())
+        sk, hk = self.fold(siam.featK_bn, siam.featK.bias.detach())
+        self.scale = torch.cat((sq, sk)).contiguous()
+        self.shift = torch.cat((hq, hk)).contiguous()
+
+
+_plans = weakref.WeakKeyDictionary()
+
+
+def _plan(module, cls):
+    p = _plans.get(module)
+    if p is None or p.key != _state_key(module) or not isinstance(p, cls):
+        p = cls(module)
+        _plans[module] = p
+    return p
+
+
+# ----------------------------------------------------------------------------
+# eval forward
+# ----------------------------------------------------------------------------
+def _conv_layer(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
+    """x: [n_img*H*W][cin] channels-last.  Returns (y, Ho, Wo)."""
+    if c.k == 1 and stride == 1:
+        M = n_img * H * W
+        y = _new((M, c.N), x)
+        gemm(x, c.w, y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu, **kw)
+        return y, H, W
+    pad = c.k // 2
+    Ho = (H + 2 * pad - c.k) // stride + 1
+    Wo = (W + 2 * pad - c.k) // stride + 1
+    M = n_img * Ho * Wo
+    y = _new((M, c.N), x)
+    gemm(x, c.w, y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu,
+         conv=(H, W, c.cin, Ho, Wo, c.k, c.k, stride, pad), **kw)
+    return y, Ho, Wo
+
+
+def _to_nchw(y, n, H, W):
+    return y.view(n, H, W, -1).permute(0, 3, 1, 2)
+
+
+def trunk_eval(plan, x, taps=None):
+    """x [n,3,H,W] NCHW -> channels-last [n*16*8][2048] (for 256x128 input)."""
+    n, _, H, W = x.shape
+    Hs, Ws = H // 2, W // 2
+    stem = _new((n * Hs * Ws, 64), x)
+    _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+          ptr(stem), n, H, W)
+    Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
+    cur = _new((n * Hp * Wp, 64), x)
+    _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)
+    if taps is not None:
+        taps['stem'] = _to_nchw(stem, n, Hs, Ws)
+        taps['pool'] = _to_nchw(cur, n, Hp, Wp)
+    del stem
+    H, W = Hp, Wp
+    counts = (3, 4, 6, 3)
+    bi = 0
+    for li, nb in enumerate(counts):
+        for _ in range(nb):
+            e = plan.blocks[bi]
+            bi += 1
+            s = e['stride']
+            o1, _, _ = _conv_layer(cur, e['c1'], n, H, W)
+            o2, Ho, Wo = _conv_layer(o1, e['c2'], n, H, W, stride=s)
+            if e['down'] is not None:
+                res, _, _ = _conv_layer(cur, e['down'], n, H, W, stride=s, relu=False)
+            else:
+                res = cur
+            cur, _, _ = _conv_layer(o2, e['c3'], n, Ho, Wo, res=res)
+            H, W = Ho, Wo
+        if taps is not None:
+            taps['layer%d' % (li + 1)] = _to_nchw(cur, n, H, W)
+    return cur, H, W
+
+
+def gce_eval(plan, x4, b, t, taps=None):
+    """x4 [b*t*128][2048] -> (x_uncorr, x_corr) same shape, corr_map [b*t*128]."""
+    M = x4.shape[0]
+    x_glo = _new((b, 2048), x4)
+    _call('grl_group_mean', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
+    g = plan.glo_fc
+    glo = _new((b, 1024), x4)
+    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True)
+    # W.[x; g] = Wx.x + Wg.g : the broadcast-concat of basebranch.py:59-61 becomes a
+    # per-clip bias added inside the accumulator epilogue.
+    c0 = plan.corr0
+    gb = _new((b, 1024), x4)
+    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072)
+    h1 = _new((M, 1024), x4)
+    gemm(x4, c0.w, h1, M, 1024, 2048, ldw=3072, gbias=gb, rows_per_group=t * PIX,
+         scale=c0.scale, shift=c0.shift, relu=False)
+    c2 = plan.corr2
+    h2 = _new((M, 256), x4)
+    gemm(h1, c2.w, h2, M, 256, 1024, scale=c2.scale, shift=c2.shift, relu=True)
+    cmap = _new((M,), x4)
+    xc = _new((M, 2048), x4)
+    xu = _new((M, 2048), x4)
+    _call('grl_gce_gate', ptr(h2), ptr(plan.corr5_w), ptr(plan.corr6_scale), ptr(plan.corr6_shift),
+          ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 256, 2048)
+    if taps is not None:
+        taps['x_glo'], taps['glo'] = x_glo, glo
+        taps['corr_map'] = cmap.view(b * t, 1, 16, 8)
+    return xu, xc, cmap
+
+
+def trl_eval(plan, xu, xc, b, t, taps=None):
+    """xu, xc [b][t][128][2048] (flat) -> f_uncorr [b][2048], f_corr [b][t][2048]."""
+    Cc = 2048
+    frame = PIX * Cc
+    Mb = b * PIX
+    memo0 = _new((Mb, Cc), xu)
+    _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
+    gapc = _new((b * t, Cc), xu)
+    _call('grl_group_mean', ptr(xc), ptr(gapc), b * t, PIX, Cc, Cc, C.c_float(1.0), 0)
+    # conv_f2(x_corr_i) does not depend on the recurrence: one GEMM over all T per direction
+    f2 = []
+    for d in plan.dirs:
+        y = _new((b * t * PIX, Cc), xu)
+        gemm(xc, d['f2'].w, y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True)
+        f2.append(y)
+    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device)
+    memo = [memo0, memo0]
+    dvec = _new((b, Cc), xu)
+    catte = _new((b, Cc), xu) if taps is not None else None
+    for i in range(t):
+        for di, d in enumerate(plan.dirs):
+            ti = i if di == 0 else t - 1 - i
+            f1 = _new((Mb, Cc), xu)
+            gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
+            _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+            _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
+                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0])
+            if taps is not None:
+                taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
+            s = _new((Mb, Cc), xu)
+            _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
+            o = _new((Mb, 512), xu)
+            c1, c2, c3 = d['c1'], d['c2'], d['c3']
+            gemm(s, c1.w, o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True)
+            o2 = _new((Mb, 512), xu)
+            gemm(o, c2.w, o2, Mb, 512, 512, scale=c2.scale, shift=c2.shift, relu=True)
+            nm = _new((Mb, Cc), xu)
+            gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True)
+            memo[di] = nm
+    f_uncorr = _new((b, Cc), xu)
+    _call('grl_group_mean', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
+    _call('grl_group_mean', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
+    if taps is not None:
+        taps['f_uncorr'], taps['f_corr'] = f_uncorr, fcorr
+    return f_uncorr, fcorr
+
+
+def _grl_eval(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
+    plan = _plan(model, GrlEvalPlan)
+    b, t, c, h, w = inputs.shape
+    if (c, h, w) != (3, 256, 128):
+        raise ValueError('GRL expects clips of [B,T,3,256,128] (got %s)' % (tuple(inputs.shape),))
+    x = inputs.contiguous().view(b * t, c, h, w)
+    x4, _, _ = trunk_eval(plan, x, taps)
+    xu, xc, _ = gce_eval(plan, x4, b, t, taps)
+    del x4
+    f_uncorr, f_corr = trl_eval(plan, xu, xc, b, t, taps)
+    x_corr = _new((b, t, 2048), inputs)
+    _call('grl_affine_l2norm', ptr(f_corr), ptr(plan.corr_bn[0]), ptr(plan.corr_bn[1]), ptr(x_corr),
+          b * t, 2048, 2048)
+    x_uncorr = out_uncorr if out_uncorr is not None else _new((b, 2048), inputs)
+    _call('grl_affine_l2norm', ptr(f_uncorr), ptr(plan.uncorr_bn[0]), ptr(plan.uncorr_bn[1]),
+          ptr(x_uncorr), b, 2048, ld_uncorr)
+    return x_uncorr, x_corr
+
+
+def grl_forward(model, inputs, taps=None):
+    """ResNet50_GRL_Model.forward.  eval(): folded-BN inference path.
+    train(): batch-statistics forward recorded for the HIP backward."""
+    require_device(inputs, 'inputs')
+    if inputs.dim() != 5:
+        raise ValueError('inputs must be [B,T,3,256,128]')
+    if model.training:
+        from . import train_engine
+        return train_engine.grl_forward_train(model, inputs)
+    with torch.no_grad():
+        return _grl_eval(model, inputs, taps)
+
+
+# ----------------------------------------------------------------------------
+# Siamese heads
+# ----------------------------------------------------------------------------
+def _attn_into(siam, x, out, ldy):
+    plan = _plan(siam, SiameseEvalPlan)
+    b, t, c = x.shape
+    x = x.contiguous()
+    qk = _new((b * t, 2 * plan.D), x)
+    gemm(x, plan.wqk, qk, b * t, 2 * plan.D, c, scale=plan.scale, shift=plan.shift)
+    _call('grl_siamese_attn', ptr(qk), ptr(x), ptr(out), b, t, plan.D, c, ldy)
+    return out
+
+
+def siamese_self_attention(siam, x):
+    require_device(x, 'input')
+    if siam.training:
+        from . import train_engine
+        return train_engine.siamese_self_attention_train(siam, x)
+    with torch.no_grad():
+        return _attn_into(siam, x, _new((x.shape[0], x.shape[2]), x), x.shape[2])
+
+
+def siamese_forward(siam, x):
+    require_device(x, 'input')
+    from . import train_engine
+    return train_engine.siamese_forward(siam, x)
+
+
+def siamese_video_forward(siamv, x):
+    require_device(x, 'input')
+    from . import train_engine
+    return train_engine.siamese_video_forward(siamv, x)
+
+
+def extract_features(cnn, siam, clips):
+    """attevaluator.py:100-112 in one pass: [b,T,3,256,128] -> [b,6144] =
+    cat(x_uncorr, self_attention(x_corr), mean_T(x_corr)), each written straight
+    into its slice of the feature row."""
+    require_device(clips, 'clips')
+    cnn = getattr(cnn, 'module', cnn)            # nn.DataParallel wrapper (mars_train.py:80)
+    if cnn.training or siam.training:
+        raise RuntimeError('extract_features needs cnn.eval() and siamese.eval()')
+    with torch.no_grad():
+        b, t = clips.shape[:2]
+        feat = _new((b, 6144), clips)
+        _, x_corr = _grl_eval(cnn, clips, out_uncorr=feat, ld_uncorr=6144)
+        _attn_into(siam, x_corr, feat[:, 2048:], 6144)
+        _call('grl_mean_T', ptr(x_corr), ptr(feat[:, 4096:]), b, t, 2048, 6144)
+        return feat
+
+
+# ----------------------------------------------------------------------------
+# evaluator distance matrices
+# ----------------------------------------------------------------------------
+def cosin_dist(qf, gf):
+    """-qf . gf^T  (attevaluator.py:44-46) as one fp32 MFMA GEMM."""
+    require_device(qf, 'qf'); require_device(gf, 'gf')
+    qf, gf = qf.contiguous(), gf.contiguous()
+    m, k = qf.shape
+    n = gf.shape[0]
+    out = _new((m, n), qf)
+    return gemm(qf, gf, out, m, n, k, epilogue=EPI_NEGDOT)
+
+
+def pairwise_distance_tensor(x, y):
+    """sqrt(clamp(|x|^2 + |y|^2 - 2 x.y^T, 1e-12))  (attevaluator.py:33-41)."""
+    require_device(x, 'x'); require_device(y, 'y')
+    m, n = x.shape[0], y.shape[0]
+    x, y = x.contiguous().view(m, -1), y.contiguous().view(n, -1)
+    k = x.shape[1]
+    rn, cn = _new((m,), x), _new((n,), x)
+    _call('grl_row_sqnorm', ptr(x), ptr(rn), m, k, k)
+    _call('grl_row_sqnorm', ptr(y), ptr(cn), n, k, k)
+    out = _new((m, n), x)
+    return gemm(x, y, out, m, n, k, epilogue=EPI_EUCLID, rnorm=rn, cnorm=cn)

@@ -1,0 +1,88 @@
+"""ATTEvaluator with the reference's constructor and methods
+(/root/reference/reid/evaluator/attevaluator.py:49-163).  Feature extraction and
+the query x gallery distance matrix run on the GPU through grl_amd.engine; the
+ranking metrics stay on the host."""
+import math
+
+import numpy as np
+import torch
+
+from grl_amd import engine
+from .eva_functions import evaluate
+from .rerank import re_ranking
+
+__all__ = ['ATTEvaluator', 'evaluate_seq', 'cosin_dist', 'pairwise_distance_tensor']
+
+
+def evaluate_seq(distmat, query_pids, query_camids, gallery_pids, gallery_camids, path,
+                 cmc_topk=(1, 5, 10, 20)):
+    """Prints mAP / Rank-k in the reference's format and returns Rank-1
+    (attevaluator.py:15-30)."""
+    cmc_scores, mAP = evaluate(distmat, np.array(query_pids), np.array(gallery_pids),
+                               np.array(query_camids), np.array(gallery_camids))
+    print('Mean AP: {:4.1%}'.format(mAP))
+    for r in cmc_topk:
+        print("Rank-{:<3}: {:.1%}".format(r, cmc_scores[r - 1]))
+    print("------------------")
+    return cmc_scores[0]
+
+
+def cosin_dist(qf, gf):
+    return engine.cosin_dist(qf, gf)
+
+
+def pairwise_distance_tensor(query_x, gallery_x):
+    return engine.pairwise_distance_tensor(query_x, gallery_x)
+
+
+class ATTEvaluator(object):
+    def __init__(self, cnn_model, Siamese_model, only_eval):
+        self.cnn_model = cnn_model
+        self.siamese_model = Siamese_model
+        self.only_eval = only_eval
+        self.chunk = 8            # clips per forward in dense mode (attevaluator.py:72-76)
+
+    def _device(self):
+        return next(self.cnn_model.parameters()).device
+
+    @torch.no_grad()
+    def extract_feature(self, data_loader):
+        self.cnn_model.eval()
+        self.siamese_model.eval()
+        dev = self._device()
+        feats, pids_all, cams_all = [], [], []
+        for imgs, pids, camids in data_loader:
+            if self.only_eval:
+                # dense mode: one tracklet per item, all its clips; features are averaged
+                # over clips (attevaluator.py:68-98)
+                b, n, s, c, h, w = imgs.size()
+                clips = imgs.view(b * n, s, c, h, w).to(dev, torch.float32)
+                parts = [engine.extract_features(self.cnn_model, self.siamese_model,
+                                                 clips[y * self.chunk:(y + 1) * self.chunk])
+                         for y in range(int(math.ceil(b * n / float(self.chunk))))]
+                feats.append(torch.cat(parts, 0).mean(dim=0, keepdim=True))
+            else:
+                clips = imgs.to(dev, torch.float32)
+                feats.append(engine.extract_features(self.cnn_model, self.siamese_model, clips))
+            pids_all.extend(pids)
+            cams_all.extend(camids)
+        return torch.cat(feats, 0), np.asarray(pids_all), np.asarray(cams_all)
+
+    def evaluate(self, query, gallery, query_loader, gallery_loader, path, visual, rerank):
+        if visual:
+            raise NotImplementedError('ranked-result visualisation is outside the GRL hot path')
+        qf, q_pids, q_camids = self.extract_feature(query_loader)
+        print('Done, obtained {}-by-{} matrix'.format(qf.size(0), qf.size(1)))
+        gf, g_pids, g_camids = self.extract_feature(gallery_loader)
+        gf = torch.cat((qf, gf), 0)               # query is prepended (attevaluator.py:143-145)
+        g_pids = np.append(q_pids, g_pids)
+        g_camids = np.append(q_camids, g_camids)
+        print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
+        print("Computing distance matrix")
+        distmat = cosin_dist(qf, gf).cpu().numpy()
+        if rerank:
+            print('Applying person re-ranking ...')
+            distmat_qq = pairwise_distance_tensor(qf, qf).cpu().numpy()
+            distmat_gg = pairwise_distance_tensor(gf, gf).cpu().numpy()
+            distmat = re_ranking(distmat, distmat_qq, distmat_gg)
+        return evaluate_seq(distmat, q_pids, q_camids, g_pids, g_camids, path)

@@ -1,0 +1,207 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (ctypes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    from grl_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 128, 64), (128, 64, 32), (300, 200, 96), (33, 1024, 2048),
+                                   (1000, 70, 160), (4096, 512, 2048), (129, 129, 32)])
+def test_gemm_bit_exact_vs_fma_chain(dev, M, N, K):
+    """Dense GEMM equals the C oracle's k-ordered fmaf chain bit for bit (all tile
+    configurations, ragged M/N edges)."""
+    from grl_amd import engine
+    from oracle.ref_c import chain_gemm
+    rng = np.random.default_rng(M * 7 + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    y = torch.empty(M, N, device=dev)
+    engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K)
+    got = y.cpu().numpy()
+    ref = chain_gemm(a, w)
+    assert _rel(got, a.astype(np.float64) @ w.astype(np.float64).T) < 1e-5
+    assert np.array_equal(got, ref), 'max diff %g' % np.abs(got - ref).max()
+
+
+def test_gemm_epilogue_affine_residual_relu_gbias(dev):
+    from grl_amd import engine
+    rng = np.random.default_rng(3)
+    M, N, K = 512, 192, 128
+    a, w = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    gb = rng.standard_normal((M // 128, N)).astype(np.float32)
+    rs = rng.uniform(0, 1, M).astype(np.float32)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    y = torch.empty(M, N, device=dev)
+    engine.gemm(t(a), t(w), y, M, N, K, scale=t(sc), shift=t(sh), res=t(res), gbias=t(gb),
+                rows_per_group=128, rowscale=t(rs), relu=True)
+    acc = a.astype(np.float64) @ w.T.astype(np.float64)
+    ref = np.maximum((acc * rs[:, None] + np.repeat(gb, 128, 0)) * sc + sh + res, 0)
+    assert _rel(y.cpu().numpy(), ref) < 1e-5
+    # strided output (writes into a slice of a wider row) and strided W (ldw > K)
+    wide = torch.zeros(M, N + 64, device=dev)
+    wpad = torch.from_numpy(np.concatenate([rng.standard_normal((N, 32)).astype(np.float32), w], 1)).to(dev)
+    engine.gemm(t(a), wpad[:, 32:], wide[:, 64:], M, N, K, ldw=K + 32, ldy=N + 64)
+    assert _rel(wide[:, 64:].cpu().numpy(), acc) < 1e-5
+    assert float(wide[:, :64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,H,W,n', [
+    (64, 64, 3, 1, 16, 8, 3), (128, 128, 3, 2, 16, 16, 2), (256, 512, 1, 2, 8, 8, 4),
+    (64, 256, 1, 1, 8, 4, 2), (512, 512, 3, 1, 16, 8, 2)])
+def test_conv_implicit_gemm_vs_torch(dev, cin, cout, k, stride, H, W, n):
+    """Implicit-GEMM conv (+ folded BN, ReLU, residual) vs F.conv2d on CPU."""
+    from grl_amd import engine
+    rng = np.random.default_rng(cin + cout + k)
+    x = torch.from_numpy(rng.standard_normal((n, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = F.conv2d(x, w, stride=stride, padding=k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    res = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    ref = F.relu(ref + res)
+    Ho, Wo = ref.shape[2:]
+    xl = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = torch.empty(cout, k * k * cin, device=dev)
+    from grl_amd._lib import ptr
+    engine._call('grl_pack_conv_weight', ptr(w.to(dev)), ptr(wp), cout, cin, k, k)
+    assert torch.equal(wp.cpu().view(cout, k * k, cin), w.view(cout, cin, k * k).permute(0, 2, 1))
+    y = torch.empty(n * Ho * Wo, cout, device=dev)
+    engine.gemm(xl, wp, y, n * Ho * Wo, cout, k * k * cin, scale=sc.to(dev), shift=sh.to(dev),
+                res=res.permute(0, 2, 3, 1).contiguous().to(dev), relu=True,
+                conv=(H, W, cin, Ho, Wo, k, k, stride, k // 2))
+    got = y.view(n, Ho, Wo, cout).permute(0, 3, 1, 2).cpu()
+    assert _rel(got.numpy(), ref.numpy()) < 1e-5
+
+
+def test_gemm_train_stats_slab(dev):
+    from grl_amd import engine, _lib
+    rng = np.random.default_rng(5)
+    M, N, K = 1000, 96, 64
+    a, w = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    d = _lib.GrlGemm(); d.M, d.N, d.K = M, N, K
+    rows = _lib.load().grl_conv_gemm_f32_stat_rows(C.byref(d))
+    stats = torch.zeros(rows, 2, N, device=dev)
+    y = torch.empty(M, N, device=dev)
+    engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K, stats=stats)
+    yy = y.cpu().double().numpy()
+    s = stats.sum(0).cpu().numpy()
+    assert _rel(s[0], yy.sum(0)) < 1e-5 and _rel(s[1], (yy ** 2).sum(0)) < 1e-5
+
+
+def test_stem_and_maxpool_vs_torch(dev):
+    from grl_amd import engine
+    from grl_amd._lib import ptr
+    rng = np.random.default_rng(9)
+    n, H, W = 2, 64, 32
+    x = torch.from_numpy(rng.standard_normal((n, 3, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(64).astype(np.float32) * 0.1)
+    ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y = torch.empty(n * (H // 2) * (W // 2), 64, device=dev)
+    engine._call('grl_stem_conv7x7', ptr(x.to(dev)), ptr(w.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(y), n, H, W)
+    got = y.view(n, H // 2, W // 2, 64).permute(0, 3, 1, 2).cpu()
+    assert _rel(got.numpy(), ref.numpy()) < 1e-5
+    pooled = torch.empty(n * (H // 4) * (W // 4), 64, device=dev)
+    engine._call('grl_maxpool3x3s2', ptr(y), ptr(pooled), n, H // 2, W // 2, 64)
+    refp = F.max_pool2d(got, 3, stride=2, padding=1)
+    assert torch.equal(pooled.view(n, H // 4, W // 4, 64).permute(0, 3, 1, 2).cpu(), refp)
+
+
+def test_pointwise_kernels_vs_torch(dev):
+    from grl_amd import engine
+    from grl_amd._lib import ptr
+    rng = np.random.default_rng(11)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    b, T, P, Cc = 3, 4, 128, 2048
+    x = t(b, T, P, Cc); xd = x.to(dev)
+    # group mean (GAP over pixels, GAP over pixels and T, accumulate)
+    y = torch.empty(b * T, Cc, device=dev)
+    engine._call('grl_group_mean', ptr(xd), ptr(y), b * T, P, Cc, Cc, C.c_float(1.0), 0)
+    assert _rel(y.cpu().numpy(), x.mean(2).view(b * T, Cc).numpy()) < 1e-5
+    y2 = torch.empty(b, Cc, device=dev)
+    engine._call('grl_group_mean', ptr(xd), ptr(y2), b, T * P, Cc, Cc, C.c_float(1.0), 0)
+    engine._call('grl_group_mean', ptr(xd), ptr(y2), b, T * P, Cc, Cc, C.c_float(1.0), 1)
+    assert _rel(y2.cpu().numpy(), 2 * x.mean((1, 2)).numpy()) < 1e-5
+    # temporal mean / add_strided / sqdiff_mean / mean_T
+    tm = torch.empty(b, P * Cc, device=dev)
+    engine._call('grl_temporal_mean', ptr(xd), ptr(tm), b, T, P * Cc)
+    assert _rel(tm.cpu().numpy(), x.mean(1).view(b, -1).numpy()) < 1e-6
+    a = t(b, P, Cc); ad = a.to(dev)
+    s = torch.empty(b, P * Cc, device=dev)
+    engine._call('grl_add_strided', ptr(ad), ptr(xd.view(-1)[2 * P * Cc:]), ptr(s), b, P * Cc, T * P * Cc)
+    assert torch.equal(s.cpu().view(b, P, Cc), a + x[:, 2])
+    d = torch.empty(b, Cc, device=dev)
+    engine._call('grl_sqdiff_mean', ptr(ad), ptr(xd.view(-1)[1 * P * Cc:]), ptr(d), b, P, Cc, T * P * Cc)
+    assert _rel(d.cpu().numpy(), (a - x[:, 1]).pow(2).mean(1).numpy()) < 1e-5
+    f = t(b, T, Cc); mt = torch.zeros(b, 3 * Cc, device=dev)
+    engine._call('grl_mean_T', ptr(f.to(dev)), ptr(mt[:, Cc:]), b, T, Cc, 3 * Cc)
+    assert _rel(mt[:, Cc:2 * Cc].cpu().numpy(), f.mean(1).numpy()) < 1e-6 and float(mt[:, :Cc].abs().max()) == 0
+    # GCE gate
+    M = 37
+    h, w3, xx = t(M, 256), t(256) * 0.1, t(M, Cc)
+    bs, bh = torch.tensor([0.8]), torch.tensor([-0.1])
+    cm, xc, xu = torch.empty(M, device=dev), torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+    engine._call('grl_gce_gate', ptr(h.to(dev)), ptr(w3.to(dev)), ptr(bs.to(dev)), ptr(bh.to(dev)), ptr(xx.to(dev)),
+                 ptr(cm), ptr(xc), ptr(xu), M, 256, Cc)
+    g = torch.sigmoid((h @ w3) * 0.8 - 0.1)
+    assert _rel(cm.cpu().numpy(), g.numpy()) < 1e-5
+    assert _rel(xc.cpu().numpy(), (xx * g[:, None]).numpy()) < 1e-5
+    assert _rel(xu.cpu().numpy(), (xx * (1 - g[:, None])).numpy()) < 1e-5
+    # channel attention + f_step accumulate
+    dv, w1, w2 = t(b, Cc).abs(), t(128, Cc) * 0.02, t(Cc, 128) * 0.1
+    gap = t(b, T, Cc); fs = t(b, T, Cc); fsd = fs.clone().to(dev)
+    ca = torch.empty(b, Cc, device=dev)
+    engine._call('grl_channel_atte', ptr(dv.to(dev)), ptr(w1.to(dev)), ptr(w2.t().contiguous().to(dev)),
+                 ptr(gap.to(dev)[:, 1]), T * Cc, ptr(ca), ptr(fsd.view(b * T, Cc)[2:]), T * Cc, 1, b, Cc, 128)
+    cref = torch.sigmoid(F.relu(dv @ w1.t()) @ w2.t())
+    assert _rel(ca.cpu().numpy(), cref.numpy()) < 1e-5
+    fref = fs.clone(); fref[:, 2] += gap[:, 1] * cref + gap[:, 1]
+    assert _rel(fsd.cpu().numpy(), fref.numpy()) < 1e-5
+    # affine + l2norm into a strided destination, row_sqnorm
+    v, sc, sh = t(5, Cc), t(Cc), t(Cc)
+    out = torch.zeros(5, 3 * Cc, device=dev)
+    engine._call('grl_affine_l2norm', ptr(v.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(out[:, Cc:]), 5, Cc, 3 * Cc)
+    assert _rel(out[:, Cc:2 * Cc].cpu().numpy(), F.normalize(v * sc + sh, dim=1).numpy()) < 1e-5
+    rn = torch.empty(5, device=dev)
+    engine._call('grl_row_sqnorm', ptr(v.to(dev)), ptr(rn), 5, Cc, Cc)
+    assert _rel(rn.cpu().numpy(), v.pow(2).sum(1).numpy()) < 1e-5
+    # bn fold
+    gm, bt, mu, var, bias = t(Cc).abs() + 0.5, t(Cc), t(Cc), t(Cc).abs() + 0.5, t(Cc)
+    so, ho = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    engine._call('grl_bn_fold', ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(mu.to(dev)), ptr(var.to(dev)), ptr(bias.to(dev)),
+                 C.c_float(1e-5), ptr(so), ptr(ho), Cc)
+    sref = gm / torch.sqrt(var + 1e-5)
+    assert _rel(so.cpu().numpy(), sref.numpy()) < 1e-6
+    assert _rel(ho.cpu().numpy(), (bt - mu * sref + bias * sref).numpy()) < 1e-5
+
+
+def test_empty_and_bad_arguments_raise(dev):
+    from grl_amd import engine
+    from grl_amd._lib import GrlHipError, ptr
+    x = torch.zeros(64, 48, device=dev)
+    with pytest.raises(GrlHipError):          # K not a multiple of 32
+        engine.gemm(x, x, torch.empty(64, 64, device=dev), 64, 64, 48)
+    with pytest.raises(GrlHipError):          # empty
+        engine.gemm(x, x, x, 0, 64, 32)
+    with pytest.raises(GrlHipError):          # T > 16
+        engine._call('grl_siamese_attn', ptr(x), ptr(x), ptr(x), 1, 17, 512, 2048, 2048)

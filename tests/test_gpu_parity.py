@@ -1,0 +1,149 @@
+"""End-to-end parity of the HIP path (through the reid API + C ABI) with the
+reference-generated golden vectors and the oracle, on a real MI355X.
+Tolerance: north_star asks <= 1e-3 relative fp32; the eval path is held to 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from grl_amd.synthetic import synth_clips, synth_eval_features
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def gpu_models(synth_models):
+    assert torch.cuda.is_available()
+    cnn, siam, siamv = synth_models
+    dev = torch.device('cuda:0')
+    return cnn.to(dev).eval(), siam.to(dev).eval(), siamv.to(dev).eval()
+
+
+def _sample_check(t, g, key, tol=TOL):
+    f = t.detach().cpu().contiguous().reshape(-1).double()
+    assert tuple(t.shape) == tuple(g[key + '.shape'])
+    assert _rel(f[torch.from_numpy(g[key + '.idx'])].numpy(), g[key + '.val']) < tol
+    assert abs(f.sum().item() - g[key + '.sum']) <= tol * g[key + '.abssum']
+
+
+def test_eval_forward_matches_reference_golden(golden, gpu_models):
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    g = golden('grl_eval_b2t4.npz')
+    clips = synth_clips(2, 4, seed=0).cuda()
+    taps = {}
+    xu, xc = engine.grl_forward(cnn, clips, taps=taps)
+    for k in ('stem', 'pool', 'layer1', 'layer2', 'layer3', 'layer4'):
+        _sample_check(taps[k], g, 'tap.' + k)
+    assert _rel(taps['corr_map'].cpu().numpy(), g['corr_map']) < TOL
+    assert _rel(torch.stack(taps['fwd_catte'])[:, :, ::16].cpu().numpy(), g['catte.fwd']) < TOL
+    assert _rel(torch.stack(taps['bwd_catte'])[:, :, ::16].cpu().numpy(), g['catte.bwd']) < TOL
+    assert _rel(taps['f_uncorr'].cpu().numpy(), g['f_uncorr']) < TOL
+    assert _rel(taps['f_corr'].cpu().numpy(), g['f_corr']) < TOL
+    assert _rel(xu.cpu().numpy(), g['x_uncorr']) < TOL
+    assert _rel(xc.cpu().numpy(), g['x_corr']) < TOL
+    # the module API (what mars_train.py / the evaluator call) gives the same tensors
+    xu2, xc2 = cnn(clips)
+    assert torch.equal(xu2, xu) and torch.equal(xc2, xc)
+    feat = engine.extract_features(cnn, siam, clips)
+    assert _rel(feat.cpu().numpy(), g['feat']) < TOL
+    pooled = siam.self_attention(xc)
+    assert torch.equal(torch.cat((xu, pooled, xc.mean(dim=1)), 1)[:, :4096], feat[:, :4096])
+
+
+def test_eval_forward_matches_oracle_other_shapes(gpu_models):
+    """T=8 (reference default seq_len) and an odd batch, against the oracle."""
+    from oracle import grl_oracle as O
+    cnn, siam, _ = gpu_models
+    sd = {k: v.detach().cpu() for k, v in cnn.state_dict().items()}
+    ssd = {k: v.detach().cpu() for k, v in siam.state_dict().items()}
+    for b, t, seed in ((1, 8, 3), (3, 2, 4)):
+        clips = synth_clips(b, t, seed=seed)
+        from grl_amd import engine
+        feat = engine.extract_features(cnn, siam, clips.cuda())
+        assert _rel(feat.cpu().numpy(), O.extract_features(sd, ssd, clips).numpy()) < TOL
+
+
+def test_features_do_not_depend_on_batch_composition(gpu_models):
+    """Eval BN is folded, clips are independent and every GEMM element is one
+    k-ordered accumulation chain whatever the tile shape, so a clip's feature row is
+    bit-identical in a batch of 32 (BASELINE size) and in a batch of 2."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    clips = synth_clips(32, 4, seed=5).cuda()
+    big = engine.extract_features(cnn, siam, clips)
+    assert big.shape == (32, 6144) and bool(torch.isfinite(big).all())
+    small = engine.extract_features(cnn, siam, clips[10:12].contiguous())
+    assert torch.equal(big[10:12], small)
+    nrm = big.view(32, 3, 2048).norm(dim=2)
+    assert float((nrm[:, :2] - 1).abs().max()) < 1e-5       # unit-norm blocks
+    again = engine.extract_features(cnn, siam, clips)
+    assert torch.equal(big, again)                          # run-to-run deterministic
+
+
+def test_siamese_heads_match_reference_golden(golden, gpu_models):
+    _, siam, siamv = gpu_models
+    g = golden('siamese_b4t4.npz')
+    x = torch.from_numpy(g['x']).cuda()
+    assert _rel(siam.self_attention(x).cpu().numpy(), g['eval.attn']) < TOL
+    cls, out = siam(x)
+    assert _rel(cls.cpu().numpy(), g['eval.cls']) < TOL and _rel(out.cpu().numpy(), g['eval.out']) < TOL
+    cls, out = siamv(x[:, 0].contiguous())
+    assert _rel(cls.cpu().numpy(), g['eval.v_cls']) < TOL and _rel(out.cpu().numpy(), g['eval.v_out']) < TOL
+    x8 = torch.randn(2, 16, 2048, generator=torch.Generator().manual_seed(1))
+    from oracle import grl_oracle as O
+    ssd = {k: v.detach().cpu() for k, v in siam.state_dict().items()}
+    assert _rel(siam.self_attention(x8.cuda()).cpu().numpy(), O.self_attention(ssd, x8).numpy()) < TOL
+
+
+def test_evaluator_matches_reference_golden(golden):
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    from oracle.ref_c import chain_gemm
+    g = golden('evaluator_q40_g400.npz')
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    d = engine.cosin_dist(qf.cuda(), gf.cuda()).cpu().numpy()
+    assert _rel(d, g['dist']) < 2e-5
+    # bit-exact against the fma-chain oracle => ranking indices bit-exact
+    ref = chain_gemm(qf.numpy(), gf.numpy(), mode=1)
+    assert np.array_equal(d, ref)
+    assert np.array_equal(np.argsort(d, axis=1), np.argsort(ref, axis=1))
+    # against the reference's own BLAS ranking: only rounding-level neighbours may swap
+    resorted = np.take_along_axis(g['dist'], np.argsort(d, axis=1), 1)
+    assert (resorted[:, :-1] - resorted[:, 1:]).max() <= 3e-5
+    cmc, mAP = evaluate(d, qp, gp, qc, gc)
+    assert np.allclose(cmc[:20], g['cmc'], atol=1e-6) and abs(mAP - float(g['mAP'])) < 1e-6
+    e = engine.pairwise_distance_tensor(qf.cuda(), qf.cuda()).cpu().numpy()
+    assert _rel(e ** 2, g['euclid_qq'] ** 2) < 1e-5
+    qd = qf.view(20, 2, -1).mean(1); gd = torch.cat((qd, gf[40:240]), 0)
+    assert _rel(engine.cosin_dist(qd.cuda(), gd.cuda()).cpu().numpy(), g['dist_dense']) < 2e-5
+    e = engine.pairwise_distance_tensor(qd.cuda(), gd.cuda()).cpu().numpy()
+    assert _rel(e ** 2, g['euclid_dense'] ** 2) < 1e-5
+
+
+def test_evaluator_full_mars_size_properties():
+    """BASELINE config 5: 1980 x 11310 x 6144.  Bit-exact against the C oracle on a
+    row sample, symmetry D(q,g) == D(g,q)^T, self-distance and Euclid/-dot
+    consistency on unit-norm-triple rows (|q-g|^2 = 6 - 2 q.g)."""
+    from grl_amd import engine
+    from oracle.ref_c import chain_gemm
+    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1)
+    qd, gd = qf.cuda(), gf.cuda()
+    d = engine.cosin_dist(qd, gd)
+    assert d.shape == (1980, 11310)
+    rows = np.array([0, 1, 31, 32, 127, 128, 777, 1919, 1951, 1979])
+    ref = chain_gemm(qf.numpy()[rows], gf.numpy(), mode=1)
+    got = d.cpu().numpy()
+    assert np.array_equal(got[rows], ref)
+    assert np.array_equal(np.argsort(got[rows], axis=1), np.argsort(ref, axis=1))
+    dt = engine.cosin_dist(gd, qd)
+    assert torch.equal(dt.t(), d)
+    diag = got[np.arange(1980), np.arange(1980)]
+    assert np.abs(diag + 3.0).max() < 1e-5 and (got.argmin(1) == np.arange(1980)).all()
+    e = engine.pairwise_distance_tensor(qd[:256], gd)
+    assert float((e ** 2 - (6 + 2 * d[:256])).abs().max()) < 1e-4

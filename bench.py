@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: clip-features/sec of the GRL eval path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic MARS-shaped clips
+(BASELINE.json configs[1]: B x T = 32 x 4, 256 x 128, fp32): ResNet-50 trunk + GCE +
+TRL + Siamese temporal attention + concat -> one 6144-d feature row per clip
+(reference: reid/evaluator/attevaluator.py:100-112).  Inputs are resident in HBM
+before the timed region.  With --gpus N (launched by torch.distributed.run, one rank
+per GPU) every rank processes its own batch: clips are independent, there is no
+data-path collective (weak scaling); the barrier only brackets the timed region.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, T = 32, 4
+GFLOP_PER_CLIP = 57.94 + 0.017          # conv+linear fwd at T=4, + Siamese Q/K
+PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_models(dev):
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625,
+                            pretrained=False)
+    siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    sd = synth_state_dict(cnn, seed=0)
+    ssd = synth_state_dict(siam, seed=0, prefix='siamese.')
+    cnn.load_state_dict(sd)
+    siam.load_state_dict(ssd)
+    return cnn.to(dev).eval(), siam.to(dev).eval(), sd, ssd
+
+
+def gemm_roofline(cnn, siam, clips, iters=3):
+    """Live per-launch timing of the dominant kernel (gemm_f32_kernel: every conv /
+    linear of the path) with HIP events on the launch stream, outside the timed
+    region.  achieved = algorithmic FLOPs of all its launches in one step (2*M*N*K per
+    launch, counted by the host wrapper) / sum of their measured durations."""
+    from grl_amd import engine
+    recs = []
+    orig = engine.gemm
+
+    def timed(a, w, y, M, N, K, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(a, w, y, M, N, K, *args, **kw)
+        e1.record()
+        recs.append((2.0 * M * N * K, e0, e1))
+        return out
+
+    engine.gemm = timed
+    try:
+        for _ in range(iters):
+            engine.extract_features(cnn, siam, clips)
+        torch.cuda.synchronize()
+    finally:
+        engine.gemm = orig
+    flops = sum(r[0] for r in recs) / iters
+    ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
+    launches = len(recs) // iters
+    return flops, ms, launches
+
+
+def cpu_baseline(sd, ssd):
+    """The oracle (plain PyTorch-CPU restatement of the reference path) timed on this
+    node's host cores on a bounded sample of the same workload."""
+    from oracle import grl_oracle as O
+    from grl_amd.synthetic import synth_clips
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O.extract_features(sd, ssd, synth_clips(2, T, seed=1))        # warm-up (allocator, threads)
+    nb = 16
+    clips = synth_clips(nb, T, seed=0)
+    t0 = time.time()
+    O.extract_features(sd, ssd, clips)
+    dt = time.time() - t0
+    return {"value": round(nb / dt, 3), "unit": "clip-features/sec", "cores": cores,
+            "kind": "port",
+            "sample": "oracle.extract_features (torch CPU fp32, %d threads) on %d of the %d "
+                      "clips of one step, T=%d, 1 timed pass (%.1f s)" % (cores, nb, B, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local if world > 1 else 0)
+
+    from grl_amd import engine, _lib
+    from grl_amd.synthetic import synth_clips
+    _lib.load()
+    cnn, siam, sd, ssd = build_models(dev)
+    clips = synth_clips(B, T, seed=rank).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        feat = engine.extract_features(cnn, siam, clips)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feat = engine.extract_features(cnn, siam, clips)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(feat).all())
+
+    if rank == 0:
+        n = max(world, 1)
+        value = n * B * args.steps / dt
+        flops, gemm_ms, launches = gemm_roofline(cnn, siam, clips)
+        achieved = flops / (gemm_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_gemm_pmc.json')
+        if os.path.isfile(pmc):
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
+        out = {
+            "metric": "clip-features/sec", "value": round(value, 2), "unit": "clip-features/sec",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GRL eval clip features (ResNet-50 s1 trunk + GCE + TRL + "
+                                   "Siamese attention -> 6144-d), BASELINE configs[1]",
+                       "clips_per_gpu": B, "seq_len": T, "frame": "256x128",
+                       "parallelism": "replicas x%d (no collective)" % n},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "gemm_f32_kernel (fp32 MFMA implicit-GEMM conv), %d launches/step, "
+                                   "%.3f ms/step, %.1f algorithmic GFLOP/step" % (launches, gemm_ms, flops / 1e9)},
+            "end_to_end_tflops": round(value / n * GFLOP_PER_CLIP / 1e3, 2),
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, ssd)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

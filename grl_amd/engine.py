@@ -110,7 +110,8 @@ class EvalPlan(object):
             c.w = w.contiguous().view(c.N, c.cin)
         else:
             c.w = torch.empty(c.N, c.k * c.k * c.cin, dtype=torch.float32, device=self.dev)
-            _call('grl_pack_conv_weight', ptr(w.contiguous()), ptr(c.w), c.N, c.cin, c.k, c.k)
+            wc = w.contiguous()          # must outlive the launch below
+            _call('grl_pack_conv_weight', ptr(wc), ptr(c.w), c.N, c.cin, c.k, c.k)
         c.K = c.w.shape[1]
         c.ldw = c.K
         bias = getattr(conv, 'bias', None)

@@ -82,7 +82,8 @@ def test_conv_implicit_gemm_vs_torch(dev, cin, cout, k, stride, H, W, n):
     xl = x.permute(0, 2, 3, 1).contiguous().to(dev)
     wp = torch.empty(cout, k * k * cin, device=dev)
     from grl_amd._lib import ptr
-    engine._call('grl_pack_conv_weight', ptr(w.to(dev)), ptr(wp), cout, cin, k, k)
+    wd = w.to(dev)
+    engine._call('grl_pack_conv_weight', ptr(wd), ptr(wp), cout, cin, k, k)
     assert torch.equal(wp.cpu().view(cout, k * k, cin), w.view(cout, cin, k * k).permute(0, 2, 1))
     y = torch.empty(n * Ho * Wo, cout, device=dev)
     engine.gemm(xl, wp, y, n * Ho * Wo, cout, k * k * cin, scale=sc.to(dev), shift=sh.to(dev),
@@ -118,7 +119,8 @@ def test_stem_and_maxpool_vs_torch(dev):
     sh = torch.from_numpy(rng.standard_normal(64).astype(np.float32) * 0.1)
     ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     y = torch.empty(n * (H // 2) * (W // 2), 64, device=dev)
-    engine._call('grl_stem_conv7x7', ptr(x.to(dev)), ptr(w.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(y), n, H, W)
+    xd, wd, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)     # keep alive across the launch
+    engine._call('grl_stem_conv7x7', ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(y), n, H, W)
     got = y.view(n, H // 2, W // 2, 64).permute(0, 3, 1, 2).cpu()
     assert _rel(got.numpy(), ref.numpy()) < 1e-5
     pooled = torch.empty(n * (H // 4) * (W // 4), 64, device=dev)
@@ -153,15 +155,16 @@ def test_pointwise_kernels_vs_torch(dev):
     d = torch.empty(b, Cc, device=dev)
     engine._call('grl_sqdiff_mean', ptr(ad), ptr(xd.view(-1)[1 * P * Cc:]), ptr(d), b, P, Cc, T * P * Cc)
     assert _rel(d.cpu().numpy(), (a - x[:, 1]).pow(2).mean(1).numpy()) < 1e-5
-    f = t(b, T, Cc); mt = torch.zeros(b, 3 * Cc, device=dev)
-    engine._call('grl_mean_T', ptr(f.to(dev)), ptr(mt[:, Cc:]), b, T, Cc, 3 * Cc)
+    f = t(b, T, Cc); mt = torch.zeros(b, 3 * Cc, device=dev); fd = f.to(dev)
+    engine._call('grl_mean_T', ptr(fd), ptr(mt[:, Cc:]), b, T, Cc, 3 * Cc)
     assert _rel(mt[:, Cc:2 * Cc].cpu().numpy(), f.mean(1).numpy()) < 1e-6 and float(mt[:, :Cc].abs().max()) == 0
     # GCE gate
     M = 37
     h, w3, xx = t(M, 256), t(256) * 0.1, t(M, Cc)
     bs, bh = torch.tensor([0.8]), torch.tensor([-0.1])
     cm, xc, xu = torch.empty(M, device=dev), torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
-    engine._call('grl_gce_gate', ptr(h.to(dev)), ptr(w3.to(dev)), ptr(bs.to(dev)), ptr(bh.to(dev)), ptr(xx.to(dev)),
+    hd, w3d, bsd, bhd, xxd = h.to(dev), w3.to(dev), bs.to(dev), bh.to(dev), xx.to(dev)
+    engine._call('grl_gce_gate', ptr(hd), ptr(w3d), ptr(bsd), ptr(bhd), ptr(xxd),
                  ptr(cm), ptr(xc), ptr(xu), M, 256, Cc)
     g = torch.sigmoid((h @ w3) * 0.8 - 0.1)
     assert _rel(cm.cpu().numpy(), g.numpy()) < 1e-5
@@ -171,8 +174,9 @@ def test_pointwise_kernels_vs_torch(dev):
     dv, w1, w2 = t(b, Cc).abs(), t(128, Cc) * 0.02, t(Cc, 128) * 0.1
     gap = t(b, T, Cc); fs = t(b, T, Cc); fsd = fs.clone().to(dev)
     ca = torch.empty(b, Cc, device=dev)
-    engine._call('grl_channel_atte', ptr(dv.to(dev)), ptr(w1.to(dev)), ptr(w2.t().contiguous().to(dev)),
-                 ptr(gap.to(dev)[:, 1]), T * Cc, ptr(ca), ptr(fsd.view(b * T, Cc)[2:]), T * Cc, 1, b, Cc, 128)
+    dvd, w1d, w2td, gapd = dv.to(dev), w1.to(dev), w2.t().contiguous().to(dev), gap.to(dev)
+    engine._call('grl_channel_atte', ptr(dvd), ptr(w1d), ptr(w2td),
+                 ptr(gapd[:, 1]), T * Cc, ptr(ca), ptr(fsd.view(b * T, Cc)[2:]), T * Cc, 1, b, Cc, 128)
     cref = torch.sigmoid(F.relu(dv @ w1.t()) @ w2.t())
     assert _rel(ca.cpu().numpy(), cref.numpy()) < 1e-5
     fref = fs.clone(); fref[:, 2] += gap[:, 1] * cref + gap[:, 1]
@@ -180,15 +184,17 @@ def test_pointwise_kernels_vs_torch(dev):
     # affine + l2norm into a strided destination, row_sqnorm
     v, sc, sh = t(5, Cc), t(Cc), t(Cc)
     out = torch.zeros(5, 3 * Cc, device=dev)
-    engine._call('grl_affine_l2norm', ptr(v.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(out[:, Cc:]), 5, Cc, 3 * Cc)
+    vd, scd, shd = v.to(dev), sc.to(dev), sh.to(dev)
+    engine._call('grl_affine_l2norm', ptr(vd), ptr(scd), ptr(shd), ptr(out[:, Cc:]), 5, Cc, 3 * Cc)
     assert _rel(out[:, Cc:2 * Cc].cpu().numpy(), F.normalize(v * sc + sh, dim=1).numpy()) < 1e-5
     rn = torch.empty(5, device=dev)
-    engine._call('grl_row_sqnorm', ptr(v.to(dev)), ptr(rn), 5, Cc, Cc)
+    engine._call('grl_row_sqnorm', ptr(vd), ptr(rn), 5, Cc, Cc)
     assert _rel(rn.cpu().numpy(), v.pow(2).sum(1).numpy()) < 1e-5
     # bn fold
     gm, bt, mu, var, bias = t(Cc).abs() + 0.5, t(Cc), t(Cc), t(Cc).abs() + 0.5, t(Cc)
     so, ho = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
-    engine._call('grl_bn_fold', ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(mu.to(dev)), ptr(var.to(dev)), ptr(bias.to(dev)),
+    dd = [z.to(dev) for z in (gm, bt, mu, var, bias)]
+    engine._call('grl_bn_fold', ptr(dd[0]), ptr(dd[1]), ptr(dd[2]), ptr(dd[3]), ptr(dd[4]),
                  C.c_float(1e-5), ptr(so), ptr(ho), Cc)
     sref = gm / torch.sqrt(var + 1e-5)
     assert _rel(so.cpu().numpy(), sref.numpy()) < 1e-6

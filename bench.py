@@ -57,7 +57,7 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         e0.record()
         out = orig(a, w, y, M, N, K, *args, **kw)
         e1.record()
-        recs.append((2.0 * M * N * K, e0, e1))
+        recs.append((2.0 * M * N * K, e0, e1, (M, N, K, kw.get('conv'))))
         return out
 
     engine.gemm = timed
@@ -70,6 +70,16 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
     launches = len(recs) // iters
+    if os.environ.get('GRL_GEMM_REPORT'):
+        agg = {}
+        for f, a, b2, shape in recs:
+            e = agg.setdefault(str(shape), [0, 0.0, f])
+            e[0] += 1
+            e[1] += a.elapsed_time(b2)
+        rows = sorted(((k, v[0] // iters, v[1] / iters, v[2]) for k, v in agg.items()), key=lambda r: -r[2])
+        with open(os.environ['GRL_GEMM_REPORT'], 'w') as fh:
+            for k, cnt, tms, f in rows:
+                fh.write('%-60s calls %3d  total %8.3f ms  %7.1f TF/s\n' % (k, cnt, tms, f * cnt / (tms * 1e-3) / 1e12))
     return flops, ms, launches
 
 
@@ -78,10 +88,12 @@ def cpu_baseline(sd, ssd):
     node's host cores on a bounded sample of the same workload."""
     from oracle import grl_oracle as O
     from grl_amd.synthetic import synth_clips
-    cores = os.cpu_count() or 1
+    # PyTorch-CPU convs stop scaling (and then regress) long before a 2-socket host's
+    # full core count; 32 threads was the fastest setting measured on the GPU node.
+    cores = min(os.cpu_count() or 1, int(os.environ.get('GRL_CPU_THREADS', '32')))
     torch.set_num_threads(cores)
     O.extract_features(sd, ssd, synth_clips(2, T, seed=1))        # warm-up (allocator, threads)
-    nb = 16
+    nb = 8
     clips = synth_clips(nb, T, seed=0)
     t0 = time.time()
     O.extract_features(sd, ssd, clips)

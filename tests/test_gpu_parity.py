@@ -144,6 +144,6 @@ def test_evaluator_full_mars_size_properties():
     dt = engine.cosin_dist(gd, qd)
     assert torch.equal(dt.t(), d)
     diag = got[np.arange(1980), np.arange(1980)]
-    assert np.abs(diag + 3.0).max() < 1e-5 and (got.argmin(1) == np.arange(1980)).all()
+    assert np.abs(diag + 3.0).max() < 5e-5 and (got.argmin(1) == np.arange(1980)).all()
     e = engine.pairwise_distance_tensor(qd[:256], gd)
     assert float((e ** 2 - (6 + 2 * d[:256])).abs().max()) < 1e-4

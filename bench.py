@@ -89,8 +89,8 @@ def cpu_baseline(sd, ssd):
     from oracle import grl_oracle as O
     from grl_amd.synthetic import synth_clips
     # PyTorch-CPU convs stop scaling (and then regress) long before a 2-socket host's
-    # full core count; 32 threads was the fastest setting measured on the GPU node.
-    cores = min(os.cpu_count() or 1, int(os.environ.get('GRL_CPU_THREADS', '32')))
+    # full core count; 16 threads was the fastest setting measured on the GPU node.
+    cores = min(os.cpu_count() or 1, int(os.environ.get('GRL_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
     O.extract_features(sd, ssd, synth_clips(2, T, seed=1))        # warm-up (allocator, threads)
     nb = 8

@@ -40,7 +40,7 @@ _SIGNATURES = {
     'grl_temporal_mean': ([_fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_sqdiff_mean': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_channel_atte': ([_fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, C.c_int, C.c_int, C.c_int,
-                          C.c_int, _fp], C.c_int),
+                          C.c_int, _fp, _fp], C.c_int),
     'grl_add_strided': ([_fp, _fp, _fp, C.c_int, _i64, _i64, _fp], C.c_int),
     'grl_affine_l2norm': ([_fp, _fp, _fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_siamese_attn': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),

@@ -38,7 +38,7 @@ struct RowInfo {          // per staged A row: where it comes from
 
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
-                                                           const int num_tiles) {
+                                                           const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
@@ -179,6 +179,61 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     // ---- epilogue --------------------------------------------------------------
     // acc[i][j][r] is Y[row][col] with row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31
     const int col_l = lane & 31;
+
+    if (vec_epi) {
+        // Wide path (N, ldy, ldres multiples of 4, 16-B aligned bases): each wave parks its
+        // sub-tile in LDS (the A/B stages are dead: the K loop ended on a barrier) and
+        // reads it back row-major, so every lane owns 4 consecutive channels of one
+        // row: float4 scale/shift/residual loads and 256-B contiguous row segments per
+        // 16 lanes on the store, instead of 64 dword-wide store instructions.
+        float* Cs = smem;                                   // [BM][BN]
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + wn * WTN +
+                       j * 32 + col_l] = acc[i][j][r];
+        constexpr int LPR = WTN / 4;                        // lanes per row
+        constexpr int RPI = 64 / LPR;                       // rows per pass
+        const int lrow = lane / LPR, lcol = (lane % LPR) * 4;
+        const int n = n0 + wn * WTN + lcol;
+        if (n < p.N) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, cn = sh;
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            if (p.epilogue == GRL_EPI_EUCLID) cn = *reinterpret_cast<const f32x4*>(p.cnorm + n);
+#pragma unroll 4
+            for (int it = 0; it < WTM / RPI; ++it) {
+                const int row = wm * WTM + it * RPI + lrow;
+                const int m = m0 + row;
+                if (m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol);
+                    if (p.epilogue == GRL_EPI_AFFINE) {
+                        if (p.rowscale) v *= p.rowscale[m];
+                        if (p.gbias)
+                            v += *reinterpret_cast<const f32x4*>(
+                                p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n);
+                        v = v * sc + sh;
+                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                    } else if (p.epilogue == GRL_EPI_NEGDOT) {
+                        v = -v;
+                    } else {
+                        v = p.rnorm[m] + cn - 2.f * v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = sqrtf(v[e] > 1e-12f ? v[e] : 1e-12f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                }
+            }
+        }
+        return;
+    }
     float csum[NT], csq[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
@@ -263,14 +318,19 @@ int launch(const GrlGemm& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    static_assert((size_t)BM * BN <= (size_t)2 * (BM + BN) * BK, "C staging must fit the A/B stages");
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
+                         (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
+                         al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (d.conv) {
         auto k = gemm_f32_kernel<BM, BN, true>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     } else {
         auto k = gemm_f32_kernel<BM, BN, false>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
 }

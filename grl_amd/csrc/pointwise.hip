@@ -230,47 +230,50 @@ __global__ void add_strided_kernel(const float* __restrict__ a, const float* __r
 }
 
 // ---------------------------------------------------------------------------------
-// Channel attention of one TRL step, one workgroup per clip.
-//   hid = relu(W1 d)  (W1 [Hd][C], one wave per hidden unit, lanes stride C)
-//   c   = sigmoid(W2 hid) (W2T [Hd][C]: lanes stride the output channel)
-//   fstep (+)= (1 + c) * gap
-__global__ __launch_bounds__(256) void channel_atte_kernel(
-    const float* __restrict__ d, const float* __restrict__ w1, const float* __restrict__ w2t,
-    const float* __restrict__ gap, int64_t gap_stride, float* __restrict__ catte,
-    float* __restrict__ fstep, int64_t fstep_stride, int accumulate, int C, int Hd) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* ds = sm;            // [C]
-    float* hid = sm + C;       // [Hd]
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x * 4; c < C; c += 1024)
-        *reinterpret_cast<f32x4*>(ds + c) = *reinterpret_cast<const f32x4*>(d + (int64_t)b * C + c);
-    __syncthreads();
-    for (int j = wave; j < Hd; j += 4) {
-        float s = 0.f;
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (int64_t)j * C + c);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ds + c);
-            s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
-        }
-        s = wave_sum(s);
-        if (lane == 0) hid[j] = s > 0.f ? s : 0.f;
+// Channel attention of one TRL step (b clips, C channels, Hd hidden units), two
+// launches so that the 2 x 1 MB of MLP weights are streamed by the whole chip instead
+// of by one workgroup per clip:
+//   hid[b][j] = relu(W1[j] . d[b])           one wave per (clip, hidden unit)
+//   c[b][n]   = sigmoid(sum_j W2T[j][n] hid[b][j]);  fstep (+)= (1 + c) * gap
+__global__ __launch_bounds__(256) void channel_hidden_kernel(const float* __restrict__ d,
+                                                             const float* __restrict__ w1,
+                                                             float* __restrict__ hid, int C, int Hd,
+                                                             int total) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= total) return;
+    const int b = idx / Hd, j = idx - b * Hd;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (int64_t)j * C + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d + (int64_t)b * C + c);
+        s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
     }
+    s = wave_sum(s);
+    if (lane == 0) hid[idx] = s > 0.f ? s : 0.f;
+}
+
+__global__ __launch_bounds__(256) void channel_atte_out_kernel(
+    const float* __restrict__ hid, const float* __restrict__ w2t, const float* __restrict__ gap,
+    int64_t gap_stride, float* __restrict__ catte, float* __restrict__ fstep, int64_t fstep_stride,
+    int accumulate, int C, int Hd) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];      // [Hd]
+    const int b = blockIdx.y;
+    for (int j = threadIdx.x; j < Hd; j += 256) hs[j] = hid[(int64_t)b * Hd + j];
     __syncthreads();
-    for (int c = threadIdx.x * 4; c < C; c += 1024) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < Hd; ++j)
-            s += *reinterpret_cast<const f32x4*>(w2t + (int64_t)j * C + c) * hid[j];
-        f32x4 a;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < Hd; ++j) s += *reinterpret_cast<const f32x4*>(w2t + (int64_t)j * C + c) * hs[j];
+    f32x4 a;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = sigmoidf_(s[e]);
-        if (catte) *reinterpret_cast<f32x4*>(catte + (int64_t)b * C + c) = a;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gap + (int64_t)b * gap_stride + c);
-        // reference: mean(x*c + x) == gap*c + gap
-        f32x4 o = g * a + g;
-        float* fp = fstep + (int64_t)b * fstep_stride + c;
-        if (accumulate) o += *reinterpret_cast<const f32x4*>(fp);
-        *reinterpret_cast<f32x4*>(fp) = o;
-    }
+    for (int e = 0; e < 4; ++e) a[e] = sigmoidf_(s[e]);
+    if (catte) *reinterpret_cast<f32x4*>(catte + (int64_t)b * C + c) = a;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gap + (int64_t)b * gap_stride + c);
+    f32x4 o = g * a + g;                                   // reference: mean(x*c + x) == gap*c + gap
+    float* fp = fstep + (int64_t)b * fstep_stride + c;
+    if (accumulate) o += *reinterpret_cast<const f32x4*>(fp);
+    *reinterpret_cast<f32x4*>(fp) = o;
 }
 
 // y[row] = v / max(|v|, 1e-12), v = x[row]*scale + shift   (one workgroup per row)
@@ -505,12 +508,13 @@ extern "C" int grl_sqdiff_mean(const float* f1, const float* f2, float* d, int b
 
 extern "C" int grl_channel_atte(const float* d, const float* w1, const float* w2t, const float* gap,
                                 int64_t gap_stride, float* catte, float* fstep, int64_t fstep_stride, int accumulate,
-                                int b, int C, int Hd, void* stream) {
-    GRL_REQUIRE(d && w1 && w2t && gap && fstep && b > 0, "channel_atte: null");
+                                int b, int C, int Hd, float* hid_ws, void* stream) {
+    GRL_REQUIRE(d && w1 && w2t && gap && fstep && hid_ws && b > 0 && Hd > 0, "channel_atte: null");
     GRL_REQUIRE(C % 4 == 0 && gap_stride % 4 == 0 && fstep_stride % 4 == 0, "channel_atte: alignment");
-    const size_t lds = (size_t)(C + Hd) * sizeof(float);
-    hipLaunchKernelGGL(channel_atte_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, d, w1, w2t, gap,
-                       gap_stride, catte, fstep, fstep_stride, accumulate, C, Hd);
+    hipLaunchKernelGGL(channel_hidden_kernel, dim3(grl_ceil_div((int64_t)b * Hd, 4)), dim3(256), 0,
+                       (hipStream_t)stream, d, w1, hid_ws, C, Hd, b * Hd);
+    hipLaunchKernelGGL(channel_atte_out_kernel, dim3(grl_ceil_div(C, 1024), b), dim3(256), (size_t)Hd * sizeof(float),
+                       (hipStream_t)stream, hid_ws, w2t, gap, gap_stride, catte, fstep, fstep_stride, accumulate, C, Hd);
     return grl_check_launch("grl_channel_atte");
 }
 

@@ -291,6 +291,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     memo = [memo0, memo0]
     dvec = _new((b, Cc), xu)
     catte = _new((b, Cc), xu) if taps is not None else None
+    hid = _new((b, 128), xu)
     for i in range(t):
         for di, d in enumerate(plan.dirs):
             ti = i if di == 0 else t - 1 - i
@@ -298,7 +299,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
             gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
             _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
             _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0])
+                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
             if taps is not None:
                 taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
             s = _new((Mb, Cc), xu)

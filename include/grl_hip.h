@@ -121,7 +121,8 @@ int grl_sqdiff_mean(const float* f1, const float* f2, float* d, int b, int rows,
  * then f_step[b][c] (+)= (1 + c) * gap[b][c]   (grl_model.py:150-151,164-165). */
 int grl_channel_atte(const float* d, const float* w1 /*[Hd][C]*/, const float* w2t /*[Hd][C] = W2^T*/,
                      const float* gap, int64_t gap_stride, float* catte, float* fstep,
-                     int64_t fstep_stride, int accumulate, int b, int C, int Hd, void* stream);
+                     int64_t fstep_stride, int accumulate, int b, int C, int Hd,
+                     float* hid_ws /* workspace [b][Hd] */, void* stream);
 
 /* y = a + b elementwise (grl_model.py:68, memo + x_uncorr_t); b rows strided per clip */
 int grl_add_strided(const float* a, const float* b, float* y, int nb, int64_t inner,

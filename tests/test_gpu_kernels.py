@@ -173,10 +173,10 @@ def test_pointwise_kernels_vs_torch(dev):
     # channel attention + f_step accumulate
     dv, w1, w2 = t(b, Cc).abs(), t(128, Cc) * 0.02, t(Cc, 128) * 0.1
     gap = t(b, T, Cc); fs = t(b, T, Cc); fsd = fs.clone().to(dev)
-    ca = torch.empty(b, Cc, device=dev)
+    ca = torch.empty(b, Cc, device=dev); hidw = torch.empty(b, 128, device=dev)
     dvd, w1d, w2td, gapd = dv.to(dev), w1.to(dev), w2.t().contiguous().to(dev), gap.to(dev)
     engine._call('grl_channel_atte', ptr(dvd), ptr(w1d), ptr(w2td),
-                 ptr(gapd[:, 1]), T * Cc, ptr(ca), ptr(fsd.view(b * T, Cc)[2:]), T * Cc, 1, b, Cc, 128)
+                 ptr(gapd[:, 1]), T * Cc, ptr(ca), ptr(fsd.view(b * T, Cc)[2:]), T * Cc, 1, b, Cc, 128, ptr(hidw))
     cref = torch.sigmoid(F.relu(dv @ w1.t()) @ w2.t())
     assert _rel(ca.cpu().numpy(), cref.numpy()) < 1e-5
     fref = fs.clone(); fref[:, 2] += gap[:, 1] * cref + gap[:, 1]

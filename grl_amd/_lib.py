@@ -27,13 +27,19 @@ class GrlGemm(C.Structure):
                                     'kw', 'stride', 'pad')]
 
 
+class GrlWgrad(C.Structure):
+    _fields_ = [(n, _fp) for n in ('dz', 'x', 'dw', 'workspace')] + \
+               [(n, _i32) for n in ('M', 'N', 'K', 'ldz', 'ldx', 'k_out', 'accumulate', 'conv', 'H', 'W',
+                                    'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad')]
+
+
 _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
     'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),
-    'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_maxpool3x3s2': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_group_mean': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp], C.c_int),
     'grl_gce_gate': ([_fp] * 8 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
@@ -46,6 +52,33 @@ _SIGNATURES = {
     'grl_siamese_attn': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_mean_T': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_pair_verify': ([_fp] * 7 + [C.c_int] * 4 + [_fp], C.c_int),
+    'grl_col_stats_rows': ([C.c_int], C.c_int),
+    'grl_col_stats': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_slab_sum': ([_fp, C.c_int, _i64, C.c_int, _fp, C.c_int, _fp], C.c_int),
+    'grl_bn_stats_finalize': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
+                               _fp, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp], C.c_int),
+    'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
+    'grl_axpby': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
+    'grl_axpy_strided': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),
+    'grl_transpose': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_pack_dgrad_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_dilate2': ([_fp, _fp] + [C.c_int] * 6 + [_fp], C.c_int),
+    'grl_maxpool3x3s2_bwd': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_im2col': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_wgrad_workspace_floats': ([C.POINTER(GrlWgrad)], _i64),
+    'grl_conv_wgrad_f32': ([C.POINTER(GrlWgrad), _fp], C.c_int),
+    'grl_gate_apply': ([_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_gate_bwd': ([_fp, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_add_rowbcast': ([_fp, _fp, _i64, _i64, _i64, C.c_float, C.c_int, _fp], C.c_int),
+    'grl_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _i64, C.c_int, _fp], C.c_int),
+    'grl_catte_bwd': ([_fp, _i64, _fp, _i64, _fp, _fp, _fp, _i64, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_l2norm_bwd': ([_fp, _i64, _fp, _i64, _fp, _fp, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_siamese_attn_bwd': ([_fp, _fp, _fp, _i64, _fp, _i64, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_int, _fp], C.c_int),
+    'grl_pair_sqdiff': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_pair_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
 }
 

@@ -52,7 +52,7 @@ constexpr int SP = 2 * ST + 5;         // input patch edge (37)
 
 __global__ __launch_bounds__(256) void stem_conv7x7_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, int H, int W) {
+    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu) {
     __shared__ float patch[3][SP][SP + 1];
     const int Ho = H >> 1, Wo = W >> 1;
     const int img = blockIdx.z, oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = acc[o + e] * scale[o + e] + shift[o + e];
-                v[e] = t > 0.f ? t : 0.f;
+                v[e] = (t > 0.f || !relu) ? t : 0.f;
             }
             *reinterpret_cast<f32x4*>(yo + o) = v;
         }
@@ -456,12 +456,12 @@ extern "C" int grl_bn_fold(const float* gamma, const float* beta, const float* m
 }
 
 extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* scale, const float* shift,
-                                float* y, int n, int H, int W, void* stream) {
+                                float* y, int n, int H, int W, int relu, void* stream) {
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
     hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grl_ceil_div(Wo, ST), grl_ceil_div(Ho, ST), n), dim3(256), 0,
-                       (hipStream_t)stream, x, w, scale, shift, y, H, W);
+                       (hipStream_t)stream, x, w, scale, shift, y, H, W, relu);
     return grl_check_launch("grl_stem_conv7x7");
 }
 

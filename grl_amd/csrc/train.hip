@@ -1,0 +1,670 @@
+// Train-mode kernels of the GRL path for gfx950: batch-statistics BatchNorm
+// (forward finalize/apply, backward reduce/apply), ReLU/max-pool/gating backward,
+// weight-gradient GEMM (reduction over pixels, split over workgroups, deterministic
+// slab reduction) and the layout helpers the data-gradient path needs.
+//
+// Reference semantics: torch.nn.BatchNorm{1,2}d in training mode as used by
+// reid/models/resnets1.py:76-91, basebranch.py:38-50, grl_model.py:71-83,203-226,
+// Siamese.py:84-94,135-139 (biased variance for normalisation, unbiased variance and
+// momentum 0.1 for the running estimate), and autograd's backward of those modules
+// (reid/train/trainer.py:54).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int CHUNK = 128;     // rows per partial of the column reductions
+
+// ---------------------------------------------------------------------------------
+// column statistics of x[M][C] (row stride ld): slab[chunk][0][c] = sum, [1][c] = sum sq
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ slab, int M, int C,
+                                                        int ld) {
+    __shared__ f32x4 red[2][4][64];
+    const int chunk = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+    if (c < C) {
+        const int r1 = min(M, (chunk + 1) * CHUNK);
+        for (int r = chunk * CHUNK + wave; r < r1; r += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c);
+            s += v; q += v * v;
+        }
+    }
+    red[0][wave][lane] = s; red[1][wave][lane] = q;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        s = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        q = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 0) * C + c) = s;
+        *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 1) * C + c) = q;
+    }
+}
+
+// out[c] (+)= sum_r slab[r*stride + c]
+__global__ void slab_sum_kernel(const float* __restrict__ slab, int rows, int64_t stride, int C,
+                                float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += slab[(int64_t)r * stride + c];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+// BN forward finalize: batch mean / biased var from the partial slab, running-stat
+// update (PyTorch: running = (1-m)*running + m*stat, unbiased var for the running
+// estimate), folded scale/shift for the apply pass.
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+                                         double count, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum,
+                                         float eps, float* mean, float* invstd, float* scale,
+                                         float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += slab[((int64_t)r * 2 + 0) * C + c];
+        q += slab[((int64_t)r * 2 + 1) * C + c];
+    }
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * is;
+    shift[c] = b - (float)mu * g * is;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = relu?(z*scale + shift + res)
+__global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ res,
+                                float* __restrict__ y, int C4, int64_t total4, int relu) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
+        v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+        if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// BN backward, pass 1: g = dy * (act > 0) ; slab[chunk][0][c] = sum g, [1][c] = sum g*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
+    int M, int C) {
+    __shared__ f32x4 red[2][4][64];
+    const int chunk = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+    if (c < C) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const int r1 = min(M, (chunk + 1) * CHUNK);
+        for (int r = chunk * CHUNK + wave; r < r1; r += 4) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)r * C + c);
+            if (act) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(act + (int64_t)r * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + (int64_t)r * C + c) - mu) * is;
+            s += g; q += g * xh;
+        }
+    }
+    red[0][wave][lane] = s; red[1][wave][lane] = q;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        s = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        q = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 0) * C + c) = s;
+        *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 1) * C + c) = q;
+    }
+}
+
+// finalize pass 1: dgamma += sum g*xhat, dbeta += sum g, coef[0][c] = sum g / M,
+// coef[1][c] = sum g*xhat / M
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+                                       double count, float* dgamma, float* dbeta,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += slab[((int64_t)r * 2 + 0) * C + c];
+        q += slab[((int64_t)r * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] += (float)s;
+    if (dgamma) dgamma[c] += (float)q;
+    coef[c] = (float)(s / count);
+    coef[C + c] = (float)(q / count);
+}
+
+// pass 2: dz = gamma*invstd * (g - mean_g - xhat * mean_gx)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                    const float* __restrict__ act, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ coef, float* __restrict__ dz, int C,
+                                    int64_t total4) {
+    const int C4 = C >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        if (act) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 xh = (reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c)) * is;
+        f32x4 gm = is;
+        if (gamma) gm = gm * *reinterpret_cast<const f32x4*>(gamma + c);
+        reinterpret_cast<f32x4*>(dz)[i] =
+            gm * (g - *reinterpret_cast<const f32x4*>(coef + c) - xh * *reinterpret_cast<const f32x4*>(coef + C + c));
+    }
+}
+
+// out = (accumulate ? out : 0) + dy * (act > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
+                                float* __restrict__ out, int64_t total4, int accumulate) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        if (act) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        }
+        if (accumulate) g += reinterpret_cast<const f32x4*>(out)[i];
+        reinterpret_cast<f32x4*>(out)[i] = g;
+    }
+}
+
+// y = alpha*a + beta*b (b may be NULL)
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                             float* __restrict__ y, float alpha, float beta, int64_t total4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * alpha;
+        if (b) v += reinterpret_cast<const f32x4*>(b)[i] * beta;
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// dst[b*dstride + i] (+)= alpha * src[b*sstride + i]   (i < inner)
+__global__ void axpy_strided_kernel(float* __restrict__ dst, int64_t dstride4,
+                                    const float* __restrict__ src, int64_t sstride4, int64_t inner4,
+                                    float alpha, int accumulate, int64_t total4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / inner4, r = i - b * inner4;
+        f32x4 v = reinterpret_cast<const f32x4*>(src)[b * sstride4 + r] * alpha;
+        f32x4* d = reinterpret_cast<f32x4*>(dst) + b * dstride4 + r;
+        if (accumulate) v += *d;
+        *d = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// layout helpers
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C,
+                                 int ldx) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = x[(int64_t)(r0 + j) * ldx + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) y[(int64_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
+// data-gradient weights of a kxk conv: out[c][kk-1-t][n] = w[n][c][t]
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                         int N, int C, int taps) {
+    const int64_t total = (int64_t)N * C * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i % N;
+        const int t = (i / N) % taps;
+        const int c = i / ((int64_t)N * taps);
+        out[i] = w[((int64_t)n * C + c) * taps + (taps - 1 - t)];
+    }
+}
+
+// zero-stuffing for stride-2 data gradients: up[img][2oy][2ox][:] = dz[img][oy][ox][:]
+__global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__ up, int Ho, int Wo,
+                               int H, int W, int C4, int64_t total4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        int64_t r = i / C4;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int img = r / H;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+            v = reinterpret_cast<const f32x4*>(dz)[(((int64_t)img * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c];
+        reinterpret_cast<f32x4*>(up)[i] = v;
+    }
+}
+
+// max-pool 3x3/s2/p1 backward, gather form (deterministic): an input pixel receives
+// dy of every window in which it is the FIRST maximum in (ky,kx) scan order -- the
+// element torch.nn.MaxPool2d records as argmax.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dx, int H, int W, int C4, int64_t total4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C = C4 * 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int ix = r % W; r /= W;
+        const int iy = r % H;
+        const int img = r / H;
+        const float* xi = x + (int64_t)img * H * W * C + c;
+        const f32x4 me = *reinterpret_cast<const f32x4*>(xi + ((int64_t)iy * W + ix) * C);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows (oy, ox) with 2*o-1 <= i <= 2*o+1:  o in [i>>1, (i+1)>>1]
+        for (int oy = iy >> 1; oy <= ((iy + 1) >> 1); ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox) {
+                if (ox >= Wo) continue;
+                // is (iy,ix) the first max of window (oy,ox)?
+                bool first[4] = {true, true, true, true};
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        if (yy == iy && xx == ix) continue;
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(xi + ((int64_t)yy * W + xx) * C);
+                        const bool before = (yy < iy) || (yy == iy && xx < ix);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (o[e] > me[e] || (before && o[e] == me[e])) first[e] = false;
+                    }
+                }
+                const f32x4 d = *reinterpret_cast<const f32x4*>(
+                    dy + (((int64_t)img * Ho + oy) * Wo + ox) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+}
+
+// stem im2col for the 7x7 weight gradient: col[m][k], k = (c*7+ky)*7+kx, padded to Kp
+__global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int H, int W,
+                                   int Kp, int64_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = i % Kp;
+        int64_t m = i / Kp;
+        const int ox = m % Wo; m /= Wo;
+        const int oy = m % Ho;
+        const int img = m / Ho;
+        float v = 0.f;
+        if (k < 147) {
+            const int c = k / 49, ky = (k / 7) % 7, kx = k % 7;
+            const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = x[(((int64_t)img * 3 + c) * H + iy) * W + ix];
+        }
+        col[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Weight-gradient GEMM:  dW[n][k] = sum_m dz[m][n] * Xg[m][k]   (reduction over pixels)
+// Both operands are stored with the reduction index as the ROW, so a stage is a copy of
+// 32 rows of dz (BM floats) and 32 (gathered) rows of X (BN floats) into LDS as
+// [kr][out]; lane (i = l&31, h = l>>5) feeds v_mfma_f32_32x32x2_f32 with
+// A = tile[2s+h][i] by ds_read_b32 (consecutive lanes -> consecutive banks).
+// grid = (tiles, splits): each split reduces its own pixel range into its own slab.
+struct WgradArgs {
+    const float* dz; const float* x; float* slab;
+    int M, N, K;                 // pixels, Cout, taps*C
+    int ldz, ldx;
+    int64_t slab_stride;         // N*K
+    int chunk;                   // pixels per split (multiple of 32)
+    int conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
+    constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
+    constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // float4 per thread per stage (32 rows)
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;         // threads per row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][32][BM]
+    float* Bs = smem + 2 * 32 * BM;        // [2][32][BN]
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * BM, k0 = tile_k * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_begin = blockIdx.y * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    int tap = 0, c0 = k0, ky = 0, kx = 0;
+    if (p.conv) { tap = k0 / p.C; c0 = k0 - tap * p.C; ky = tap / p.kw; kx = tap - ky * p.kw; }
+
+    f32x4 areg[A_ITEMS], breg[B_ITEMS];
+    auto load_stage = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < A_ITEMS; ++i) {
+            const int e = tid + 256 * i, row = e / A_TPR, col = (e - row * A_TPR) * 4;
+            const int m = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end && n0 + col < p.N)
+                v = *reinterpret_cast<const f32x4*>(p.dz + (int64_t)m * p.ldz + n0 + col);
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i) {
+            const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
+            const int m = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end && k0 + col < p.K) {
+                if (p.conv) {
+                    const int hw = p.Ho * p.Wo;
+                    const int img = m / hw, rem = m - img * hw;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                        v = *reinterpret_cast<const f32x4*>(
+                            p.x + (((int64_t)img * p.H + iy) * p.W + ix) * p.C + c0 + col);
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + k0 + col);
+                }
+            }
+            breg[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ITEMS; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(As + buf * 32 * BM + e * 4) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(Bs + buf * 32 * BN + e * 4) = breg[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nst = (m_end - m_begin + 31) / 32;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    if (nst > 0) {
+        load_stage(m_begin);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(m_begin + (st + 1) * 32);
+        const float* Ab = As + buf * 32 * BM + wm * WTM;
+        const float* Bb = Bs + buf * 32 * BN + wn * WTN;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = Ab[(2 * s + fhalf) * BM + i * 32 + frow];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bb[(2 * s + fhalf) * BN + j * 32 + frow];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nst) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = p.slab + (int64_t)blockIdx.y * p.slab_stride;
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int k = k0 + wn * WTN + j * 32 + col_l;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (n < p.N) out[(int64_t)n * p.K + k] = acc[i][j][r];
+            }
+    }
+}
+
+// dW (torch layout [N][C][taps], or [N][K] when taps == 1) (+)= sum_z slab[z][n][t*C + c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t stride,
+                                    int N, int C, int taps, int Kslab, float* __restrict__ dw,
+                                    int Kout, int accumulate) {
+    const int64_t total = (int64_t)N * Kout;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i / Kout, ko = i - (int64_t)n * Kout;        // ko = c*taps + t
+        const int c = ko / taps, t = ko - c * taps;
+        const int64_t src = (int64_t)n * Kslab + (int64_t)t * C + c;
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * stride + src];
+        dw[i] = (accumulate ? dw[i] : 0.f) + s;
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_col_stats_rows(int M) { return (M + CHUNK - 1) / CHUNK; }
+
+extern "C" int grl_col_stats(const float* x, float* slab, int M, int C, int ld, void* stream) {
+    GRL_REQUIRE(x && slab && M > 0 && C % 4 == 0 && ld % 4 == 0, "col_stats: bad args");
+    hipLaunchKernelGGL(col_stats_kernel, dim3(grl_ceil_div(C, 256), grl_col_stats_rows(M)), dim3(256), 0,
+                       (hipStream_t)stream, x, slab, M, C, ld);
+    return grl_check_launch("grl_col_stats");
+}
+
+extern "C" int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out, int accumulate,
+                            void* stream) {
+    GRL_REQUIRE(slab && out && rows > 0 && C > 0, "slab_sum: bad args");
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grl_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, slab, rows,
+                       stride, C, out, accumulate);
+    return grl_check_launch("grl_slab_sum");
+}
+
+extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, float* mean, float* invstd, float* scale, float* shift,
+                                     void* stream) {
+    GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
+    GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, slab,
+                       rows, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                       scale, shift);
+    return grl_check_launch("grl_bn_stats_finalize");
+}
+
+extern "C" int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y,
+                            int64_t M, int C, int relu, void* stream) {
+    GRL_REQUIRE(z && scale && shift && y && M > 0 && C % 4 == 0, "bn_apply: bad args");
+    const int64_t total4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                       res, y, C / 4, total4, relu);
+    return grl_check_launch("grl_bn_apply");
+}
+
+extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
+                          const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
+                          float* slab_ws, float* coef_ws, int M, int C, void* stream) {
+    GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
+    const int rows = grl_col_stats_rows(M);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
+                       invstd, slab_ws, M, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 128)), dim3(128), 0, s, slab_ws, rows, C,
+                       (double)M, dgamma, dbeta, coef_ws);
+    const int64_t total4 = (int64_t)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
+                       coef_ws, dz, C, total4);
+    return grl_check_launch("grl_bn_bwd");
+}
+
+extern "C" int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream) {
+    GRL_REQUIRE(dy && out && n > 0 && n % 4 == 0, "relu_bwd: bad args");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, act, out, n / 4,
+                       accumulate);
+    return grl_check_launch("grl_relu_bwd");
+}
+
+extern "C" int grl_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {
+    GRL_REQUIRE(a && y && n > 0 && n % 4 == 0, "axpby: bad args");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, alpha, beta,
+                       n / 4);
+    return grl_check_launch("grl_axpby");
+}
+
+extern "C" int grl_axpy_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int nb,
+                                int64_t inner, float alpha, int accumulate, void* stream) {
+    GRL_REQUIRE(dst && src && nb > 0 && inner > 0 && inner % 4 == 0 && dst_stride % 4 == 0 && src_stride % 4 == 0,
+                "axpy_strided: bad args");
+    const int64_t total4 = (int64_t)nb * inner / 4;
+    hipLaunchKernelGGL(axpy_strided_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dst,
+                       dst_stride / 4, src, src_stride / 4, inner / 4, alpha, accumulate, total4);
+    return grl_check_launch("grl_axpy_strided");
+}
+
+extern "C" int grl_transpose(const float* x, float* y, int R, int C, int ldx, void* stream) {
+    GRL_REQUIRE(x && y && R > 0 && C > 0 && ldx >= C, "transpose: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3(grl_ceil_div(C, 32), grl_ceil_div(R, 32)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, R, C, ldx);
+    return grl_check_launch("grl_transpose");
+}
+
+extern "C" int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream) {
+    GRL_REQUIRE(w && out && N > 0 && C > 0 && kh > 0 && kw > 0, "pack_dgrad_weight: bad args");
+    hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(grid_for((int64_t)N * C * kh * kw)), dim3(256), 0,
+                       (hipStream_t)stream, w, out, N, C, kh * kw);
+    return grl_check_launch("grl_pack_dgrad_weight");
+}
+
+extern "C" int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, void* stream) {
+    GRL_REQUIRE(dz && up && n > 0 && C % 4 == 0, "dilate2: bad args");
+    const int64_t total4 = (int64_t)n * H * W * (C / 4);
+    hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dz, up, Ho, Wo, H, W,
+                       C / 4, total4);
+    return grl_check_launch("grl_dilate2");
+}
+
+extern "C" int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
+                                    void* stream) {
+    GRL_REQUIRE(x && dy && dx && n > 0 && C % 4 == 0, "maxpool_bwd: bad args");
+    const int64_t total4 = (int64_t)n * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W,
+                       C / 4, total4);
+    return grl_check_launch("grl_maxpool3x3s2_bwd");
+}
+
+extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, int Kp, void* stream) {
+    GRL_REQUIRE(x && col && n > 0 && Kp >= 147 && Kp % 32 == 0, "stem_im2col: bad args");
+    const int64_t total = (int64_t)n * (H / 2) * (W / 2) * Kp;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, col, H, W, Kp,
+                       total);
+    return grl_check_launch("grl_stem_im2col");
+}
+
+static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
+    const int64_t tiles = (int64_t)((d.N + bm - 1) / bm) * ((d.K + bn - 1) / bn);
+    int64_t want = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (d.M + 255) / 256;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+static void wgrad_tile(const GrlWgrad& d, int* bm, int* bn) {
+    *bm = d.N >= 128 ? 128 : 64;
+    const int cdiv = d.conv ? d.C : d.K;
+    *bn = (cdiv % 128 == 0) ? 128 : 64;
+}
+
+extern "C" int64_t grl_wgrad_workspace_floats(const GrlWgrad* d) {
+    if (!d) return -1;
+    int bm, bn;
+    wgrad_tile(*d, &bm, &bn);
+    return (int64_t)wgrad_splits(*d, bm, bn) * d->N * d->K;
+}
+
+extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
+    GRL_REQUIRE(desc, "wgrad: null desc");
+    const GrlWgrad& d = *desc;
+    GRL_REQUIRE(d.dz && d.x && d.dw && d.workspace, "wgrad: null pointer");
+    GRL_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.ldz % 4 == 0, "wgrad: bad shape");
+    GRL_REQUIRE(d.N % 4 == 0 && d.K % 4 == 0, "wgrad: N and K must be multiples of 4");
+    if (d.conv) {
+        GRL_REQUIRE(d.C % 64 == 0 && d.K == d.kh * d.kw * d.C, "wgrad conv: C % 64, K = kh*kw*C");
+        GRL_REQUIRE(d.M % (d.Ho * d.Wo) == 0, "wgrad conv: M must be nimg*Ho*Wo");
+    } else {
+        GRL_REQUIRE(d.ldx % 4 == 0, "wgrad: ldx % 4");
+    }
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    const int splits = wgrad_splits(d, bm, bn);
+    WgradArgs a;
+    a.dz = d.dz; a.x = d.x; a.slab = d.workspace;
+    a.M = d.M; a.N = d.N; a.K = d.K; a.ldz = d.ldz; a.ldx = d.ldx;
+    a.slab_stride = (int64_t)d.N * d.K;
+    a.chunk = (int)((((int64_t)d.M + splits - 1) / splits + 31) / 32 * 32);
+    a.conv = d.conv; a.H = d.H; a.W = d.W; a.C = d.C; a.Ho = d.Ho; a.Wo = d.Wo;
+    a.kh = d.kh; a.kw = d.kw; a.stride = d.stride; a.pad = d.pad;
+    const int real_splits = (d.M + a.chunk - 1) / a.chunk;
+    const int tiles_n = (d.N + bm - 1) / bm, tiles_k = (d.K + bn - 1) / bn;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * 32 * (bm + bn) * sizeof(float);
+    dim3 grid(tiles_n * tiles_k, real_splits);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), lds, s, a, tiles_k);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), lds, s, a, tiles_k);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), lds, s, a, tiles_k);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), lds, s, a, tiles_k);
+    const int taps = d.conv ? d.kh * d.kw : 1;
+    const int Cc = d.conv ? d.C : d.K;
+    const int kout = d.k_out > 0 ? d.k_out : d.K;      // stem: K padded to 160, 147 real
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)d.N * kout)), dim3(256), 0, s, d.workspace,
+                       real_splits, a.slab_stride, d.N, Cc, taps, d.K, d.dw, kout, d.accumulate);
+    return grl_check_launch("grl_conv_wgrad_f32");
+}

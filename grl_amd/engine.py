@@ -37,7 +37,12 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
-    (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution."""
+    (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
+    ``stats=True`` allocates and returns the per-channel partial-sum slab
+    (train-mode BatchNorm) as ``(y, slab)``."""
+    want_stats = stats is True
+    if want_stats:
+        stats = None
     d = GrlGemm()
     d.a, d.w, d.y = ptr(a), ptr(w), ptr(y)
     d.scale, d.shift, d.res = ptr(scale), ptr(shift), ptr(res)
@@ -54,7 +59,14 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
-    check(_lib.load().grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+    lib = _lib.load()
+    if want_stats:
+        rows = lib.grl_conv_gemm_f32_stat_rows(C.byref(d))
+        slab = torch.empty((rows, 2, N), dtype=torch.float32, device=y.device)
+        d.stats = ptr(slab)
+        check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+        return y, slab
+    check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
     return y
 
 
@@ -213,7 +225,7 @@ def trunk_eval(plan, x, taps=None):
     Hs, Ws = H // 2, W // 2
     stem = _new((n * Hs * Ws, 64), x)
     _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-          ptr(stem), n, H, W)
+          ptr(stem), n, H, W, 1)
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
     _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)

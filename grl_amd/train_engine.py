@@ -1,19 +1,618 @@
-"""Train-mode (batch-statistics BatchNorm + backward) side of the GRL path and
-the pair-verification heads.
+"""Train-mode side of the GRL path on MI355X: batch-statistics BatchNorm forward and
+the hand-written HIP backward, wired into torch.autograd through two
+``autograd.Function``s so that ``loss.backward()`` in the trainer
+(/root/reference/reid/train/trainer.py:53-55) runs our kernels.
 
-Reference call sites: reid/models/Siamese.py:108-142,
-reid/models/Siamese_video.py:158-184, reid/train/trainer.py:107-170.
+A tiny tape (list of closures) records the launch order of the forward; backward
+replays it in reverse.  Gradients live in plain device tensors keyed by the forward
+tensor they belong to; parameter gradients are accumulated (BatchNorms of the TRL memo
+block are applied T times per forward, grl_model.py:153,167).
+
+Reference call sites: reid/models/grl_model.py:211-228 (+ basebranch.py:52-68,
+resnets1.py:73-109), reid/models/Siamese.py:79-142, reid/models/Siamese_video.py:158-184.
 """
 import ctypes as C
 
 import torch
 
-from . import _lib
-from ._lib import ptr
-from . import engine
-from .engine import _call, _new, _plan, EvalPlan
+from . import _lib, engine
+from ._lib import GrlWgrad, check, ptr
+from .engine import _call, _new, gemm, EvalPlan, PIX
+
+FRAME_C = 2048
 
 
+# ----------------------------------------------------------------------------
+# tape
+# ----------------------------------------------------------------------------
+class Tape(object):
+    def __init__(self, dev):
+        self.dev = dev
+        self.ops = []
+        self.g = {}          # id(forward tensor) -> gradient tensor
+        self.pg = {}         # id(param) -> (param, grad)
+        self.wc = {}         # packed weights for this step
+        self.no_grad = set() # ids of tensors that need no gradient (network input)
+
+    # gradients of activations -------------------------------------------------
+    def add_grad(self, t, g):
+        cur = self.g.get(id(t))
+        if cur is None:
+            self.g[id(t)] = g
+        else:
+            _call('grl_axpby', ptr(cur), ptr(g), ptr(cur), C.c_float(1.0), C.c_float(1.0), cur.numel())
+
+    def add_masked(self, t, dy, act):
+        """grad(t) += dy * (act > 0)"""
+        cur = self.g.get(id(t))
+        if cur is None:
+            cur = _new(tuple(dy.shape), dy)
+            self.g[id(t)] = cur
+            _call('grl_relu_bwd', ptr(dy), ptr(act), ptr(cur), dy.numel(), 0)
+        else:
+            _call('grl_relu_bwd', ptr(dy), ptr(act), ptr(cur), dy.numel(), 1)
+
+    def full_grad(self, t):
+        cur = self.g.get(id(t))
+        if cur is None:
+            cur = torch.zeros_like(t)
+            self.g[id(t)] = cur
+        return cur
+
+    def take(self, t):
+        return self.g.pop(id(t), None)
+
+    # gradients of parameters --------------------------------------------------
+    def pgrad(self, p):
+        e = self.pg.get(id(p))
+        if e is None:
+            e = (p, torch.zeros_like(p))
+            self.pg[id(p)] = e
+        return e[1]
+
+    # packed weights -------------------------------------------------------------
+    def w_fwd(self, conv):
+        """Forward GEMM weight [N][K] (3x3: tap-major pack)."""
+        w = conv.weight
+        key = ('f', id(w))
+        if key not in self.wc:
+            wd = w.detach()
+            if wd.dim() == 4 and wd.shape[2] > 1:
+                n, c, k, _ = wd.shape
+                out = torch.empty(n, k * k * c, dtype=torch.float32, device=self.dev)
+                wc = wd.contiguous()
+                _call('grl_pack_conv_weight', ptr(wc), ptr(out), n, c, k, k)
+                self.wc[key] = out
+            else:
+                self.wc[key] = wd.contiguous().view(wd.shape[0], -1)
+        return self.wc[key]
+
+    def w_t(self, w2d, key_obj, ld=None):
+        """Transposed [K][N] of a dense weight [N][K] (row stride ld) for the data gradient."""
+        key = ('t', id(key_obj), w2d.data_ptr())
+        if key not in self.wc:
+            n, k = w2d.shape
+            out = torch.empty(k, n, dtype=torch.float32, device=self.dev)
+            _call('grl_transpose', ptr(w2d), ptr(out), n, k, ld or k)
+            self.wc[key] = out
+        return self.wc[key]
+
+    def w_dgrad(self, conv):
+        w = conv.weight
+        key = ('d', id(w))
+        if key not in self.wc:
+            wd = w.detach().contiguous()
+            n, c, k, _ = wd.shape
+            out = torch.empty(c, k * k * n, dtype=torch.float32, device=self.dev)
+            _call('grl_pack_dgrad_weight', ptr(wd), ptr(out), n, c, k, k)
+            self.wc[key] = out
+        return self.wc[key]
+
+    def backward(self):
+        for fn in reversed(self.ops):
+            fn()
+        self.ops = []
+
+
+def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1):
+    """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32."""
+    d = GrlWgrad()
+    d.dz, d.x, d.dw = ptr(dz), ptr(x), ptr(dw)
+    d.M, d.N, d.K = M, N, K
+    d.ldz = ldz or N
+    d.ldx = ldx or K
+    d.k_out = k_out
+    d.accumulate = accumulate
+    if conv is not None:
+        d.conv = 1
+        (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
+    lib = _lib.load()
+    ws = torch.empty(lib.grl_wgrad_workspace_floats(C.byref(d)), dtype=torch.float32, device=dz.device)
+    d.workspace = ptr(ws)
+    check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream()), 'grl_conv_wgrad_f32')
+
+
+def colsum_into(g, M, Ccols, out, ld=None):
+    """out[c] += sum_m g[m][c]."""
+    rows = _lib.load().grl_col_stats_rows(M)
+    slab = _new((rows, 2, Ccols), g)
+    _call('grl_col_stats', ptr(g), ptr(slab), M, Ccols, ld or Ccols)
+    _call('grl_slab_sum', ptr(slab), rows, 2 * Ccols, Ccols, ptr(out), 1)
+
+
+class _BNState(object):
+    __slots__ = ('mean', 'invstd', 'scale', 'shift')
+
+
+def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None):
+    st = _BNState()
+    st.mean, st.invstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    st.scale, st.shift = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    gamma = bn.weight if gamma is None else gamma
+    beta = bn.bias if beta is None else beta
+    rm = bn.running_mean if rm is None else rm
+    rv = bn.running_var if rv is None else rv
+    _call('grl_bn_stats_finalize', ptr(slab), rows, Cc, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+          C.c_float(bn.momentum), C.c_float(bn.eps), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift))
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return st
+
+
+def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc):
+    dz = _new((M, Cc), dy)
+    rows = _lib.load().grl_col_stats_rows(M)
+    slab = _new((rows, 2, Cc), dy)
+    coef = _new((2, Cc), dy)
+    _call('grl_bn_bwd', ptr(dy), ptr(z), ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma), ptr(dz),
+          ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc)
+    return dz
+
+
+# ----------------------------------------------------------------------------
+# ops (forward now, backward closure on the tape)
+# ----------------------------------------------------------------------------
+def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kcols=None, ldw=None):
+    """Conv (1x1 / 3x3, stride 1 / 2) + train-mode BN (+residual) (+ReLU).
+    x: channels-last [n_img*H*W][cin].  ``kcols``/``ldw``: use only the first kcols input
+    channels of a wider 1x1 weight (GCE split weight)."""
+    w = conv.weight
+    N, k = w.shape[0], (w.shape[2] if w.dim() == 4 else 1)
+    stride = conv.stride[0] if hasattr(conv, 'stride') else 1
+    cin = kcols or w.shape[1]
+    wf = tp.w_fwd(conv)
+    K = k * k * cin
+    if k == 1 and stride == 1:
+        Ho, Wo, geom = H, W, None
+    else:
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        geom = (H, W, cin, Ho, Wo, k, k, stride, pad)
+    M = n_img * Ho * Wo
+    z = _new((M, N), x)
+    _, slab = gemm(x, wf, z, M, N, K, ldw=ldw or wf.shape[1], gbias=gbias, rows_per_group=rpg,
+                   stats=True, conv=geom)
+    st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
+    a = _new((M, N), x)
+    _call('grl_bn_apply', ptr(z), ptr(st.scale), ptr(st.shift), ptr(res), ptr(a), M, N, 1 if relu else 0)
+
+    def bwd():
+        da = tp.take(a)
+        if da is None:
+            return
+        act = a if relu else None
+        if res is not None:
+            tp.add_masked(res, da, act)
+        dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N)
+        conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
+                                   kcols=kcols, ldw=ldw)
+        if gbias is not None:
+            tp.g[('gbias', id(z))] = dz          # the caller's closure reduces it per clip
+    tp.ops.append(bwd)
+    return a, Ho, Wo, z
+
+
+def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
+                               kcols=None, ldw=None):
+    """dW += dz^T . X (gathered), dx = dz . W (data gradient)."""
+    w = conv.weight
+    M = n_img * Ho * Wo
+    K = k * k * cin
+    if kcols is None:
+        wgrad(dz, x, tp.pgrad(w), M, N, K, conv=geom)
+    else:                                   # first kcols columns of a wider weight
+        tmp = torch.empty(N, kcols, dtype=torch.float32, device=tp.dev)
+        wgrad(dz, x, tmp, M, N, K, accumulate=0)
+        tp.pgrad(w).view(N, -1)[:, :kcols] += tmp
+    if id(x) in tp.no_grad:
+        return
+    Min = n_img * H * W
+    dx = _new((Min, cin), dz)
+    if k == 1:
+        w2d = w.detach().view(N, -1)
+        wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1])
+        src = dz
+        if stride != 1:
+            src = _new((Min, N), dz)
+            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
+        gemm(src, wt, dx, Min, cin, N)
+    else:
+        wd = tp.w_dgrad(conv)
+        src = dz
+        if stride != 1:
+            src = _new((Min, N), dz)
+            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
+        gemm(src, wd, dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2))
+    tp.add_grad(x, dx)
+
+
+def biased_conv_relu(tp, x, M, conv):
+    """1x1 conv with bias + ReLU (TRL f1/f2, grl_model.py:95-121)."""
+    w = conv.weight
+    N, K = w.shape[0], w.shape[1]
+    w2d = w.detach().view(N, K)
+    a = _new((M, N), x)
+    gemm(x, w2d, a, M, N, K, shift=conv.bias.detach(), relu=True)
+
+    def bwd():
+        da = tp.take(a)
+        if da is None:
+            return
+        g = _new((M, N), da)
+        _call('grl_relu_bwd', ptr(da), ptr(a), ptr(g), da.numel(), 0)
+        colsum_into(g, M, N, tp.pgrad(conv.bias))
+        wgrad(g, x, tp.pgrad(w), M, N, K)
+        dx = _new((M, K), g)
+        gemm(g, tp.w_t(w2d, w), dx, M, K, N)
+        tp.add_grad(x, dx)
+    tp.ops.append(bwd)
+    return a
+
+
+def linear_bn_relu(tp, x, M, lin, bn):
+    """Linear(+bias) + BN1d(train) + ReLU on [M][K] rows (basebranch.py:38-40)."""
+    w = lin.weight
+    N, K = w.shape
+    z = _new((M, N), x)
+    gemm(x, w.detach(), z, M, N, K, shift=lin.bias.detach())
+    rows = _lib.load().grl_col_stats_rows(M)
+    slab = _new((rows, 2, N), x)
+    _call('grl_col_stats', ptr(z), ptr(slab), M, N, N)
+    st = bn_finalize(slab, rows, N, M, bn, tp.dev)
+    a = _new((M, N), x)
+    _call('grl_bn_apply', ptr(z), ptr(st.scale), ptr(st.shift), None, ptr(a), M, N, 1)
+
+    def bwd():
+        da = tp.take(a)
+        if da is None:
+            return
+        dz = bn_backward(da, z, a, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N)
+        colsum_into(dz, M, N, tp.pgrad(lin.bias))
+        wgrad(dz, x, tp.pgrad(w), M, N, K)
+        dx = _new((M, K), dz)
+        gemm(dz, tp.w_t(w.detach(), w), dx, M, K, N)
+        tp.add_grad(x, dx)
+    tp.ops.append(bwd)
+    return a
+
+
+def group_mean_op(tp, x, groups, rows, Cc):
+    y = _new((groups, Cc), x)
+    _call('grl_group_mean', ptr(x), ptr(y), groups, rows, Cc, Cc, C.c_float(1.0), 0)
+
+    def bwd():
+        dy = tp.take(y)
+        if dy is None:
+            return
+        cur = tp.g.get(id(x))
+        if cur is None:
+            cur = _new(tuple(x.shape), x)
+            tp.g[id(x)] = cur
+            acc = 0
+        else:
+            acc = 1
+        _call('grl_add_rowbcast', ptr(cur), ptr(dy), groups * rows, Cc, rows, C.c_float(1.0 / rows), acc)
+    tp.ops.append(bwd)
+    return y
+
+
+def bn1d_l2norm(tp, f, rows, Cc, bn):
+    """BatchNorm1d(train) + F.normalize on [rows][C] (grl_model.py:222-226)."""
+    nr = _lib.load().grl_col_stats_rows(rows)
+    slab = _new((nr, 2, Cc), f)
+    _call('grl_col_stats', ptr(f), ptr(slab), rows, Cc, Cc)
+    st = bn_finalize(slab, nr, Cc, rows, bn, tp.dev)
+    y = _new((rows, Cc), f)
+    _call('grl_bn_apply', ptr(f), ptr(st.scale), ptr(st.shift), None, ptr(y), rows, Cc, 0)
+    out = _new((rows, Cc), f)
+    _call('grl_affine_l2norm', ptr(y), None, None, ptr(out), rows, Cc, Cc)
+
+    def bwd():
+        dout = tp.take(out)
+        if dout is None:
+            return
+        dy = _new((rows, Cc), f)
+        _call('grl_l2norm_bwd', ptr(dout), Cc, ptr(out), Cc, ptr(y), ptr(dy), rows, Cc)
+        df = bn_backward(dy, f, None, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), rows, Cc)
+        tp.add_grad(f, df)
+    tp.ops.append(bwd)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# model sections
+# ----------------------------------------------------------------------------
+def trunk_train(tp, model, x):
+    base = model.backbone.base
+    n, _, H, W = x.shape
+    tp.no_grad.add(id(x))
+    Hs, Ws = H // 2, W // 2
+    M0 = n * Hs * Ws
+    conv1, bn1 = base[0], base[1]
+    ones, zeros = torch.ones(64, device=tp.dev), torch.zeros(64, device=tp.dev)
+    z0 = _new((M0, 64), x)
+    w0 = conv1.weight.detach().contiguous()
+    _call('grl_stem_conv7x7', ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0)
+    rows = _lib.load().grl_col_stats_rows(M0)
+    slab = _new((rows, 2, 64), x)
+    _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64)
+    st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev)
+    a0 = _new((M0, 64), x)
+    _call('grl_bn_apply', ptr(z0), ptr(st.scale), ptr(st.shift), None, ptr(a0), M0, 64, 1)
+    Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
+    p0 = _new((n * Hp * Wp, 64), x)
+    _call('grl_maxpool3x3s2', ptr(a0), ptr(p0), n, Hs, Ws, 64)
+
+    def bwd_stem():
+        dp = tp.take(p0)
+        if dp is None:
+            return
+        da = _new((M0, 64), dp)
+        _call('grl_maxpool3x3s2_bwd', ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
+        dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
+        col = _new((M0, 160), dp)
+        _call('grl_stem_im2col', ptr(x), ptr(col), n, H, W, 160)
+        wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
+    tp.ops.append(bwd_stem)
+
+    cur, H, W = p0, Hp, Wp
+    for li in (4, 5, 6, 7):
+        for blk in base[li]:
+            o1, _, _, _ = conv_bn(tp, cur, n, H, W, blk.conv1, blk.bn1, True)
+            o2, Ho, Wo, _ = conv_bn(tp, o1, n, H, W, blk.conv2, blk.bn2, True)
+            if blk.downsample is not None:
+                res, _, _, _ = conv_bn(tp, cur, n, H, W, blk.downsample[0], blk.downsample[1], False)
+            else:
+                res = cur
+            cur, _, _, _ = conv_bn(tp, o2, n, Ho, Wo, blk.conv3, blk.bn3, True, res=res)
+            H, W = Ho, Wo
+    return cur
+
+
+def _pad32(vec, fill=0.0):
+    out = torch.full((32,), fill, dtype=torch.float32, device=vec.device)
+    out[:vec.numel()] = vec.detach().reshape(-1)
+    return out
+
+
+def gce_train(tp, model, x4, b, t):
+    bb = model.backbone
+    M = x4.shape[0]
+    rpc = t * PIX
+    x_glo = group_mean_op(tp, x4, b, rpc, 2048)
+    glo = linear_bn_relu(tp, x_glo, b, bb.glo_fc[0], bb.glo_fc[1])
+    conv0, bn0 = bb.corr_atte[0], bb.corr_atte[1]
+    w0 = conv0.weight.detach().view(1024, 3072)
+    gb = _new((b, 1024), x4)
+    gemm(glo, w0[:, 2048:], gb, b, 1024, 1024, ldw=3072)
+    h1, _, _, z1 = conv_bn(tp, x4, b * t, 16, 8, conv0, bn0, False, gbias=gb, rpg=rpc, kcols=2048, ldw=3072)
+
+    def bwd_gbias():
+        dz1 = tp.g.pop(('gbias', id(z1)), None)
+        if dz1 is None:
+            return
+        dgb = _new((b, 1024), x4)
+        _call('grl_group_mean', ptr(dz1), ptr(dgb), b, rpc, 1024, 1024, C.c_float(float(rpc)), 0)
+        tmp = torch.empty(1024, 1024, dtype=torch.float32, device=tp.dev)
+        wgrad(dgb, glo, tmp, b, 1024, 1024, accumulate=0)
+        tp.pgrad(conv0.weight).view(1024, 3072)[:, 2048:] += tmp
+        dglo = _new((b, 1024), x4)
+        gemm(dgb, tp.w_t(w0[:, 2048:], ('wg', id(conv0.weight)), ld=3072), dglo, b, 1024, 1024)
+        tp.add_grad(glo, dglo)
+    # h1's closure (already on the tape) must run BEFORE this one in backward, and the
+    # closures of glo's producers after it: insert right below the h1 closure.
+    tp.ops.insert(len(tp.ops) - 1, bwd_gbias)
+
+    h2, _, _, _ = conv_bn(tp, h1, b * t, 16, 8, bb.corr_atte[2], bb.corr_atte[3], True)
+    # 256 -> 1 conv + BN(1): run as a 32-wide padded channel block (K of the data-gradient
+    # GEMM must be a multiple of 32); only column 0 is real.
+    conv5, bn6 = bb.corr_atte[5], bb.corr_atte[6]
+    w5 = torch.zeros(32, 256, dtype=torch.float32, device=tp.dev)
+    w5[0] = conv5.weight.detach().view(256)
+    z3 = _new((M, 32), x4)
+    _, slab = gemm(h2, w5, z3, M, 32, 256, stats=True)
+    g32, b32 = _pad32(bn6.weight), _pad32(bn6.bias)
+    rm32, rv32 = _pad32(bn6.running_mean), _pad32(bn6.running_var, 1.0)
+    st = bn_finalize(slab, slab.shape[0], 32, M, bn6, tp.dev, gamma=g32, beta=b32, rm=rm32, rv=rv32)
+    bn6.running_mean.copy_(rm32[:1])
+    bn6.running_var.copy_(rv32[:1])
+    y3 = _new((M, 32), x4)
+    _call('grl_bn_apply', ptr(z3), ptr(st.scale), ptr(st.shift), None, ptr(y3), M, 32, 0)
+    cmap = _new((M,), x4)
+    xc, xu = _new((M, 2048), x4), _new((M, 2048), x4)
+    _call('grl_gate_apply', ptr(y3), 32, ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 2048)
+
+    def bwd_gate():
+        dxc, dxu = tp.take(xc), tp.take(xu)
+        if dxc is None and dxu is None:
+            return
+        dxc = dxc if dxc is not None else torch.zeros_like(xc)
+        dxu = dxu if dxu is not None else torch.zeros_like(xu)
+        dy3 = torch.zeros((M, 32), dtype=torch.float32, device=tp.dev)
+        cur = tp.g.get(id(x4))
+        if cur is None:
+            cur = _new((M, 2048), x4)
+            tp.g[id(x4)] = cur
+            acc = 0
+        else:
+            acc = 1
+        _call('grl_gate_bwd', ptr(dxc), ptr(dxu), ptr(x4), ptr(cmap), ptr(cur), acc, ptr(dy3), 32, M, 2048)
+        dg32, db32 = torch.zeros(32, device=tp.dev), torch.zeros(32, device=tp.dev)
+        dz3 = bn_backward(dy3, z3, None, st, g32, dg32, db32, M, 32)
+        tp.pgrad(bn6.weight).add_(dg32[:1])
+        tp.pgrad(bn6.bias).add_(db32[:1])
+        dw5 = torch.empty(32, 256, dtype=torch.float32, device=tp.dev)
+        wgrad(dz3, h2, dw5, M, 32, 256, accumulate=0)
+        tp.pgrad(conv5.weight).view(1, 256).add_(dw5[:1])
+        dh2 = _new((M, 256), x4)
+        gemm(dz3, tp.w_t(w5, ('w5', id(conv5.weight))), dh2, M, 256, 32)
+        tp.add_grad(h2, dh2)
+    tp.ops.append(bwd_gate)
+    return xu, xc, cmap
+
+
+def _axpy_frame(dst_full, ti, src, b, t, frame, alpha=1.0):
+    """dst_full[b][ti] += alpha * src[b]  (frame-sized rows)."""
+    _call('grl_axpy_strided', ptr(dst_full.view(-1)[ti * frame:]), t * frame, ptr(src), frame, b, frame,
+          C.c_float(alpha), 1)
+
+
+def trl_train(tp, model, xu, xc, b, t):
+    trl = model.temporal_learning_block
+    Cc, frame, Mb = FRAME_C, PIX * FRAME_C, b * PIX
+    dirs = ((trl.forward_f1, trl.forward_f2, trl.channel_atte_foreward_corr, trl.uncorr_memo_forward),
+            (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward))
+    memo0 = _new((Mb, Cc), xu)
+    _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
+
+    def bwd_memo0():
+        dm = tp.take(memo0)
+        if dm is None:
+            return
+        g = tp.full_grad(xu)
+        _call('grl_add_rowbcast', ptr(g), ptr(dm), b * t, frame, t, C.c_float(1.0 / t), 1)
+    tp.ops.append(bwd_memo0)
+
+    gapc = group_mean_op(tp, xc, b * t, PIX, Cc)          # full_grad(xc) accumulates inside
+    f2 = [biased_conv_relu(tp, xc, b * t * PIX, d[1][0]) for d in dirs]
+    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=tp.dev)
+    memo = [memo0, memo0]
+    for i in range(t):
+        for di, (f1m, _, mlp, blk) in enumerate(dirs):
+            ti = i if di == 0 else t - 1 - i
+            f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
+            dvec = _new((b, Cc), xu)
+            f2t = f2[di]
+            _call('grl_sqdiff_mean', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+            hid = _new((b, 128), xu)
+            catte = _new((b, Cc), xu)
+            w1, w2 = mlp[0].weight, mlp[2].weight
+            w2t = tp.w_t(w2.detach(), w2)                   # [128][2048]
+            _call('grl_channel_atte', ptr(dvec), ptr(w1.detach()), ptr(w2t), ptr(gapc[ti:]), t * Cc,
+                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
+
+            def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t):
+                dfc = tp.g.get(id(fcorr))
+                if dfc is None:
+                    return
+                ds = _new((b, Cc), xu)
+                dgap = tp.full_grad(gapc)
+                _call('grl_catte_bwd', ptr(dfc.view(b * t, Cc)[ti:]), t * Cc, ptr(gapc[ti:]), t * Cc,
+                      ptr(catte), ptr(ds), ptr(dgap[ti:]), t * Cc, 1, b, Cc)
+                dhid = _new((b, 128), xu)
+                gemm(ds, w2t, dhid, b, 128, Cc)
+                wgrad(ds, hid, tp.pgrad(w2), b, Cc, 128)
+                dhp = _new((b, 128), xu)
+                _call('grl_relu_bwd', ptr(dhid), ptr(hid), ptr(dhp), dhid.numel(), 0)
+                wgrad(dhp, dvec, tp.pgrad(w1), b, 128, Cc)
+                dd = _new((b, Cc), xu)
+                gemm(dhp, tp.w_t(w1.detach(), w1), dd, b, Cc, 128)
+                # through d = mean (f1 - f2)^2
+                df1 = _new((Mb, Cc), xu)
+                df2 = tp.full_grad(f2t)
+                _call('grl_sqdiff_bwd', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dd), ptr(df1),
+                      ptr(df2[ti * PIX:]), b, PIX, Cc, t * frame, 1)
+                tp.add_grad(f1, df1)
+            tp.ops.append(bwd_atte)
+
+            s = _new((Mb, Cc), xu)
+            _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
+            prev = memo[di]
+
+            def bwd_add(s=s, prev=prev, ti=ti):
+                dsum = tp.take(s)
+                if dsum is None:
+                    return
+                _axpy_frame(tp.full_grad(xu), ti, dsum, b, t, frame)
+                tp.add_grad(prev, dsum)
+            tp.ops.append(bwd_add)
+            o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
+            o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
+            memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
+    f_uncorr = _new((b, Cc), xu)
+    _call('grl_group_mean', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
+    _call('grl_group_mean', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
+    mf, mb_ = memo
+
+    def bwd_funcorr():
+        d = tp.take(f_uncorr)
+        if d is None:
+            return
+        for m in (mf, mb_):
+            g = _new((Mb, Cc), xu)
+            _call('grl_add_rowbcast', ptr(g), ptr(d), Mb, Cc, PIX, C.c_float(1.0 / PIX), 0)
+            tp.add_grad(m, g)
+    tp.ops.append(bwd_funcorr)
+    return f_uncorr, fcorr
+
+
+class _GrlTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_box, inputs, *params):
+        model = model_box[0]
+        tp = Tape(inputs.device)
+        b, t = inputs.shape[:2]
+        x = inputs.contiguous().view(b * t, 3, 256, 128)
+        x4 = trunk_train(tp, model, x)
+        xu, xc, _ = gce_train(tp, model, x4, b, t)
+        f_uncorr, f_corr = trl_train(tp, model, xu, xc, b, t)
+        fc2d = f_corr.view(b * t, 2048)
+
+        def bwd_alias():        # gradient of the 2-D view belongs to the 3-D f_corr
+            g = tp.g.pop(id(fc2d), None)
+            if g is not None:
+                tp.g[id(f_corr)] = g.view(b, t, 2048)
+        tp.ops.append(bwd_alias)
+        x_corr = bn1d_l2norm(tp, fc2d, b * t, 2048, model.corr_bn)
+        x_uncorr = bn1d_l2norm(tp, f_uncorr, b, 2048, model.uncorr_bn)
+        ctx.tape, ctx.outs, ctx.params, ctx.keep = tp, (x_uncorr, x_corr), params, (x, fc2d)
+        return x_uncorr.clone(), x_corr.view(b, t, 2048).clone()
+
+    @staticmethod
+    def backward(ctx, d_uncorr, d_corr):
+        tp = ctx.tape
+        xu_out, xc_out = ctx.outs
+        if d_uncorr is not None:
+            tp.g[id(xu_out)] = d_uncorr.contiguous()
+        if d_corr is not None:
+            tp.g[id(xc_out)] = d_corr.contiguous().view(xc_out.shape)
+        tp.backward()
+        grads = []
+        for p in ctx.params:
+            e = tp.pg.get(id(p))
+            grads.append(e[1] if e is not None else None)
+        ctx.tape = None
+        return (None, None) + tuple(grads)
+
+
+def grl_forward_train(model, inputs):
+    params = tuple(model.parameters())
+    return _GrlTrainFn.apply([model], inputs, *params)
+
+
+# ----------------------------------------------------------------------------
+# Siamese heads
+# ----------------------------------------------------------------------------
 class VerifyEvalPlan(EvalPlan):
     def __init__(self, head):
         super().__init__(head)
@@ -22,15 +621,8 @@ class VerifyEvalPlan(EvalPlan):
         self.b = head.classifierlinear.bias.detach().contiguous()
 
 
-_vplans = {}
-
-
 def _verify_eval(head, probe, gallery):
-    key = id(head)
-    p = _vplans.get(key)
-    if p is None or p.key != engine._state_key(head):
-        p = VerifyEvalPlan(head)
-        _vplans[key] = p
+    p = engine._plan(head, VerifyEvalPlan)
     nb, k = probe.shape
     ncls = p.w.shape[0]
     out = _new((nb, gallery.shape[0], ncls), probe)
@@ -39,25 +631,195 @@ def _verify_eval(head, probe, gallery):
     return out
 
 
-def _train_not_ready(what):
-    raise NotImplementedError(
-        '%s: the train-mode (batch-stat BN + HIP backward) path is not built yet; '
-        'call .eval() for the inference path' % what)
+def attn_train(tp, siam, x, b, t):
+    """Siamese.self_attention in train mode on x [b][t][C] (contiguous)."""
+    Cc, D = x.shape[2], siam.featQ.out_features
+    M = b * t
+    wqk = torch.cat((siam.featQ.weight.detach(), siam.featK.weight.detach()), 0).contiguous()
+    bqk = torch.cat((siam.featQ.bias.detach(), siam.featK.bias.detach())).contiguous()
+    z = _new((M, 2 * D), x)
+    gemm(x, wqk, z, M, 2 * D, Cc, shift=bqk)
+    rows = _lib.load().grl_col_stats_rows(M)
+    sts = []
+    scale, shift = _new((2 * D,), x), _new((2 * D,), x)
+    for h, bn in enumerate((siam.featQ_bn, siam.featK_bn)):
+        slab = _new((rows, 2, D), x)
+        _call('grl_col_stats', ptr(z[:, h * D:]), ptr(slab), M, D, 2 * D)
+        st = bn_finalize(slab, rows, D, M, bn, tp.dev)
+        scale[h * D:(h + 1) * D] = st.scale
+        shift[h * D:(h + 1) * D] = st.shift
+        sts.append(st)
+    qk = _new((M, 2 * D), x)
+    _call('grl_bn_apply', ptr(z), ptr(scale), ptr(shift), None, ptr(qk), M, 2 * D, 0)
+    out = _new((b, Cc), x)
+    _call('grl_siamese_attn', ptr(qk), ptr(x), ptr(out), b, t, D, Cc, Cc)
+
+    def bwd():
+        dout = tp.take(out)
+        if dout is None:
+            return
+        dqk = _new((M, 2 * D), x)
+        cur = tp.g.get(id(x))
+        acc = 1
+        if cur is None:
+            cur = _new(tuple(x.shape), x)
+            tp.g[id(x)] = cur
+            acc = 0
+        _call('grl_siamese_attn_bwd', ptr(qk), ptr(x), ptr(out), Cc, ptr(dout), Cc, ptr(dqk), ptr(cur), acc,
+              b, t, D, Cc)
+        mean = torch.cat((sts[0].mean, sts[1].mean)).contiguous()
+        invstd = torch.cat((sts[0].invstd, sts[1].invstd)).contiguous()
+        gamma = torch.cat((siam.featQ_bn.weight.detach(), siam.featK_bn.weight.detach())).contiguous()
+        st = _BNState()
+        st.mean, st.invstd = mean, invstd
+        dg, db = torch.zeros(2 * D, device=tp.dev), torch.zeros(2 * D, device=tp.dev)
+        dz = bn_backward(dqk, z, None, st, gamma, dg, db, M, 2 * D)
+        tp.pgrad(siam.featQ_bn.weight).add_(dg[:D]); tp.pgrad(siam.featK_bn.weight).add_(dg[D:])
+        tp.pgrad(siam.featQ_bn.bias).add_(db[:D]); tp.pgrad(siam.featK_bn.bias).add_(db[D:])
+        dbias = torch.zeros(2 * D, device=tp.dev)
+        colsum_into(dz, M, 2 * D, dbias)
+        tp.pgrad(siam.featQ.bias).add_(dbias[:D]); tp.pgrad(siam.featK.bias).add_(dbias[D:])
+        dw = torch.empty(2 * D, Cc, dtype=torch.float32, device=tp.dev)
+        wgrad(dz, x, dw, M, 2 * D, Cc, accumulate=0)
+        tp.pgrad(siam.featQ.weight).add_(dw[:D]); tp.pgrad(siam.featK.weight).add_(dw[D:])
+        dx = _new((M, Cc), x)
+        gemm(dz, tp.w_t(wqk, ('wqk', id(siam.featQ.weight))), dx, M, Cc, 2 * D)
+        tp.add_grad(x, dx.view(tuple(x.shape)))
+    tp.ops.append(bwd)
+    return out
 
 
-def grl_forward_train(model, inputs):
-    _train_not_ready('ResNet50_GRL_Model.forward')
+def verify_train(tp, head, probe, gallery):
+    """(p_i - g_j)^2 -> BN1d(train) -> Linear(K, ncls) on all probe x gallery pairs."""
+    nb, K = probe.shape
+    ng = gallery.shape[0]
+    P = nb * ng
+    bn, lin = head.classifierBN, head.classifierlinear
+    ncls = lin.out_features
+    diff = _new((P, K), probe)
+    _call('grl_pair_sqdiff', ptr(probe), ptr(gallery), ptr(diff), nb, ng, K)
+    rows = _lib.load().grl_col_stats_rows(P)
+    slab = _new((rows, 2, K), probe)
+    _call('grl_col_stats', ptr(diff), ptr(slab), P, K, K)
+    st = bn_finalize(slab, rows, K, P, bn, tp.dev)
+    dn = _new((P, K), probe)
+    _call('grl_bn_apply', ptr(diff), ptr(st.scale), ptr(st.shift), None, ptr(dn), P, K, 0)
+    wpad = torch.zeros(32, K, dtype=torch.float32, device=tp.dev)
+    wpad[:ncls] = lin.weight.detach()
+    bpad = _pad32(lin.bias)
+    cls32 = _new((P, 32), probe)
+    gemm(dn, wpad, cls32, P, 32, K, shift=bpad)
+    cls = cls32[:, :ncls].contiguous().view(nb, ng, ncls)
+
+    def bwd():
+        dcls = tp.take(cls)
+        if dcls is None:
+            return
+        d32 = torch.zeros((P, 32), dtype=torch.float32, device=tp.dev)
+        d32[:, :ncls] = dcls.reshape(P, ncls)
+        db = torch.zeros(32, device=tp.dev)
+        colsum_into(d32, P, 32, db)
+        tp.pgrad(lin.bias).add_(db[:ncls])
+        dw = torch.empty(32, K, dtype=torch.float32, device=tp.dev)
+        wgrad(d32, dn, dw, P, 32, K, accumulate=0)
+        tp.pgrad(lin.weight).add_(dw[:ncls])
+        ddn = _new((P, K), probe)
+        gemm(d32, tp.w_t(wpad, ('wcls', id(lin.weight))), ddn, P, K, 32)
+        dd = bn_backward(ddn, diff, None, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), P, K)
+        dp, dg = _new((nb, K), probe), _new((ng, K), probe)
+        _call('grl_pair_sqdiff_bwd', ptr(probe), ptr(gallery), ptr(dd), ptr(dp), ptr(dg), nb, ng, K)
+        tp.add_grad(probe, dp)
+        tp.add_grad(gallery, dg)
+    tp.ops.append(bwd)
+    return cls
+
+
+class _SiameseTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, box, x, *params):
+        siam = box[0]
+        tp = Tape(x.device)
+        bsz, t, d = x.shape
+        half = bsz // 2
+        xv = x.contiguous().view(half, 2, t, d)
+        xp, xg = xv[:, 0].contiguous(), xv[:, 1].contiguous()
+        # the reference pools the probe half first, then the gallery half (two BN calls each)
+        pp = attn_train(tp, siam, xp, half, t)
+        pg = attn_train(tp, siam, xg, half, t)
+        cls = verify_train(tp, siam, pp, pg)
+        ctx.tape, ctx.parts, ctx.params, ctx.shape = tp, (xp, xg, pp, pg, cls), params, (bsz, t, d)
+        return cls.clone(), torch.cat((pp, pg)).contiguous()
+
+    @staticmethod
+    def backward(ctx, dcls, dout):
+        tp = ctx.tape
+        xp, xg, pp, pg, cls = ctx.parts
+        bsz, t, d = ctx.shape
+        half = bsz // 2
+        if dcls is not None:
+            tp.g[id(cls)] = dcls.contiguous()
+        if dout is not None:
+            dout = dout.contiguous()
+            tp.add_grad(pp, dout[:half].clone())
+            tp.add_grad(pg, dout[half:].clone())
+        tp.backward()
+        dx = torch.zeros((half, 2, t, d), dtype=torch.float32, device=xp.device)
+        gp, gg = tp.take(xp), tp.take(xg)
+        if gp is not None:
+            dx[:, 0] = gp.view(half, t, d)
+        if gg is not None:
+            dx[:, 1] = gg.view(half, t, d)
+        grads = [tp.pg[id(p)][1] if id(p) in tp.pg else None for p in ctx.params]
+        ctx.tape = None
+        return (None, dx.view(bsz, t, d)) + tuple(grads)
+
+
+class _VerifyTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, box, x, *params):
+        head = box[0]
+        tp = Tape(x.device)
+        bsz = x.shape[0]
+        half = bsz // 2
+        xv = x.contiguous().view(half, 2, -1)
+        xp, xg = xv[:, 0].contiguous(), xv[:, 1].contiguous()
+        cls = verify_train(tp, head, xp, xg)
+        ctx.tape, ctx.parts, ctx.params, ctx.bsz = tp, (xp, xg, cls), params, bsz
+        return cls.clone(), torch.cat((xp, xg)).contiguous()
+
+    @staticmethod
+    def backward(ctx, dcls, dout):
+        tp = ctx.tape
+        xp, xg, cls = ctx.parts
+        half = ctx.bsz // 2
+        if dcls is not None:
+            tp.g[id(cls)] = dcls.contiguous()
+        tp.backward()
+        dx = torch.zeros((half, 2, xp.shape[1]), dtype=torch.float32, device=xp.device)
+        gp, gg = tp.take(xp), tp.take(xg)
+        if gp is not None:
+            dx[:, 0] = gp
+        if gg is not None:
+            dx[:, 1] = gg
+        if dout is not None:
+            dx[:, 0] += dout[:half]
+            dx[:, 1] += dout[half:]
+        grads = [tp.pg[id(p)][1] if id(p) in tp.pg else None for p in ctx.params]
+        ctx.tape = None
+        return (None, dx.view(ctx.bsz, -1)) + tuple(grads)
 
 
 def siamese_self_attention_train(siam, x):
-    _train_not_ready('Siamese.self_attention')
+    raise NotImplementedError(
+        'Siamese.self_attention is only called in eval mode by the reference '
+        '(attevaluator.py:107); call siamese.eval() first')
 
 
 def siamese_forward(siam, x):
-    """Siamese.forward: de-interleave (probe, gallery) pairs, pool each half with
-    the temporal attention, verification head on all probe x gallery pairs."""
+    """Siamese.forward: de-interleave (probe, gallery) pairs, pool each half with the
+    temporal attention, verification head on all probe x gallery pairs."""
     if siam.training:
-        _train_not_ready('Siamese.forward')
+        return _SiameseTrainFn.apply([siam], x, *tuple(siam.parameters()))
     with torch.no_grad():
         bsz, t, d = x.shape
         xv = x.contiguous().view(bsz // 2, 2, t, d)
@@ -72,7 +834,7 @@ def siamese_forward(siam, x):
 def siamese_video_forward(head, x):
     """Siamese_video.forward on pooled [B,D] features."""
     if head.training:
-        _train_not_ready('Siamese_video.forward')
+        return _VerifyTrainFn.apply([head], x, *tuple(head.parameters()))
     with torch.no_grad():
         bsz = x.shape[0]
         xv = x.contiguous().view(bsz // 2, 2, -1)

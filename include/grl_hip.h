@@ -91,10 +91,10 @@ int grl_pack_conv_weight(const float* w, float* out, int N, int C, int kh, int k
 int grl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                 const float* bias, float eps, float* scale, float* shift, int C, void* stream);
 
-/* Stem: 7x7 stride-2 pad-3 conv on NCHW input [n][3][H][W] + folded BN + ReLU ->
+/* Stem: 7x7 stride-2 pad-3 conv on NCHW input [n][3][H][W], y = relu?(conv*scale+shift) ->
  * channels-last [n][H/2][W/2][64]   (resnets1.py:101-103 / basebranch.py:28-30). */
 int grl_stem_conv7x7(const float* x, const float* w /*[64][3][7][7]*/, const float* scale,
-                     const float* shift, float* y, int n, int H, int W, void* stream);
+                     const float* shift, float* y, int n, int H, int W, int relu, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool, channels-last (resnets1.py:104). */
 int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream);
@@ -149,6 +149,103 @@ int grl_pair_verify(const float* p, const float* g, const float* scale, const fl
 
 /* |x_row|^2 for the Euclidean epilogue (attevaluator.py:37-38). */
 int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Train mode: batch-statistics BatchNorm and the backward pass (autograd of the modules
+ * above, driven by reid/train/trainer.py:54 `loss.backward()`).
+ * ---------------------------------------------------------------------------------- */
+
+/* column partials of x [M][C] (row stride ld): slab [grl_col_stats_rows(M)][2][C] = sum, sum sq */
+int grl_col_stats_rows(int M);
+int grl_col_stats(const float* x, float* slab, int M, int C, int ld, void* stream);
+/* out[c] (+)= sum_r slab[r*stride + c]  (bias gradients, partial reductions) */
+int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out, int accumulate,
+                 void* stream);
+
+/* nn.BatchNorm forward in training mode, step 1: from a partial slab [rows][2][C]
+ * (written by grl_conv_gemm_f32's `stats` or by grl_col_stats) to batch mean / invstd,
+ * folded scale/shift and the running-stat update (momentum, unbiased running var). */
+int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale,
+                          float* shift, void* stream);
+/* step 2: y = relu?(z*scale + shift + res) */
+int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res,
+                 float* y, int64_t M, int C, int relu, void* stream);
+
+/* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask);
+ * dgamma += sum g*xhat; dbeta += sum g; dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
+ * slab_ws: grl_col_stats_rows(M)*2*C floats, coef_ws: 2*C floats. gamma/dgamma/dbeta may be NULL. */
+int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
+               const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
+               float* slab_ws, float* coef_ws, int M, int C, void* stream);
+
+/* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
+int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);
+/* y = alpha*a + beta*b (b may be NULL) */
+int grl_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);
+
+/* dst[b*dst_stride + i] (+)= alpha*src[b*src_stride + i], i < inner (gradient accumulation
+ * into one frame of a [b][T][...] tensor) */
+int grl_axpy_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int nb,
+                     int64_t inner, float alpha, int accumulate, void* stream);
+/* y[C][R] = x[R][C]^T (weights for the data-gradient GEMM of 1x1 convs / linears) */
+int grl_transpose(const float* x, float* y, int R, int C, int ldx, void* stream);
+/* [N][C][kh][kw] -> [C][flipped tap][N]: data gradient of a kxk conv as a conv over dz */
+int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream);
+/* zero-stuffing of a stride-2 conv's output gradient: up[img][2oy][2ox] = dz[img][oy][ox] */
+int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, void* stream);
+/* nn.MaxPool2d(3,2,1) backward (first-maximum rule, deterministic gather form) */
+int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
+                         void* stream);
+/* im2col of the NCHW stem input for the 7x7 weight gradient: [n*H/2*W/2][Kp], 147 real columns */
+int grl_stem_im2col(const float* x, float* col, int n, int H, int W, int Kp, void* stream);
+
+/* Weight gradient  dW[n][k] (+)= sum_m dz[m][n] * X[m][k]  as an fp32 MFMA GEMM with the
+ * pixel reduction split over workgroups (deterministic slab reduction).  conv != 0: X is
+ * gathered from channels-last images and dW is written in torch layout [N][C][kh][kw]. */
+typedef struct GrlWgrad {
+    const float* dz;        /* [M][ldz]                                   */
+    const float* x;         /* dense [M][ldx] or images [nimg][H][W][C]   */
+    float*       dw;        /* [N][k_out] (dense) or [N][C][kh][kw]       */
+    float*       workspace; /* grl_wgrad_workspace_floats(desc) floats    */
+    int32_t M, N, K, ldz, ldx;
+    int32_t k_out;          /* dense: columns of dw actually written (0 = K) */
+    int32_t accumulate;
+    int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
+} GrlWgrad;
+int64_t grl_wgrad_workspace_floats(const GrlWgrad* desc);
+int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream);
+
+/* GCE gate in train mode (logit already batch-normalised, first column of y[M][ldy]):
+ * map = sigmoid(y), x_corr = x*map, x_uncorr = x*(1-map)          (basebranch.py:63-66) */
+int grl_gate_apply(const float* y, int ldy, const float* x, float* cmap, float* xc, float* xu,
+                   int M, int C, void* stream);
+/* its backward: dx (+)= dxc*map + dxu*(1-map); dy[m*ldy] = map(1-map) sum_c (dxc-dxu)*x */
+int grl_gate_bwd(const float* dxc, const float* dxu, const float* x, const float* cmap, float* dx,
+                 int accumulate, float* dy, int ldy, int M, int C, void* stream);
+/* dst[m][c] (+)= v[m / rows_per_group][c] * scale: backward of every mean over rows
+ * (GAP, global descriptor, temporal mean with C = a whole frame) */
+int grl_add_rowbcast(float* dst, const float* v, int64_t M, int64_t C, int64_t rows_per_group,
+                     float scale, int accumulate, void* stream);
+/* backward of grl_sqdiff_mean: df1 = 2(f1-f2)dd/rows, df2 (+)= -df1 */
+int grl_sqdiff_bwd(const float* f1, const float* f2, const float* dd, float* df1, float* df2,
+                   int b, int rows, int C, int64_t f2_clip_stride, int accumulate_df2, void* stream);
+/* backward of f_step = gap*c + gap through the sigmoid: ds = dfs*gap*c(1-c), dgap (+)= dfs*(1+c) */
+int grl_catte_bwd(const float* dfs, int64_t dfs_stride, const float* gap, int64_t gap_stride,
+                  const float* catte, float* ds, float* dgap, int64_t dgap_stride, int accumulate,
+                  int b, int C, void* stream);
+/* backward of y = v/|v| (F.normalize, grl_model.py:223,226): dv = (dy - y(y.dy))/|v| */
+int grl_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* v,
+                   float* dv, int rows, int C, void* stream);
+/* backward of grl_siamese_attn: gradients of the (BN-ed) Q|K rows and of the frame features */
+int grl_siamese_attn_bwd(const float* qk, const float* x, const float* out, int64_t ldo,
+                         const float* dout, int64_t lddo, float* dqk, float* dx, int dx_accumulate,
+                         int b, int T, int D, int C, void* stream);
+/* verification head, train mode: diff[i*ng+j] = (p_i - g_j)^2 and its backward (Siamese.py:133-137) */
+int grl_pair_sqdiff(const float* p, const float* g, float* diff, int np, int ng, int K, void* stream);
+int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* ddiff, float* dp, float* dg,
+                        int np, int ng, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ class Tape(object):
         self.pg = {}         # id(param) -> (param, grad)
         self.wc = {}         # packed weights for this step
         self.no_grad = set() # ids of tensors that need no gradient (network input)
+        self.taps = None     # optional dict of intermediates (tests)
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
@@ -375,6 +376,9 @@ def trunk_train(tp, model, x):
         wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
     tp.ops.append(bwd_stem)
 
+    if tp.taps is not None:
+        tp.taps['stem'] = engine._to_nchw(a0, n, Hs, Ws)
+        tp.taps['pool'] = engine._to_nchw(p0, n, Hp, Wp)
     cur, H, W = p0, Hp, Wp
     for li in (4, 5, 6, 7):
         for blk in base[li]:
@@ -386,6 +390,8 @@ def trunk_train(tp, model, x):
                 res = cur
             cur, _, _, _ = conv_bn(tp, o2, n, Ho, Wo, blk.conv3, blk.bn3, True, res=res)
             H, W = Ho, Wo
+        if tp.taps is not None:
+            tp.taps['layer%d' % (li - 3)] = engine._to_nchw(cur, n, H, W)
     return cur
 
 
@@ -468,6 +474,8 @@ def gce_train(tp, model, x4, b, t):
         gemm(dz3, tp.w_t(w5, ('w5', id(conv5.weight))), dh2, M, 256, 32)
         tp.add_grad(h2, dh2)
     tp.ops.append(bwd_gate)
+    if tp.taps is not None:
+        tp.taps.update(x_glo=x_glo, glo=glo, corr_map=cmap.view(b * t, 1, 16, 8))
     return xu, xc, cmap
 
 
@@ -534,6 +542,8 @@ def trl_train(tp, model, xu, xc, b, t):
                       ptr(df2[ti * PIX:]), b, PIX, Cc, t * frame, 1)
                 tp.add_grad(f1, df1)
             tp.ops.append(bwd_atte)
+            if tp.taps is not None:
+                tp.taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte)
 
             s = _new((Mb, Cc), xu)
             _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
@@ -563,6 +573,8 @@ def trl_train(tp, model, xu, xc, b, t):
             _call('grl_add_rowbcast', ptr(g), ptr(d), Mb, Cc, PIX, C.c_float(1.0 / PIX), 0)
             tp.add_grad(m, g)
     tp.ops.append(bwd_funcorr)
+    if tp.taps is not None:
+        tp.taps.update(f_uncorr=f_uncorr, f_corr=fcorr)
     return f_uncorr, fcorr
 
 
@@ -571,6 +583,7 @@ class _GrlTrainFn(torch.autograd.Function):
     def forward(ctx, model_box, inputs, *params):
         model = model_box[0]
         tp = Tape(inputs.device)
+        tp.taps = getattr(model, '_grl_taps', None)
         b, t = inputs.shape[:2]
         x = inputs.contiguous().view(b * t, 3, 256, 128)
         x4 = trunk_train(tp, model, x)

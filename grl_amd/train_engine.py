@@ -345,7 +345,8 @@ def bn1d_l2norm(tp, f, rows, Cc, bn):
 # ----------------------------------------------------------------------------
 def trunk_train(tp, model, x):
     base = model.backbone.base
-    n, _, H, W = x.shape
+    n, _, H0, W0 = x.shape
+    H, W = H0, W0
     tp.no_grad.add(id(x))
     Hs, Ws = H // 2, W // 2
     M0 = n * Hs * Ws
@@ -372,7 +373,7 @@ def trunk_train(tp, model, x):
         _call('grl_maxpool3x3s2_bwd', ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
         dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
         col = _new((M0, 160), dp)
-        _call('grl_stem_im2col', ptr(x), ptr(col), n, H, W, 160)
+        _call('grl_stem_im2col', ptr(x), ptr(col), n, H0, W0, 160)    # H, W are rebound below
         wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
     tp.ops.append(bwd_stem)
 

@@ -1,0 +1,143 @@
+"""SEQTrainer with the reference's constructor / train() signature and loss
+composition (/root/reference/reid/train/trainer.py:16-177).  The CNN / Siamese
+forward and backward run on MI355X through grl_amd (autograd.Functions around the HIP
+kernels); the only addition is the data-parallel gradient all-reduce between
+``backward()`` and ``step()`` when torch.distributed is initialised (one process per
+GPU; RCCL over xGMI)."""
+import time
+
+import torch
+import torch.nn.functional as F
+
+from grl_amd import dist as grl_dist
+from grl_amd.reid.evaluator import accuracy
+from grl_amd.reid.loss import TripletLoss
+from grl_amd.utils.meters import AverageMeter
+
+try:                                            # tensorboardX is optional here
+    from tensorboardX import SummaryWriter
+except Exception:                               # pragma: no cover
+    class SummaryWriter(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+criterion_triplet = TripletLoss('soft', True)
+
+
+class BaseTrainer(object):
+    def __init__(self, model, criterion):
+        self.model = model
+        self.criterion_ver = criterion
+        self.criterion_ver_uncorr = criterion
+        self.device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+        self._bucket = None
+
+    def _all_params(self):
+        raise NotImplementedError
+
+    def train(self, epoch, data_loader, optimizer1):
+        self.model.train()
+        batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+        precisions, precisions1, precisions2 = AverageMeter(), AverageMeter(), AverageMeter()
+        end = time.time()
+        for i, inputs in enumerate(data_loader):
+            data_time.update(time.time() - end)
+            inputs, targets = self._parse_data(inputs)
+            loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame = \
+                self._forward(inputs, targets, i, epoch)
+            losses.update(loss.item(), targets.size(0))
+            precisions.update(uncorr_prec_id_vid, targets.size(0))
+            precisions1.update(corr_prec_id_vid, targets.size(0))
+            precisions2.update(corr_prec_id_frame, targets.size(0))
+
+            optimizer1.zero_grad()
+            loss.backward()
+            if grl_dist.is_distributed():       # one RCCL all-reduce of the flat grad bucket
+                if self._bucket is None:
+                    self._bucket = grl_dist.GradBucket(self._all_params())
+                self._bucket.allreduce_mean()
+            optimizer1.step()
+
+            batch_time.update(time.time() - end)
+            end = time.time()
+            num_iter = len(data_loader) * epoch + i
+            self.writer.add_scalar('train/total_loss_step', losses.val, num_iter)
+            self.writer.add_scalar('train/total_loss_avg', losses.avg, num_iter)
+            if (i + 1) % 100 == 0:
+                print('Epoch: [{}][{}/{}]\t'
+                      'Loss {:.3f} ({:.3f})\t'
+                      'uncorr_vid {:.2%} ({:.2%})\t'
+                      'corr_vid {:.2%} ({:.2%})\t'
+                      'corr_frame {:.2%} ({:.2%})\t'
+                      .format(epoch, i + 1, len(data_loader), losses.val, losses.avg,
+                              precisions.val, precisions.avg, precisions1.val, precisions1.avg,
+                              precisions2.val, precisions2.avg))
+
+    def _parse_data(self, inputs):
+        raise NotImplementedError
+
+    def _forward(self, inputs, targets, i, epoch):
+        raise NotImplementedError
+
+
+class SEQTrainer(BaseTrainer):
+    def __init__(self, cnn_model, siamese_model, siamese_model_uncorr, criterion_veri,
+                 criterion_corr, criterion_uncorr, logdir):
+        super(SEQTrainer, self).__init__(cnn_model, criterion_veri)
+        self.siamese_model = siamese_model
+        self.siamese_model_uncorr = siamese_model_uncorr
+        self.criterion_uncorr = criterion_uncorr
+        self.criterion_corr = criterion_corr
+        self.writer = SummaryWriter(log_dir=logdir)
+        self.device = next(cnn_model.parameters()).device
+
+    def _all_params(self):
+        mods = (self.model, self.siamese_model, self.siamese_model_uncorr)
+        return [p for m in mods for p in m.parameters()]
+
+    def _parse_data(self, inputs):
+        imgs, pids, _ = inputs
+        return [imgs.to(self.device)], pids.to(self.device)
+
+    @staticmethod
+    def _pair_prob(encode_scores):
+        n0, n1 = encode_scores.size(0), encode_scores.size(1)
+        return F.softmax(encode_scores.view(-1, 2), dim=-1).view(n0, n1, 2)[:, :, 1]
+
+    def _forward(self, inputs, targets, i, epoch):
+        """trainer.py:107-170: id loss on frames + id loss on pooled clips (same LUT) +
+        20 x pair verification + batch-hard triplet on the correlated branch, id loss on
+        the uncorrelated branch."""
+        batch_size, seq_len = inputs[0].size(0), inputs[0].size(1)
+        x_uncorr, x_corr = self.model(inputs[0])
+        frame_corr = x_corr.reshape(batch_size * seq_len, -1)
+        targetX = targets.unsqueeze(1).expand(batch_size, seq_len).reshape(-1)
+        corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)
+        corr_prec_id_frame, = accuracy(output_id.data, targetX.data)
+
+        pairs = targets.data.view(batch_size // 2, -1)
+        tar_probe, tar_gallery = pairs[:, 0], pairs[:, 1]
+        target = torch.cat((tar_probe, tar_gallery))
+
+        encode_scores, siamese_out = self.siamese_model(x_corr)
+        corr_id_loss_vid, output_id = self.criterion_corr(siamese_out, target)
+        corr_prec_id_vid, = accuracy(output_id.data, target.data)
+        corr_loss_tri = criterion_triplet(siamese_out, target).mean()
+        corr_loss_ver, _ = self.criterion_ver(self._pair_prob(encode_scores), tar_probe, tar_gallery)
+
+        encode_scores, siamese_out = self.siamese_model_uncorr(x_uncorr)
+        uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out, target)
+        uncorr_prec_id_vid, = accuracy(output_id.data, target.data)
+        # (the reference also evaluates the uncorr verification loss but never adds it)
+
+        corr_loss = corr_id_loss_frame + corr_id_loss_vid + corr_loss_ver * 20 + corr_loss_tri
+        all_loss = uncorr_id_loss_vid + corr_loss
+        return all_loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame
+
+    def train(self, epoch, data_loader, optimizer1):
+        self.siamese_model.train()
+        self.siamese_model_uncorr.train()
+        super(SEQTrainer, self).train(epoch, data_loader, optimizer1)

@@ -166,22 +166,29 @@ def _fresh_models():
     return cnn.cuda(), siam.cuda(), siamv.cuda()
 
 
-def test_train_forward_backward_matches_reference_golden(golden):
-    """One train-mode forward + backward of the CNN at B x T = 2 x 4: outputs, BN running
-    statistics and parameter gradients against the reference (autograd on CPU)."""
-    g = golden('grl_train_b2t4.npz')
+@pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 5e-2),
+                                                   (4, 2, 2, 'grl_train_b4t2.npz', 4e-3)])
+def test_train_forward_backward_matches_reference_golden(golden, B, T, seed, fname, tol_xu):
+    """One train-mode forward + backward of the CNN: outputs, BN running statistics and
+    parameter gradients against the reference (fp32 autograd on CPU).
+
+    Yardstick for the tolerances: the fp32 reference itself differs from an fp64 run of the
+    same graph by 1.2e-2 (B=2) / 7e-4 (B=4) on x_uncorr and by up to 3e-2 on individual
+    gradient elements (batch-statistics BN over 2-8 samples in front of 50 ReLU layers is
+    that sensitive to rounding); |grad| sums agree to 4e-4..3e-3."""
+    g = golden(fname)
     cnn, _, _ = _fresh_models()
     cnn.train()
     rg = np.random.Generator(np.random.PCG64(7))
-    r1 = torch.from_numpy(rg.standard_normal((2, 2048)).astype(np.float32)).cuda()
-    r2 = torch.from_numpy(rg.standard_normal((2, 4, 2048)).astype(np.float32)).cuda()
-    clips = synth_clips(2, 4, seed=0).cuda()
+    r1 = torch.from_numpy(rg.standard_normal((B, 2048)).astype(np.float32)).cuda()
+    r2 = torch.from_numpy(rg.standard_normal((B, T, 2048)).astype(np.float32)).cuda()
+    clips = synth_clips(B, T, seed=seed).cuda()
     xu, xc = cnn(clips)
     # uncorr_bn / glo_fc.1 are BatchNorm1d over B = 2 rows here: (x - mean)/sqrt(var + eps) with
     # var = (x0 - x1)^2 / 4 amplifies fp32 rounding of near-equal rows, in the reference too.
     print('fwd rel err: x_uncorr %.2e x_corr %.2e' % (_rel(xu.detach().cpu().numpy(), g['x_uncorr']),
                                                      _rel(xc.detach().cpu().numpy(), g['x_corr'])))
-    assert _rel(xu.detach().cpu().numpy(), g['x_uncorr']) < 5e-2
+    assert _rel(xu.detach().cpu().numpy(), g['x_uncorr']) < tol_xu
     assert _rel(xc.detach().cpu().numpy(), g['x_corr']) < 2e-3
     loss = (xu * r1).sum() + (xc * r2).sum()
     loss.backward()
@@ -202,7 +209,7 @@ def test_train_forward_backward_matches_reference_golden(golden):
         worst[k] = (err, abs(f.abs().sum().item() - g['grad.' + k + '.abssum']) / g['grad.' + k + '.abssum'])
     for k, v in worst.items():
         print('%-70s sample rel err %.2e  abssum rel err %.2e' % (k, v[0], v[1]))
-    bad = {k: v for k, v in worst.items() if v[0] > 5e-2 or v[1] > 5e-2}
+    bad = {k: v for k, v in worst.items() if v[0] > 8e-2 or v[1] > (5e-2 if B == 2 else 1e-2)}
     assert not bad, bad
 
 
@@ -219,3 +226,39 @@ def test_siamese_train_matches_reference_golden(golden):
     assert _rel(siam.featQ.weight.grad[:, ::64].cpu().numpy(), g['train.grad_featQ_w']) < 2e-3
     assert _rel(siam.classifierlinear.weight.grad.cpu().numpy(), g['train.grad_cls_w']) < 2e-3
     assert _rel(siam.featQ_bn.running_mean.cpu().numpy(), g['train.featQ_bn_rm']) < 1e-4
+
+
+def test_trainer_steps_run_on_hip():
+    """Two SEQTrainer iterations (reference loss composition, SGD+nesterov as
+    mars_train.py:94-108) on synthetic pairs: finite loss, parameters move, OIM LUT rows
+    of the batch identities become unit vectors, eval path still works afterwards."""
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.reid.data import SyntheticPairs
+    from torch.utils.data import DataLoader
+    cnn, siam, siamv = _fresh_models()
+    dev = torch.device('cuda:0')
+    crit_c, crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    trainer = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+    params = [p for m in (cnn, siam, siamv) for p in m.parameters()]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    loader = DataLoader(SyntheticPairs(4, 2), batch_size=4, shuffle=False, drop_last=True)
+    w0 = cnn.backbone.base[0].weight.detach().clone()
+    f0 = cnn.temporal_learning_block.forward_f1[0].weight.detach().clone()
+    q0 = siam.featQ.weight.detach().clone()
+    trainer.train(0, loader, opt)
+    assert len(loader) == 2
+    for p in (cnn.backbone.base[0].weight, cnn.temporal_learning_block.forward_f1[0].weight, siam.featQ.weight):
+        assert bool(torch.isfinite(p).all())
+    assert float((cnn.backbone.base[0].weight - w0).abs().max()) > 0
+    assert float((cnn.temporal_learning_block.forward_f1[0].weight - f0).abs().max()) > 0
+    assert float((siam.featQ.weight - q0).abs().max()) > 0
+    assert siam.featV.weight.grad is None                   # unused upstream as well
+    rows = crit_c.lut.norm(dim=1)
+    assert int((rows > 0).sum()) >= 1 and float((rows[rows > 0] - 1).abs().max()) < 1e-5
+    assert int(cnn.backbone.base[1].num_batches_tracked) == 2
+    assert int(cnn.temporal_learning_block.uncorr_memo_forward.bn1.num_batches_tracked) == 4   # T calls per forward
+    from grl_amd import engine
+    cnn.eval(); siam.eval()
+    feat = engine.extract_features(cnn, siam, synth_clips(2, 2, seed=9).cuda())
+    assert bool(torch.isfinite(feat).all())

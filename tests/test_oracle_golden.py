@@ -46,17 +46,18 @@ def test_eval_forward_matches_reference(golden, synth_models):
     _close(O.extract_features(sd, ssd, clips), g['feat'])
 
 
-def test_train_forward_backward_matches_reference(golden, synth_models):
+@pytest.mark.parametrize('B,T,seed,fname', [(2, 4, 0, 'grl_train_b2t4.npz'), (4, 2, 2, 'grl_train_b4t2.npz')])
+def test_train_forward_backward_matches_reference(golden, synth_models, B, T, seed, fname):
     cnn, _, _ = synth_models
-    g = golden('grl_train_b2t4.npz')
+    g = golden(fname)
     sd = _state(cnn)
     for k, v in sd.items():
         if v.dtype.is_floating_point and 'running' not in k:
             v.requires_grad_(True)
     rg = np.random.Generator(np.random.PCG64(7))
-    r1 = torch.from_numpy(rg.standard_normal((2, 2048)).astype(np.float32))
-    r2 = torch.from_numpy(rg.standard_normal((2, 4, 2048)).astype(np.float32))
-    x = synth_clips(2, 4, seed=0).requires_grad_(True)
+    r1 = torch.from_numpy(rg.standard_normal((B, 2048)).astype(np.float32))
+    r2 = torch.from_numpy(rg.standard_normal((B, T, 2048)).astype(np.float32))
+    x = synth_clips(B, T, seed=seed).requires_grad_(True)
     xu, xc = O.grl_forward(sd, x, train=True)
     loss = (xu * r1).sum() + (xc * r2).sum()
     loss.backward()

@@ -21,6 +21,8 @@
 // the ds_read_b128 of the fragment reads bank-conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/grl_hip.h"
 #include "common.h"
 
@@ -302,6 +304,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 struct TileChoice { int bm, bn; };
 
 TileChoice choose_tile(const GrlGemm& d) {
+    // GRL_GEMM_TILE=128x128|128x64|64x64 forces a tile (kernel tuning only)
+    if (const char* e = getenv("GRL_GEMM_TILE")) {
+        int bm = 0, bn = 0;
+        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) &&
+            !(bm == 64 && bn == 128))
+            return {bm, bn};
+    }
     // Prefer the 128x128 tile; fall back to smaller tiles when the grid would not
     // give every CU (256 of them, 2 resident workgroups each) something to do.
     auto tiles = [&](int bm, int bn) {

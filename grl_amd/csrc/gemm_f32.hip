@@ -311,12 +311,17 @@ TileChoice choose_tile(const GrlGemm& d) {
             !(bm == 64 && bn == 128))
             return {bm, bn};
     }
-    // Prefer the 128x128 tile; fall back to smaller tiles when the grid would not
-    // give every CU (256 of them, 2 resident workgroups each) something to do.
+    // Measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 128x128
+    // tile wins when the K loop is long (>= 1024: 131-135 TFLOP/s); short-K layers are
+    // prologue/epilogue bound and want more, smaller workgroups per CU (K <= 128: 64x64,
+    // K <= 512: 128x64).  Small grids fall back to smaller tiles so that every CU (256,
+    // two resident workgroups each) has work.
     auto tiles = [&](int bm, int bn) {
         return (int64_t)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
     };
     if (d.N <= 64) return tiles(128, 64) >= 512 ? TileChoice{128, 64} : TileChoice{64, 64};
+    if (d.K <= 128) return {64, 64};
+    if (d.K <= 512) return tiles(128, 64) >= 448 ? TileChoice{128, 64} : TileChoice{64, 64};
     if (tiles(128, 128) >= 448) return {128, 128};
     if (tiles(128, 64) >= 448) return {128, 64};
     return {64, 64};

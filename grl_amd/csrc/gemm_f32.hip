@@ -28,6 +28,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -38,15 +40,27 @@ struct RowInfo {          // per staged A row: where it comes from
     int iy0, ix0;         // conv: top-left input coordinate of the window
 };
 
-template <int BM, int BN, bool CONV>
+// MATH selects the multiplier datapath (the accumulator is always fp32):
+//   0  exact fp32: v_mfma_f32_32x32x2_f32 (the documented fmaf chain; default)
+//   1  bf16 operands (rounded to nearest-even while staging), v_mfma_f32_32x32x16_bf16
+//   3  split-bf16 ("bf16x3"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product
+//      is hi*hi + hi*lo + lo*hi on the bf16 MFMA (3/16 of the fp32 MFMA cycles); the
+//      dropped lo*lo term and the 16-bit operand significands give ~2^-16 relative error
+//      per product -- fp32-class accuracy for the 1e-3 parity budget, NOT bit-exact.
+// In modes 1/3 operands stay fp32 in HBM and are converted in the staging pass; LDS
+// rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
+template <int BM, int BN, bool CONV, int MATH>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
                                                            const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [2][BM*32]
+    float* As = smem;                     // [2][BM*32]           (MATH == 0)
     float* Bs = smem + 2 * BM * BK;       // [2][BN*32]
+    constexpr int PL = MATH == 3 ? 2 : 1; // bf16 planes per operand (hi, lo)
+    char* const Ah = reinterpret_cast<char*>(smem);                // [2][PL][BM][64 B]
+    char* const Bh = Ah + 2 * PL * BM * 64;                        // [2][PL][BN][64 B]
 
     // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch);
     // give each XCD a contiguous run of tiles so that the W panel / A panel re-reads
@@ -114,18 +128,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         for (int i = 0; i < B_ITEMS; ++i)
             breg[i] = *reinterpret_cast<const f32x4*>(p.w + bofs[i] + k0 + ld_chunk * 4);
     };
-    auto store_stage = [&](int buf) {
+    auto split_store = [&](char* plane0, int plane_bytes, int row, const f32x4 v) {
+        const int off = row * 64 + (((ld_chunk >> 1) ^ ((row >> 2) & 3)) << 4) + (ld_chunk & 1) * 8;
+        bf16x4 hi;
 #pragma unroll
-        for (int i = 0; i < A_ITEMS; ++i) {
-            const int row = ld_row + 32 * i;
-            *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK +
-                                      ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = areg[i];
+        for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(plane0 + off) = hi;
+        if (MATH == 3) {
+            bf16x4 lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+            *reinterpret_cast<bf16x4*>(plane0 + plane_bytes + off) = lo;
         }
+    };
+    auto store_stage = [&](int buf) {
+        if constexpr (MATH == 0) {
 #pragma unroll
-        for (int i = 0; i < B_ITEMS; ++i) {
-            const int row = ld_row + 32 * i;
-            *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK +
-                                      ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = breg[i];
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int row = ld_row + 32 * i;
+                *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK +
+                                          ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = areg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i) {
+                const int row = ld_row + 32 * i;
+                *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK +
+                                          ((ld_chunk ^ ((row >> 1) & 7)) << 2)) = breg[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i)
+                split_store(Ah + buf * PL * BM * 64, BM * 64, ld_row + 32 * i, areg[i]);
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i)
+                split_store(Bh + buf * PL * BN * 64, BN * 64, ld_row + 32 * i, breg[i]);
         }
     };
 
@@ -147,32 +183,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_stage(ks + 1);
-        const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
-        const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
+        if constexpr (MATH == 0) {
+            const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
+            const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 af[MT], bf[NT];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = i * 32 + frow;
-                // (wm*WTM) is a multiple of 32, so (row>>1)&7 equals the tile-local swizzle
-                af[i] = *reinterpret_cast<const f32x4*>(
-                    Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                for (int i = 0; i < MT; ++i) {
+                    const int row = i * 32 + frow;
+                    // (wm*WTM) is a multiple of 32, so (row>>1)&7 equals the tile-local swizzle
+                    af[i] = *reinterpret_cast<const f32x4*>(
+                        Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = j * 32 + frow;
+                    bf[j] = *reinterpret_cast<const f32x4*>(
+                        Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
+                                                                             acc[i][j], 0, 0, 0);
             }
+        } else {
+            const char* Ab = Ah + buf * PL * BM * 64 + (wm * WTM) * 64;
+            const char* Bb = Bh + buf * PL * BN * 64 + (wn * WTN) * 64;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int row = j * 32 + frow;
-                bf[j] = *reinterpret_cast<const f32x4*>(
-                    Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
-            }
+            for (int s = 0; s < 2; ++s) {                 // two K = 16 steps per 32-wide stage
+                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int i = 0; i < MT; ++i) {
+                    const int row = i * 32 + frow;
+                    const int off = row * 64 + (((2 * s + fhalf) ^ ((row >> 2) & 3)) << 4);
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ab + off);
+                    if (MATH == 3) al[i] = *reinterpret_cast<const bf16x8*>(Ab + BM * 64 + off);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = j * 32 + frow;
+                    const int off = row * 64 + (((2 * s + fhalf) ^ ((row >> 2) & 3)) << 4);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bb + off);
+                    if (MATH == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Bb + BN * 64 + off);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
-                                                                         acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if (MATH == 3) {                  // small terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
@@ -327,26 +396,35 @@ TileChoice choose_tile(const GrlGemm& d) {
     return {64, 64};
 }
 
-template <int BM, int BN>
-int launch(const GrlGemm& d, hipStream_t s) {
+template <int BM, int BN, int MATH>
+int launch_math(const GrlGemm& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    static_assert((size_t)BM * BN <= (size_t)2 * (BM + BN) * BK, "C staging must fit the A/B stages");
+    constexpr size_t stage_bytes = MATH == 0 ? (size_t)2 * (BM + BN) * BK * sizeof(float)
+                                             : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
+    constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
+    constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (d.conv) {
-        auto k = gemm_f32_kernel<BM, BN, true>;
+        auto k = gemm_f32_kernel<BM, BN, true, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     } else {
-        auto k = gemm_f32_kernel<BM, BN, false>;
+        auto k = gemm_f32_kernel<BM, BN, false, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
+}
+
+template <int BM, int BN>
+int launch(const GrlGemm& d, hipStream_t s) {
+    if (d.math == GRL_MATH_BF16X3) return launch_math<BM, BN, 3>(d, s);
+    if (d.math == GRL_MATH_BF16) return launch_math<BM, BN, 1>(d, s);
+    return launch_math<BM, BN, 0>(d, s);
 }
 
 int validate(const GrlGemm& d) {
@@ -362,6 +440,8 @@ int validate(const GrlGemm& d) {
     } else if (d.lda % 4) {
         return grl_fail(GRL_EINVAL, "gemm: lda % 4 != 0");
     }
+    if (d.math != GRL_MATH_F32 && d.math != GRL_MATH_BF16 && d.math != GRL_MATH_BF16X3)
+        return grl_fail(GRL_EINVAL, "gemm: unknown math mode");
     if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");

@@ -22,6 +22,38 @@ import torch
 from . import _lib
 from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, check, ptr, require_device
 
+import contextlib
+import os
+
+from ._lib import MATH_F32, MATH_BF16, MATH_BF16X3
+
+_MATH_NAMES = {'f32': MATH_F32, 'bf16': MATH_BF16, 'bf16x3': MATH_BF16X3}
+# Multiplier datapath of the conv / linear GEMMs (accumulation is always fp32):
+#   'f32'    exact fp32 MFMA, the default and the mode every parity claim is made in;
+#   'bf16x3' split-bf16 (hi*hi + hi*lo + lo*hi), ~2^-16 relative per product;
+#   'bf16'   operands rounded to bf16 (BASELINE configs[2]).
+# The evaluator distance matrices always use 'f32' (bit-exact ranking contract).
+_math = [_MATH_NAMES[os.environ.get('GRL_MATH', 'f32')]]
+
+
+def set_math(name):
+    _math[0] = _MATH_NAMES[name]
+
+
+def get_math():
+    return {v: k for k, v in _MATH_NAMES.items()}[_math[0]]
+
+
+@contextlib.contextmanager
+def math_mode(name):
+    old = _math[0]
+    set_math(name)
+    try:
+        yield
+    finally:
+        _math[0] = old
+
+
 BN_EPS = 1e-5
 PIX = 128            # 16 x 8 feature map of layer4 (basebranch.py:59 hard-codes it)
 
@@ -35,7 +67,7 @@ def _new(shape, like):
 
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
-         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None):
+         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -56,6 +88,7 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.rows_per_group = rows_per_group
     d.relu = 1 if relu else 0
     d.epilogue = epilogue
+    d.math = _math[0] if math is None else math
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
@@ -425,7 +458,7 @@ def cosin_dist(qf, gf):
     m, k = qf.shape
     n = gf.shape[0]
     out = _new((m, n), qf)
-    return gemm(qf, gf, out, m, n, k, epilogue=EPI_NEGDOT)
+    return gemm(qf, gf, out, m, n, k, epilogue=EPI_NEGDOT, math=MATH_F32)
 
 
 def pairwise_distance_tensor(x, y):
@@ -438,4 +471,4 @@ def pairwise_distance_tensor(x, y):
     _call('grl_row_sqnorm', ptr(x), ptr(rn), m, k, k)
     _call('grl_row_sqnorm', ptr(y), ptr(cn), n, k, k)
     out = _new((m, n), x)
-    return gemm(x, y, out, m, n, k, epilogue=EPI_EUCLID, rnorm=rn, cnorm=cn)
+    return gemm(x, y, out, m, n, k, epilogue=EPI_EUCLID, rnorm=rn, cnorm=cn, math=MATH_F32)

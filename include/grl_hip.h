@@ -39,6 +39,11 @@ int grl_abi_version(void);
 #define GRL_EPI_NEGDOT  1   /* y = -acc                                     (attevaluator.py:44-46)  */
 #define GRL_EPI_EUCLID  2   /* y = sqrt(max(rnorm[m]+cnorm[n]-2acc,1e-12))  (attevaluator.py:33-41)  */
 
+/* multiplier datapath of grl_conv_gemm_f32 (operands are fp32 in HBM in every mode) */
+#define GRL_MATH_F32     0  /* exact fp32 MFMA: the documented fmaf chain (default)              */
+#define GRL_MATH_BF16    1  /* operands rounded to bf16 while staging, bf16 MFMA (BASELINE cfg 2) */
+#define GRL_MATH_BF16X3  3  /* split-bf16: hi*hi + hi*lo + lo*hi on the bf16 MFMA, ~2^-16 rel.   */
+
 /*
  * One fp32 MFMA GEMM  Y[M][N] = epilogue( A[M][K] . W[N][K]^T ), K-contiguous on
  * both operands.  With conv geometry set, A is gathered on the fly from a
@@ -74,6 +79,7 @@ typedef struct GrlGemm {
     int32_t epilogue;      /* GRL_EPI_*                                                   */
     /* conv geometry; conv == 0 means dense A */
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
+    int32_t math;          /* GRL_MATH_*: multiplier datapath (accumulation is always fp32)   */
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);

@@ -211,3 +211,25 @@ def test_empty_and_bad_arguments_raise(dev):
         engine.gemm(x, x, x, 0, 64, 32)
     with pytest.raises(GrlHipError):          # T > 16
         engine._call('grl_siamese_attn', ptr(x), ptr(x), ptr(x), 1, 17, 512, 2048, 2048)
+
+
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 3e-5), ('bf16', 2e-2)])
+def test_gemm_bf16_math_modes(dev, mode, tol):
+    """Alternative multiplier datapaths: split-bf16 is fp32-class (error relative to
+    sum |a||b| ~ 2^-16), plain bf16 is the BASELINE configs[2] mode."""
+    from grl_amd import engine, _lib
+    rng = np.random.default_rng(17)
+    for (M, N, K, conv) in ((512, 256, 2048, None), (300, 200, 96, None), (128 * 3, 128, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1))):
+        a = rng.standard_normal((M, K if conv is None else 64)).astype(np.float32)
+        w = rng.standard_normal((N, K)).astype(np.float32)
+        ad, wd = torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev)
+        y = torch.empty(M, N, device=dev)
+        y32 = torch.empty(M, N, device=dev)
+        engine.gemm(ad, wd, y, M, N, K, conv=conv, math={'bf16x3': 3, 'bf16': 1}[mode])
+        engine.gemm(ad, wd, y32, M, N, K, conv=conv, math=0)
+        ref = y32.cpu().double().numpy()
+        if conv is None:
+            denom = (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T).max()
+        else:
+            denom = np.abs(ref).max() * 10
+        assert np.abs(y.cpu().double().numpy() - ref).max() / denom < tol, (mode, M, N, K)

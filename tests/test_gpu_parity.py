@@ -262,3 +262,21 @@ def test_trainer_steps_run_on_hip():
     cnn.eval(); siam.eval()
     feat = engine.extract_features(cnn, siam, synth_clips(2, 2, seed=9).cuda())
     assert bool(torch.isfinite(feat).all())
+
+
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16', 5e-2)])
+def test_eval_forward_alternative_math_modes(golden, gpu_models, mode, tol):
+    """The opt-in bf16 datapaths against the reference golden: split-bf16 stays inside the
+    north star's 1e-3 fp32 parity budget; plain bf16 (BASELINE configs[2]) gets its own
+    looser bound.  The default (exact fp32) is what every other test pins."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    g = golden('grl_eval_b2t4.npz')
+    clips = synth_clips(2, 4, seed=0).cuda()
+    with engine.math_mode(mode):
+        assert engine.get_math() == mode
+        feat = engine.extract_features(cnn, siam, clips)
+    assert engine.get_math() == 'f32'
+    err = _rel(feat.cpu().numpy(), g['feat'])
+    print('%s: feature rel err vs reference %.2e' % (mode, err))
+    assert err < tol

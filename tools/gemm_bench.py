@@ -23,6 +23,10 @@ SHAPES = [  # (M, N, K, conv, calls per step, epilogue: res?)
 
 
 def bench(tile, iters=5):
+    math = 0
+    if tile in ('bf16x3', 'bf16', 'f32'):
+        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[tile]
+        tile = 'auto'
     if tile == 'auto':
         os.environ.pop('GRL_GEMM_TILE', None)
     else:
@@ -40,11 +44,11 @@ def bench(tile, iters=5):
         sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
         r = torch.randn(M, N, device=dev) if has_res else None
         for _ in range(2):
-            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=r, relu=True, conv=conv)
+            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=r, relu=True, conv=conv, math=math)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=r, relu=True, conv=conv)
+            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=r, relu=True, conv=conv, math=math)
         e1.record()
         torch.cuda.synchronize()
         res[(M, N, K, conv is not None)] = (e0.elapsed_time(e1) / iters, calls, 2.0 * M * N * K)

@@ -111,6 +111,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+                    help="multiplier datapath of the conv GEMMs for the headline `value` "
+                         "(default: exact fp32 MFMA = BASELINE configs[1])")
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 measurements')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -131,6 +135,7 @@ def main():
     _lib.load()
     cnn, siam, sd, ssd = build_models(dev)
     clips = synth_clips(B, T, seed=rank).to(dev)
+    engine.set_math(args.math)
 
     def barrier():
         if dist is not None:
@@ -176,6 +181,27 @@ def main():
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (launches, gemm_ms, flops / 1e9)},
             "end_to_end_tflops": round(value / n * GFLOP_PER_CLIP / 1e3, 2),
         }
+        out["config"]["math"] = args.math
+        if n == 1 and not args.no_alt:
+            # secondary, informational: the opt-in bf16 multiplier datapaths on the SAME
+            # workload, with their deviation from the exact-fp32 features measured live
+            alt = {}
+            for mode in ('bf16x3', 'bf16'):
+                if mode == args.math:
+                    continue
+                with engine.math_mode(mode):
+                    for _ in range(3):
+                        f2 = engine.extract_features(cnn, siam, clips)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        f2 = engine.extract_features(cnn, siam, clips)
+                    torch.cuda.synchronize()
+                    d2 = time.perf_counter() - t1
+                alt[mode] = {"value": round(B * args.steps / d2, 2), "ms_per_step": round(d2 / args.steps * 1e3, 3),
+                             "max_rel_dev_vs_headline_features": float(
+                                 ((f2 - feat).abs().max() / feat.abs().max()).item())}
+            out["alt_math"] = alt
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
         print(json.dumps(out))

@@ -105,6 +105,67 @@ def cpu_baseline(sd, ssd):
                       "step, T=%d, %d timed passes (%.1f s)" % (cores, nb, T, passes, dt)}
 
 
+def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
+    """Secondary series: train clips/sec.  One step = SEQTrainer's
+    forward (train-mode BN) + reference loss composition + HIP backward + the flat
+    gradient all-reduce when world > 1 + SGD(nesterov) step, on B x T = 32 x 4 synthetic
+    pair-interleaved clips per rank (mars_train.py -b 32 --seq_len 4)."""
+    from grl_amd.reid import models
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.synthetic import synth_clips, synth_state_dict
+    from grl_amd import dist as grl_dist
+    siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
+    siamv.to(dev)
+    crit_c = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    trainer = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+    params = trainer._all_params()
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    cnn.train(); siam.train(); siamv.train()
+    clips = synth_clips(B, T, seed=rank).to(dev)
+    pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
+    bucket = grl_dist.GradBucket(params) if world > 1 else None
+
+    def step():
+        loss, _, _, _ = trainer._forward([clips], pids, 0, 0)
+        opt.zero_grad()
+        loss.backward()
+        if bucket is not None:
+            bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(loss).all())
+    if rank == 0:
+        n = max(world, 1)
+        value = n * B * args.steps / dt
+        print(json.dumps({
+            "metric": "train clips/sec", "value": round(value, 2), "unit": "clips/sec", "n_gpus": n,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = 32 x 4 per GPU",
+                       "clips_per_gpu": B, "seq_len": T, "math": args.math,
+                       "parallelism": "dp%d (one RCCL all-reduce of the flat grad bucket per step)" % n},
+            "end_to_end_tflops": round(value / n * 173.8 / 1e3, 2)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -115,6 +176,9 @@ def main():
                     help="multiplier datapath of the conv GEMMs for the headline `value` "
                          "(default: exact fp32 MFMA = BASELINE configs[1])")
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 measurements')
+    ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
+                    help="eval (default): the headline clip-features/sec; train: secondary series, one "
+                         "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,6 +205,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.mode == 'train':
+        return train_bench(args, cnn, siam, dev, dist, rank, world, barrier)
 
     for _ in range(args.warmup):
         feat = engine.extract_features(cnn, siam, clips)

@@ -46,31 +46,59 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     }
 }
 
-// out[c] (+)= sum_r slab[r*stride + c]
-__global__ void slab_sum_kernel(const float* __restrict__ slab, int rows, int64_t stride, int C,
-                                float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_r slab[r*stride + c]      (64 channels x 16 row groups per workgroup)
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slab, int rows,
+                                                        int64_t stride, int C,
+                                                        float* __restrict__ out, int accumulate) {
+    __shared__ double sh[16 * 64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += slab[(int64_t)r * stride + c];
-    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+    if (c < C)
+        for (int r = ry; r < rows; r += 16) s += slab[(int64_t)r * stride + c];
+    sh[ry * 64 + cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        s = 0.0;
+        for (int g = 0; g < 16; ++g) s += sh[g * 64 + cx];
+        out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+    }
+}
+
+// Sum the [rows][2][C] partial slab for 64 channels with 16 row groups (1024 threads),
+// fp64 accumulation; returns the two totals to the threads of row group 0.
+__device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int rows, int C, int c,
+                                            double* sh /*[2][16][64]*/, double& s, double& q) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    s = 0.0; q = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = ry; r < rows; r += 16) {
+            s += slab[((int64_t)r * 2 + 0) * C + c];
+            q += slab[((int64_t)r * 2 + 1) * C + c];
+        }
+    }
+    sh[ry * 64 + cx] = s;
+    sh[1024 + ry * 64 + cx] = q;
+    __syncthreads();
+    if (ry == 0) {
+        s = 0.0; q = 0.0;
+        for (int g = 0; g < 16; ++g) { s += sh[g * 64 + cx]; q += sh[1024 + g * 64 + cx]; }
+    }
 }
 
 // BN forward finalize: batch mean / biased var from the partial slab, running-stat
 // update (PyTorch: running = (1-m)*running + m*stat, unbiased var for the running
 // estimate), folded scale/shift for the apply pass.
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ slab, int rows, int C,
-                                         double count, const float* gamma, const float* beta,
-                                         float* running_mean, float* running_var, float momentum,
-                                         float eps, float* mean, float* invstd, float* scale,
-                                         float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s += slab[((int64_t)r * 2 + 0) * C + c];
-        q += slab[((int64_t)r * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
+    const float* __restrict__ slab, int rows, int C, double count, const float* gamma,
+    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double sh[2 * 16 * 64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, q;
+    slab_totals(slab, rows, C, c, sh, s, q);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
     const double mu = s / count;
     double var = q / count - mu * mu;
     var = var > 0.0 ? var : 0.0;
@@ -141,16 +169,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 
 // finalize pass 1: dgamma += sum g*xhat, dbeta += sum g, coef[0][c] = sum g / M,
 // coef[1][c] = sum g*xhat / M
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
-                                       double count, float* dgamma, float* dbeta,
-                                       float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s += slab[((int64_t)r * 2 + 0) * C + c];
-        q += slab[((int64_t)r * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ slab,
+                                                               int rows, int C, double count,
+                                                               float* dgamma, float* dbeta,
+                                                               float* __restrict__ coef) {
+    __shared__ double sh[2 * 16 * 64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, q;
+    slab_totals(slab, rows, C, c, sh, s, q);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
     if (dbeta) dbeta[c] += (float)s;
     if (dgamma) dgamma[c] += (float)q;
     coef[c] = (float)(s / count);
@@ -503,7 +530,7 @@ extern "C" int grl_col_stats(const float* x, float* slab, int M, int C, int ld, 
 extern "C" int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out, int accumulate,
                             void* stream) {
     GRL_REQUIRE(slab && out && rows > 0 && C > 0, "slab_sum: bad args");
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grl_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, slab, rows,
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, slab, rows,
                        stride, C, out, accumulate);
     return grl_check_launch("grl_slab_sum");
 }
@@ -514,7 +541,7 @@ extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t
                                      void* stream) {
     GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
     GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, slab,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, slab,
                        rows, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                        scale, shift);
     return grl_check_launch("grl_bn_stats_finalize");
@@ -537,7 +564,7 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
                        invstd, slab_ws, M, C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 128)), dim3(128), 0, s, slab_ws, rows, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, s, slab_ws, rows, C,
                        (double)M, dgamma, dbeta, coef_ws);
     const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,

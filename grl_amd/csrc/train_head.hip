@@ -297,6 +297,37 @@ __global__ void pair_sqdiff_bwd_kernel(const float* __restrict__ p, const float*
     }
 }
 
+// OIM look-up-table update (reid/loss/oim.py:24-26): for every sample, in batch order,
+//   lut[y] = m*lut[y] + (1-m)*x ; lut[y] /= |lut[y]|.
+// Updates of different labels commute, updates of one label do not: one workgroup per
+// label (the workgroup of the label's FIRST sample) replays that label's samples in order.
+__global__ __launch_bounds__(256) void oim_update_kernel(float* __restrict__ lut,
+                                                         const float* __restrict__ x,
+                                                         const int64_t* __restrict__ labels, int n,
+                                                         int D, float m) {
+    __shared__ float red[16];
+    const int i = blockIdx.x;
+    const int64_t y = labels[i];
+    for (int j = 0; j < i; ++j)
+        if (labels[j] == y) return;                       // not the first sample of this label
+    float* row = lut + y * (int64_t)D;
+    for (int j = i; j < n; ++j) {
+        if (labels[j] != y) continue;                     // uniform across the workgroup
+        float ss = 0.f;
+        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(row + c) * m +
+                      *reinterpret_cast<const f32x4*>(x + (int64_t)j * D + c) * (1.f - m);
+            *reinterpret_cast<f32x4*>(row + c) = r;
+            ss += dot4(r, r);
+        }
+        ss = block_sum(ss, red);
+        const float inv = 1.f / sqrtf(ss);
+        for (int c = threadIdx.x * 4; c < D; c += 1024)
+            *reinterpret_cast<f32x4*>(row + c) = *reinterpret_cast<const f32x4*>(row + c) * inv;
+        __syncthreads();
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -385,4 +416,11 @@ extern "C" int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* 
     hipLaunchKernelGGL(pair_sqdiff_bwd_kernel, dim3(grl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, p,
                        g, ddiff, dp, dg, np, ng, K / 4);
     return grl_check_launch("grl_pair_sqdiff_bwd");
+}
+
+extern "C" int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, float momentum,
+                              void* stream) {
+    GRL_REQUIRE(lut && x && labels && n > 0 && D % 4 == 0, "oim_update: bad args");
+    hipLaunchKernelGGL(oim_update_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, lut, x, labels, n, D, momentum);
+    return grl_check_launch("grl_oim_update");
 }

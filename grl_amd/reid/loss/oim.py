@@ -35,9 +35,16 @@ class OIM(autograd.Function):
             dist.all_gather(xl, xs.contiguous())
             dist.all_gather(yl, ys.contiguous())
             xs, ys = torch.cat(xl), torch.cat(yl)
-        for x, y in zip(xs, ys.tolist()):             # sequential per sample (oim.py:24-26)
-            row = m * lut[y] + (1. - m) * x
-            lut[y] = row / row.norm()
+        if lut.is_cuda:                               # one HIP launch, no host sync
+            from grl_amd import _lib
+            import ctypes as C
+            xs, ys = xs.contiguous().float(), ys.contiguous().long()
+            _lib.check(_lib.load().grl_oim_update(lut.data_ptr(), xs.data_ptr(), ys.data_ptr(), xs.size(0),
+                                                  xs.size(1), C.c_float(m), _lib.stream()), 'grl_oim_update')
+        else:
+            for x, y in zip(xs, ys.tolist()):         # sequential per sample (oim.py:24-26)
+                row = m * lut[y] + (1. - m) * x
+                lut[y] = row / row.norm()
         return grad_inputs, None, None, None
 
 

@@ -253,6 +253,11 @@ int grl_pair_sqdiff(const float* p, const float* g, float* diff, int np, int ng,
 int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* ddiff, float* dp, float* dg,
                         int np, int ng, int K, void* stream);
 
+/* OIM look-up-table update performed inside OIM.backward (reid/loss/oim.py:24-26): per sample,
+ * in batch order, lut[y] = m*lut[y] + (1-m)*x, then renormalise the row.  labels: int64. */
+int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, float momentum,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,3 +131,20 @@ def test_wgrad_dense_shapes():
         TE.wgrad(dzd, xd, dw, M, N, K, k_out=k_out, accumulate=1)
         ref = 1.0 + dz.astype(np.float64).T @ x.astype(np.float64)[:, :ko]
         assert _rel(dw.cpu().numpy(), ref) < 1e-5, (M, N, K)
+
+
+def test_oim_update_kernel_matches_sequential_loop():
+    from grl_amd.reid.loss import OIMLoss
+    dev = torch.device('cuda:0')
+    torch.manual_seed(1)
+    x = F.normalize(torch.randn(24, 2048), dim=1)
+    y = torch.tensor([5, 5, 5, 5, 9, 9, 9, 9, 5, 5, 2, 2, 7, 7, 7, 7, 9, 9, 0, 0, 5, 2, 7, 0])
+    cpu, gpu = OIMLoss(2048, 12, scalar=30, momentum=0.5), OIMLoss(2048, 12, scalar=30, momentum=0.5).to(dev)
+    init = F.normalize(torch.randn(12, 2048), dim=1)
+    cpu.lut.copy_(init); gpu.lut.copy_(init)
+    xa, xb = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
+    la, _ = cpu(xa, y); la.backward()
+    lb, _ = gpu(xb, y.to(dev)); lb.backward()
+    assert abs(la.item() - lb.item()) < 1e-5
+    assert _rel(xb.grad.cpu().numpy(), xa.grad.numpy()) < 1e-5
+    assert _rel(gpu.lut.cpu().numpy(), cpu.lut.numpy()) < 1e-5

@@ -283,3 +283,40 @@ def test_eval_forward_alternative_math_modes(golden, gpu_models, mode, tol):
     err = _rel(feat.cpu().numpy(), g['feat'])
     print('%s: feature rel err vs reference %.2e' % (mode, err))
     assert err < tol
+
+
+def test_attevaluator_end_to_end_both_modes(gpu_models, capsys):
+    """ATTEvaluator.evaluate on synthetic loaders: rrs_test mode (mars_train.py) and the
+    dense per-tracklet mode of test_all.py (chunks of 8 clips, clip-averaged features,
+    attevaluator.py:68-98) against the oracle's feature rows; prints the reference's
+    'Mean AP / Rank-k' lines and returns Rank-1."""
+    from grl_amd.reid.evaluator import ATTEvaluator
+    from oracle import grl_oracle as O
+    cnn, siam, _ = gpu_models
+    sd = {k: v.detach().cpu() for k, v in cnn.state_dict().items()}
+    ssd = {k: v.detach().cpu() for k, v in siam.state_dict().items()}
+    T = 2
+    rng = np.random.Generator(np.random.PCG64(3))
+
+    def items(n, seed):
+        clips = synth_clips(n, T, seed=seed)
+        pids = torch.from_numpy(rng.integers(0, 3, n))
+        cams = torch.from_numpy(rng.integers(0, 2, n))
+        return clips, pids, cams
+    q, g = items(4, 21), items(6, 22)
+    ev = ATTEvaluator(cnn, siam, only_eval=False)
+    qf, qp, qc = ev.extract_feature([q])
+    assert _rel(qf.cpu().numpy(), O.extract_features(sd, ssd, q[0]).numpy()) < TOL
+    assert list(qp) == list(q[1].numpy())
+    import grl_amd.reid.evaluator.eva_functions as EF
+    r1 = ev.evaluate(None, None, [q], [g], None, False, False)
+    out = capsys.readouterr().out
+    assert 'Mean AP:' in out and 'Rank-1' in out and 0.0 <= r1 <= 1.0
+    with pytest.raises(NotImplementedError):
+        ev.evaluate(None, None, [q], [g], None, False, True)          # re-ranking: not provided
+    # dense mode: one tracklet of 11 clips -> chunks 8 + 3, features averaged over clips
+    dense = synth_clips(11, T, seed=31).unsqueeze(0)
+    evd = ATTEvaluator(cnn, siam, only_eval=True)
+    df, dp, _ = evd.extract_feature([(dense, torch.tensor([7]), torch.tensor([1]))])
+    ref = O.extract_features(sd, ssd, dense[0]).mean(dim=0, keepdim=True)
+    assert df.shape == (1, 6144) and _rel(df.cpu().numpy(), ref.numpy()) < TOL and int(dp[0]) == 7

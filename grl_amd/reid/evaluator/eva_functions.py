@@ -43,7 +43,10 @@ def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100):
             continue
         first = hits.cumsum()
         first[first > 1] = 1
-        all_cmc.append(first[:max_rank])
+        first = first[:max_rank]
+        if first.size < max_rank:       # fewer than max_rank gallery entries left for this query: the
+            first = np.concatenate([first, np.full(max_rank - first.size, first[-1])])  # curve stays flat
+        all_cmc.append(first)           # (the reference builds a ragged array and raises here)
         prec = hits.cumsum() / (np.arange(hits.size) + 1.0)
         all_ap.append((prec * hits).sum() / hits.sum())
     assert len(all_cmc) > 0, "Error: all query identities do not appear in gallery"

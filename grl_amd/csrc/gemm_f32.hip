@@ -51,8 +51,7 @@ struct RowInfo {          // per staged A row: where it comes from
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
 template <int BM, int BN, bool CONV, int MATH>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
-                                                           const int num_tiles, const int vec_epi,
-                                                           const int early_store) {
+                                                           const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
@@ -189,9 +188,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                // the other LDS stage has been free since the last barrier: park the prefetched
-                // tile mid-stage, under the remaining MFMAs, instead of after the last one
-                if (q == 2 && early_store && ks + 1 < nk) store_stage(buf ^ 1);
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -247,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                     }
             }
         }
-        if ((MATH != 0 || !early_store) && ks + 1 < nk) store_stage(buf ^ 1);
+        if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
     }
 
@@ -412,15 +408,14 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
     const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
-    static const int early_store = getenv("GRL_GEMM_LATE_STORE") ? 0 : 1;
     if (d.conv) {
         auto k = gemm_f32_kernel<BM, BN, true, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi, early_store);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     } else {
         auto k = gemm_f32_kernel<BM, BN, false, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi, early_store);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
 }

@@ -103,12 +103,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         bofs[i] = (int64_t)n * p.ldw;
     }
 
-    // register staging: one set for the fp32 path (prefetch distance 1 stage); the bf16 paths
-    // run a stage 5-16x faster, so they prefetch TWO stages ahead (second set) to keep the
-    // global-load latency covered.
-    constexpr int NSETS = MATH == 0 ? 1 : 2;
-    f32x4 aregs[NSETS][A_ITEMS], bregs[NSETS][B_ITEMS];
-    auto load_stage = [&](int ks, f32x4 (&areg)[A_ITEMS], f32x4 (&breg)[B_ITEMS]) {
+    f32x4 areg[A_ITEMS], breg[B_ITEMS];
+    auto load_stage = [&](int ks) {
         const int k0 = ks * BK;
         if (CONV) {
             const int tap = k0 / p.C, c0 = k0 - tap * p.C;          // wave-uniform
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             *reinterpret_cast<bf16x4*>(plane0 + plane_bytes + off) = lo;
         }
     };
-    auto store_stage = [&](int buf, const f32x4 (&areg)[A_ITEMS], const f32x4 (&breg)[B_ITEMS]) {
+    auto store_stage = [&](int buf) {
         if constexpr (MATH == 0) {
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i) {
@@ -180,7 +176,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     const int nk = p.K / BK;
     const int frow = lane & 31, fhalf = lane >> 5;
 
-    auto compute = [&](int buf) {
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_stage(ks + 1);
         if constexpr (MATH == 0) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
@@ -241,38 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                     }
             }
         }
-    };
-
-    if constexpr (MATH == 0) {
-        load_stage(0, aregs[0], bregs[0]);
-        store_stage(0, aregs[0], bregs[0]);
+        if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
-        for (int ks = 0; ks < nk; ++ks) {
-            const int buf = ks & 1;
-            if (ks + 1 < nk) load_stage(ks + 1, aregs[0], bregs[0]);
-            compute(buf);
-            if (ks + 1 < nk) store_stage(buf ^ 1, aregs[0], bregs[0]);
-            __syncthreads();
-        }
-    } else {
-        // LDS holds stages ks (being read) and ks+1; register set (ks & 1) receives stage
-        // ks+2 while set ((ks+1) & 1) -- loaded one iteration earlier -- is parked in LDS.
-        load_stage(0, aregs[0], bregs[0]);
-        store_stage(0, aregs[0], bregs[0]);
-        if (nk > 1) load_stage(1, aregs[NSETS - 1], bregs[NSETS - 1]);
-        __syncthreads();
-        for (int ks = 0; ks < nk; ks += 2) {
-            if (ks + 2 < nk) load_stage(ks + 2, aregs[0], bregs[0]);
-            compute(0);
-            if (ks + 1 < nk) store_stage(1, aregs[NSETS - 1], bregs[NSETS - 1]);
-            __syncthreads();
-            if (ks + 1 < nk) {
-                if (ks + 3 < nk) load_stage(ks + 3, aregs[NSETS - 1], bregs[NSETS - 1]);
-                compute(1);
-                if (ks + 2 < nk) store_stage(0, aregs[0], bregs[0]);
-                __syncthreads();
-            }
-        }
     }
 
     // ---- epilogue --------------------------------------------------------------

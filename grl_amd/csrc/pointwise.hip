@@ -5,6 +5,7 @@
 // addresses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/grl_hip.h"
 #include "common.h"
 
@@ -93,6 +94,107 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(
                 v[e] = (t > 0.f || !relu) ? t : 0.f;
             }
             *reinterpret_cast<f32x4*>(yo + o) = v;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Stem as an implicit GEMM on the fp32 MFMA: one workgroup = 8 x 16 output pixels (M = 128)
+// x 64 channels, K = 3*7*7 = 147 padded to 160.  The input patch (3 x 21 x 37) and the
+// whole weight matrix live in LDS; the A operand A[m][k] = patch[c][2py+ky][2px+kx] is
+// read with ds_read_b32 through a k -> patch-offset table, the B operand with
+// ds_read_b128 (rows padded to 164 floats: conflict-free).  Same k-permutation as the
+// GEMM kernel: lane half h supplies k = 8q + 4h + s at step s of chunk q.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SM_TH = 8, SM_TW = 16;                 // output tile
+constexpr int SM_PH = 2 * SM_TH + 5, SM_PW = 2 * SM_TW + 5, SM_PWP = SM_PW + 1;   // 21 x 37 (+1)
+constexpr int SM_K = 160, SM_WLD = 164;
+constexpr int SM_PATCH = 3 * SM_PH * SM_PWP;         // floats; cells SM_PATCH..+3 are zeros
+constexpr int SM_KOFF = (SM_PATCH + 4 + 3) / 4 * 4;  // offset of the k -> patch-offset table
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ws = sm;                                   // [64][164]
+    float* patch = Ws + 64 * SM_WLD;                  // [3][21][38] + zero cell (+pad)
+    int* koff = reinterpret_cast<int*>(patch + SM_KOFF);         // [160], 16-byte aligned
+    float* Cs = sm;                                   // epilogue staging [128][64] (reuses Ws/patch)
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int img = blockIdx.z, oy0 = blockIdx.y * SM_TH, ox0 = blockIdx.x * SM_TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 64 * SM_K; i += 256) {
+        const int n = i / SM_K, k = i - n * SM_K;
+        Ws[n * SM_WLD + k] = k < 147 ? w[n * 147 + k] : 0.f;
+    }
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    for (int i = tid; i < 3 * SM_PH * SM_PW; i += 256) {
+        const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xi[((int64_t)c * H + iy) * W + ix];
+        patch[(c * SM_PH + r) * SM_PWP + q] = v;
+    }
+    if (tid < 8) patch[SM_PATCH + (tid & 3)] = 0.f;
+    if (tid < SM_K) {
+        const int k = tid;
+        koff[k] = k < 147 ? ((k / 49) * SM_PH + (k / 7) % 7) * SM_PWP + k % 7 : SM_PATCH;
+    }
+    __syncthreads();
+    // wave tile: 64 pixels (2 MFMA row tiles) x 32 channels
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + frow;
+        abase[i] = (2 * (m / SM_TW)) * SM_PWP + 2 * (m % SM_TW);
+    }
+    const float* brow = Ws + (wn * 32 + frow) * SM_WLD;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < SM_K / 8; ++q) {
+        const int kb = 8 * q + 4 * fhalf;
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + kb);
+        const int4 ko = *reinterpret_cast<const int4*>(koff + kb);
+        const int kov[4] = {ko.x, ko.y, ko.z, ko.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // padded k (>= 147) points at the zero cell for every pixel
+            const float a0 = patch[kov[s] == SM_PATCH ? SM_PATCH : abase[0] + kov[s]];
+            const float a1 = patch[kov[s] == SM_PATCH ? SM_PATCH : abase[1] + kov[s]];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[s], acc[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // Ws / patch are dead: reuse as C staging
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * 64 + wn * 32 + col_l] = acc[i][r];
+    __syncthreads();
+    // 128 pixels x 64 channels = 2048 float4: 8 per thread, 16 lanes per pixel row
+    const int c4 = (tid & 15) * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4), sh = *reinterpret_cast<const f32x4*>(shift + c4);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int m = it * 16 + (tid >> 4);
+        const int oy = oy0 + m / SM_TW, ox = ox0 + m % SM_TW;
+        if (oy < Ho && ox < Wo) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + m * 64 + c4) * sc + sh;
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(y + (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c4) = v;
         }
     }
 }
@@ -460,8 +562,15 @@ extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* sca
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
-    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grl_ceil_div(Wo, ST), grl_ceil_div(Ho, ST), n), dim3(256), 0,
-                       (hipStream_t)stream, x, w, scale, shift, y, H, W, relu);
+    static const int use_valu = getenv("GRL_STEM_VALU") ? 1 : 0;     // kernel tuning only
+    if (use_valu) {
+        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grl_ceil_div(Wo, ST), grl_ceil_div(Ho, ST), n), dim3(256), 0,
+                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu);
+    } else {
+        const size_t lds = (size_t)(64 * SM_WLD + SM_KOFF + SM_K) * sizeof(float);
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(grl_ceil_div(Wo, SM_TW), grl_ceil_div(Ho, SM_TH), n), dim3(256), lds,
+                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu);
+    }
     return grl_check_launch("grl_stem_conv7x7");
 }
 

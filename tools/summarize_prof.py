@@ -21,7 +21,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for tag in ('gemm_f32_kernel', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
+    for tag in ('gemm_f32_kernel', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
                 'temporal_mean', 'add_strided', 'channel_hidden', 'channel_atte_out', 'affine_l2norm',
                 'siamese_attn', 'mean_T', 'row_sqnorm', 'pair_verify', 'bn_fold', 'pack_conv_weight'):
         if tag in name:
@@ -59,11 +59,12 @@ def main():
         k = short(row['Kernel_Name'])
         dur[k] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
         calls[k] += 1
-    steps = calls['stem_conv7x7']
+    stem = 'stem_mfma' if calls.get('stem_mfma') else 'stem_conv7x7'
+    steps = calls[stem]
     fetch, fcalls = read_pmc(d_fetch)
     write, wcalls = read_pmc(d_write)
     mfma, mcalls = read_pmc(d_mfma)
-    fsteps, wsteps, msteps = fcalls['stem_conv7x7'], wcalls['stem_conv7x7'], mcalls['stem_conv7x7']
+    fsteps, wsteps, msteps = fcalls[stem], wcalls[stem], mcalls[stem]
     lines = ['# %s: rocprofv3 summary (bench.py, B x T = 32 x 4, fp32), per step' % tag, '',
              '| kernel | launches/step | ms/step | avg us/launch | HBM read MB/step | HBM write MB/step | MFMA busy % |',
              '|---|---|---|---|---|---|---|']

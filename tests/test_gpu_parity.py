@@ -321,3 +321,35 @@ def test_attevaluator_end_to_end_both_modes(gpu_models, capsys):
     df, dp, _ = evd.extract_feature([(dense, torch.tensor([7]), torch.tensor([1]))])
     ref = O.extract_features(sd, ssd, dense[0]).mean(dim=0, keepdim=True)
     assert df.shape == (1, 6144) and _rel(df.cpu().numpy(), ref.numpy()) < TOL and int(dp[0]) == 7
+
+
+@pytest.mark.parametrize('b,t', [(1, 1), (1, 16), (5, 3)])
+def test_eval_edge_shapes_match_oracle(gpu_models, b, t):
+    """Smallest clip (one frame), the longest the attention kernel takes (T = 16) and a
+    ragged batch/length: features against the oracle."""
+    from grl_amd import engine
+    from oracle import grl_oracle as O
+    cnn, siam, _ = gpu_models
+    sd = {k: v.detach().cpu() for k, v in cnn.state_dict().items()}
+    ssd = {k: v.detach().cpu() for k, v in siam.state_dict().items()}
+    clips = synth_clips(b, t, seed=40 + b + t)
+    feat = engine.extract_features(cnn, siam, clips.cuda())
+    assert _rel(feat.cpu().numpy(), O.extract_features(sd, ssd, clips).numpy()) < TOL
+
+
+def test_eval_rejects_bad_inputs(gpu_models):
+    from grl_amd import engine
+    from grl_amd._lib import GrlHipError
+    cnn, siam, _ = gpu_models
+    with pytest.raises(ValueError):
+        cnn(torch.zeros(2, 4, 3, 128, 64, device='cuda'))            # the 16x8 map is hard-wired upstream too
+    with pytest.raises(ValueError):
+        cnn(torch.zeros(8, 3, 256, 128, device='cuda'))              # missing T axis
+    with pytest.raises(GrlHipError):
+        cnn(torch.zeros(1, 2, 3, 256, 128, device='cuda', dtype=torch.float16))
+    with pytest.raises(GrlHipError):
+        siam.self_attention(torch.zeros(1, 17, 2048, device='cuda'))  # T > 16
+    with pytest.raises(RuntimeError):
+        siam(torch.zeros(3, 4, 2048, device='cuda'))                 # odd batch (Siamese.py:112-113)
+    d = engine.cosin_dist(torch.ones(1, 64, device='cuda'), torch.ones(3, 64, device='cuda'))
+    assert d.shape == (1, 3) and float(d[0, 0]) == -64.0              # single query row

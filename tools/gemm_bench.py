@@ -23,10 +23,7 @@ SHAPES = [  # (M, N, K, conv, calls per step, epilogue: res?)
 
 
 def bench(tile, iters=5):
-    math = 0
-    if tile in ('bf16x3', 'bf16', 'f32'):
-        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[tile]
-        tile = 'auto'
+XX
     if tile == 'auto':
         os.environ.pop('GRL_GEMM_TILE', None)
     else:

@@ -23,7 +23,13 @@ SHAPES = [  # (M, N, K, conv, calls per step, epilogue: res?)
 
 
 def bench(tile, iters=5):
-XX
+    math = 0
+    if ':' in tile:                       # e.g. bf16x3:256x128
+        m, tile = tile.split(':')
+        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[m]
+    elif tile in ('bf16x3', 'bf16', 'f32'):
+        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[tile]
+        tile = 'auto'
     if tile == 'auto':
         os.environ.pop('GRL_GEMM_TILE', None)
     else:

@@ -379,7 +379,6 @@ TileChoice choose_tile(const GrlGemm& d) {
         if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) &&
             !(bm == 64 && bn == 128))
             return {bm, bn};
-        if (bm == 256 && bn == 128 && d.math != GRL_MATH_F32) return {256, 128};
     }
     // Measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 128x128
     // tile wins when the K loop is long (>= 1024: 131-135 TFLOP/s); short-K layers are
@@ -463,10 +462,6 @@ extern "C" int grl_conv_gemm_f32(const GrlGemm* desc, void* stream) {
     if (int e = validate(d)) return e;
     hipStream_t s = (hipStream_t)stream;
     const TileChoice t = choose_tile(d);
-    if (t.bm == 256 && t.bn == 128) {       // bf16 datapaths only: halves the L2 traffic per FLOP
-        if (d.math == GRL_MATH_BF16X3) return launch_math<256, 128, 3>(d, s);
-        return launch_math<256, 128, 1>(d, s);
-    }
     if (t.bm == 128 && t.bn == 128) return launch<128, 128>(d, s);
     if (t.bm == 128 && t.bn == 64) return launch<128, 64>(d, s);
     return launch<64, 64>(d, s);

@@ -43,9 +43,9 @@ def import_reference():
     full = r1.ResNet(r1.Bottleneck, [3, 4, 6, 3]).state_dict()
     r1.model_zoo.load_url = lambda *a, **k: full
     from reid import models as ref_models
-    from reid.evaluator import attevaluator, eva_functions
+    from reid.evaluator import attevaluator, eva_functions, rerank
     from reid.loss import pairloss, triplet
-    return ref_models, attevaluator, eva_functions, pairloss, triplet
+    return ref_models, attevaluator, eva_functions, pairloss, triplet, rerank
 
 
 def sample(t, n=256):
@@ -112,7 +112,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, REPO)
     from grl_amd.synthetic import synth_state_dict, synth_clips, synth_eval_features
-    ref_models, attev, evaf, pairloss, triplet = import_reference()
+    ref_models, attev, evaf, pairloss, triplet, rerank = import_reference()
 
     B, T = 2, 4
     cnn = ref_models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625)
@@ -215,6 +215,13 @@ def main():
                         idx_dense=np.argsort(dist_d, axis=1).astype(np.int32),
                         idx_dense_euclid=np.argsort(euc_d, axis=1).astype(np.int32))
     print('evaluator golden: mAP %.4f rank1 %.4f' % (mAP, cmc[0]))
+    # re-ranking (rerank.py:37-104) exactly as ATTEvaluator.evaluate feeds it (attevaluator.py:150-155)
+    rr = rerank.re_ranking(dist, attev.pairwise_distance_tensor(qf, qf).numpy(),
+                           attev.pairwise_distance_tensor(gf, gf).numpy())
+    cmc_r, mAP_r = evaf.evaluate(rr, qp, gp, qc, gc)
+    np.savez_compressed(os.path.join(HERE, 'rerank_q40_g400.npz'), final=rr.astype(np.float32),
+                        cmc=cmc_r[:20], mAP=np.array(mAP_r))
+    print('rerank golden: mAP %.4f rank1 %.4f' % (mAP_r, cmc_r[0]))
 
     # ---------------- (E) losses that still run on this torch -----------
     g = np.random.Generator(np.random.PCG64(13))

@@ -313,8 +313,8 @@ def test_attevaluator_end_to_end_both_modes(gpu_models, capsys):
     r1 = ev.evaluate(None, None, [q], [g], None, False, False)
     out = capsys.readouterr().out
     assert 'Mean AP:' in out and 'Rank-1' in out and 0.0 <= r1 <= 1.0
-    with pytest.raises(NotImplementedError):
-        ev.evaluate(None, None, [q], [g], None, False, True)          # re-ranking: not provided
+    r1r = ev.evaluate(None, None, [q], [g], None, False, True)        # with k-reciprocal re-ranking
+    assert 0.0 <= r1r <= 1.0
     # dense mode: one tracklet of 11 clips -> chunks 8 + 3, features averaged over clips
     dense = synth_clips(11, T, seed=31).unsqueeze(0)
     evd = ATTEvaluator(cnn, siam, only_eval=True)

@@ -215,12 +215,17 @@ def main():
                         idx_dense=np.argsort(dist_d, axis=1).astype(np.int32),
                         idx_dense_euclid=np.argsort(euc_d, axis=1).astype(np.int32))
     print('evaluator golden: mAP %.4f rank1 %.4f' % (mAP, cmc[0]))
-    # re-ranking (rerank.py:37-104) exactly as ATTEvaluator.evaluate feeds it (attevaluator.py:150-155)
-    rr = rerank.re_ranking(dist, attev.pairwise_distance_tensor(qf, qf).numpy(),
-                           attev.pairwise_distance_tensor(gf, gf).numpy())
-    cmc_r, mAP_r = evaf.evaluate(rr, qp, gp, qc, gc)
-    np.savez_compressed(os.path.join(HERE, 'rerank_q40_g400.npz'), final=rr.astype(np.float32),
-                        cmc=cmc_r[:20], mAP=np.array(mAP_r))
+    # re-ranking (rerank.py:37-104) exactly as ATTEvaluator.evaluate feeds it (attevaluator.py:150-155),
+    # on a smaller case so that the three INPUT matrices can be stored with the output: the
+    # neighbour sets are discrete, so the pin must be input-exact.
+    qf2, gf2, qp2, qc2, gp2, gc2 = synth_eval_features(16, 120, seed=5, n_ids=10, noise=3.0)
+    d2 = attev.cosin_dist(qf2, gf2).numpy()
+    qq2 = attev.pairwise_distance_tensor(qf2, qf2).numpy()
+    gg2 = attev.pairwise_distance_tensor(gf2, gf2).numpy()
+    rr = rerank.re_ranking(d2, qq2, gg2)
+    cmc_r, mAP_r = evaf.evaluate(rr, qp2, gp2, qc2, gc2)
+    np.savez_compressed(os.path.join(HERE, 'rerank_q16_g120.npz'), dist=d2, qq=qq2, gg=gg2,
+                        final=rr.astype(np.float32), cmc=cmc_r[:20], mAP=np.array(mAP_r))
     print('rerank golden: mAP %.4f rank1 %.4f' % (mAP_r, cmc_r[0]))
 
     # ---------------- (E) losses that still run on this torch -----------

@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             for (int i = 0; i < A_ITEMS; ++i) {
                 const int iy = ai[i].iy0 + ky, ix = ai[i].ix0 + kx;
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok)
-                    v = *reinterpret_cast<const f32x4*>(
-                        p.a + ai[i].base + ((int64_t)iy * p.W + ix) * p.C + c0 + ld_chunk * 4);
+                // branch-free: out-of-image taps load pixel (0,0) of the same image and are
+                // zeroed by a select, so the stage's loads issue back to back
+                const int64_t pix = ok ? (int64_t)iy * p.W + ix : 0;
+                f32x4 v = *reinterpret_cast<const f32x4*>(p.a + ai[i].base + pix * p.C + c0 + ld_chunk * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
                 areg[i] = v;
             }
         } else {

@@ -353,3 +353,43 @@ def test_eval_rejects_bad_inputs(gpu_models):
         siam(torch.zeros(3, 4, 2048, device='cuda'))                 # odd batch (Siamese.py:112-113)
     d = engine.cosin_dist(torch.ones(1, 64, device='cuda'), torch.ones(3, 64, device='cuda'))
     assert d.shape == (1, 3) and float(d[0, 0]) == -64.0              # single query row
+
+
+def test_baseline_config2_bf16_T8_B64(gpu_models):
+    """BASELINE configs[2]: bf16 MFMA datapath, T = 8, P x K = 16 x 4 (64 clips).  Full-size
+    run checked through size-independent properties (finite, unit-norm blocks, a clip's row is
+    bit-identical in the batch of 64 and in a batch of 2) and against the fp32 oracle on two
+    clips with the bf16 tolerance."""
+    from grl_amd import engine
+    from oracle import grl_oracle as O
+    cnn, siam, _ = gpu_models
+    clips = synth_clips(64, 8, seed=8).cuda()
+    with engine.math_mode('bf16'):
+        big = engine.extract_features(cnn, siam, clips)
+        small = engine.extract_features(cnn, siam, clips[30:32].contiguous())
+    assert big.shape == (64, 6144) and bool(torch.isfinite(big).all())
+    assert torch.equal(big[30:32], small)
+    assert float((big.view(64, 3, 2048).norm(dim=2)[:, :2] - 1).abs().max()) < 1e-5
+    sd = {k: v.detach().cpu() for k, v in cnn.state_dict().items()}
+    ssd = {k: v.detach().cpu() for k, v in siam.state_dict().items()}
+    ref = O.extract_features(sd, ssd, clips[30:32].cpu())
+    err = _rel(small.cpu().numpy(), ref.numpy())
+    print('configs[2] bf16 T=8: rel err vs fp32 oracle %.2e' % err)
+    assert err < 5e-2
+
+
+def test_baseline_config4_full_mars_rank1_map():
+    """BASELINE configs[4]: the full MARS-size query x gallery matrix on the GPU, then the
+    reference's host ranking: Rank-1 / mAP / CMC equal to those of the CPU (BLAS) distance
+    matrix of the oracle."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    from oracle import grl_oracle as O
+    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=9.0)
+    d_gpu = engine.cosin_dist(qf.cuda(), gf.cuda()).cpu().numpy()
+    d_cpu = O.cosin_dist(qf, gf).numpy()
+    assert _rel(d_gpu, d_cpu) < 2e-5
+    cmc_g, map_g = evaluate(d_gpu, qp, gp, qc, gc)
+    cmc_c, map_c = evaluate(d_cpu, qp, gp, qc, gc)
+    print('configs[4]: mAP %.4f Rank-1 %.4f' % (map_g, cmc_g[0]))
+    assert abs(map_g - map_c) < 1e-5 and np.abs(cmc_g - cmc_c).max() < 1e-3 and 0.05 < map_g < 0.999

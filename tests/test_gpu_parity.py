@@ -385,7 +385,7 @@ def test_baseline_config4_full_mars_rank1_map():
     from grl_amd import engine
     from grl_amd.reid.evaluator.eva_functions import evaluate
     from oracle import grl_oracle as O
-    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=9.0)
+    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=3.0)
     d_gpu = engine.cosin_dist(qf.cuda(), gf.cuda()).cpu().numpy()
     d_cpu = O.cosin_dist(qf, gf).numpy()
     assert _rel(d_gpu, d_cpu) < 2e-5

@@ -385,11 +385,11 @@ def test_baseline_config4_full_mars_rank1_map():
     from grl_amd import engine
     from grl_amd.reid.evaluator.eva_functions import evaluate
     from oracle import grl_oracle as O
-    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=3.0)
+    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=6.0)
     d_gpu = engine.cosin_dist(qf.cuda(), gf.cuda()).cpu().numpy()
     d_cpu = O.cosin_dist(qf, gf).numpy()
     assert _rel(d_gpu, d_cpu) < 2e-5
     cmc_g, map_g = evaluate(d_gpu, qp, gp, qc, gc)
     cmc_c, map_c = evaluate(d_cpu, qp, gp, qc, gc)
     print('configs[4]: mAP %.4f Rank-1 %.4f' % (map_g, cmc_g[0]))
-    assert abs(map_g - map_c) < 1e-5 and np.abs(cmc_g - cmc_c).max() < 1e-3 and 0.05 < map_g < 0.999
+    assert abs(map_g - map_c) < 1e-5 and np.abs(cmc_g - cmc_c).max() < 1e-3 and 0.02 < map_g < 0.9999

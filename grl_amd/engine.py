@@ -448,6 +448,45 @@ def extract_features(cnn, siam, clips):
         return feat
 
 
+class GraphedExtractor(object):
+    """`extract_features` captured once per input shape into a HIP graph (through
+    torch.cuda.CUDAGraph: our launches go to torch's capturing stream) and replayed.
+    One step is ~150 short launches; at small batches (the dense test_all.py mode feeds
+    chunks of <= 8 clips, attevaluator.py:72-76) the host launch cost, not the GPU, bounds
+    the eager path.  Output is bit-identical to the eager call (same kernels, same order).
+    The packed-weight plans are built eagerly before capture and re-checked on every call:
+    a parameter change drops the captured graphs."""
+
+    def __init__(self, cnn, siam):
+        self.cnn = getattr(cnn, 'module', cnn)
+        self.siam = siam
+        self._graphs = {}
+        self._key = None
+
+    def __call__(self, clips):
+        require_device(clips, 'clips')
+        key = (_state_key(self.cnn), _state_key(self.siam))
+        if key != self._key:
+            self._graphs.clear()
+            self._key = key
+        shape = tuple(clips.shape)
+        g = self._graphs.get(shape)
+        if g is None:
+            static_in = clips.clone()
+            for _ in range(2):                              # builds plans, warms the allocator
+                extract_features(self.cnn, self.siam, static_in)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = extract_features(self.cnn, self.siam, static_in)
+            g = (graph, static_in, static_out)
+            self._graphs[shape] = g
+        graph, static_in, static_out = g
+        static_in.copy_(clips)
+        graph.replay()
+        return static_out.clone()
+
+
 # ----------------------------------------------------------------------------
 # evaluator distance matrices
 # ----------------------------------------------------------------------------

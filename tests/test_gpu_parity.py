@@ -393,3 +393,19 @@ def test_baseline_config4_full_mars_rank1_map():
     cmc_c, map_c = evaluate(d_cpu, qp, gp, qc, gc)
     print('configs[4]: mAP %.4f Rank-1 %.4f' % (map_g, cmc_g[0]))
     assert abs(map_g - map_c) < 1e-5 and np.abs(cmc_g - cmc_c).max() < 1e-3 and 0.02 < map_g < 0.9999
+
+
+def test_hip_graph_replay_is_bit_identical(gpu_models):
+    """The captured-graph extractor replays the same launches: bit-identical features,
+    new inputs are picked up, a second shape gets its own graph."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    gx = engine.GraphedExtractor(cnn, siam)
+    a, b = synth_clips(4, 2, seed=50).cuda(), synth_clips(4, 2, seed=51).cuda()
+    fa, fb = gx(a), gx(b)
+    assert torch.equal(fa, engine.extract_features(cnn, siam, a))
+    assert torch.equal(fb, engine.extract_features(cnn, siam, b))
+    assert not torch.equal(fa, fb)
+    c = synth_clips(2, 3, seed=52).cuda()
+    assert torch.equal(gx(c), engine.extract_features(cnn, siam, c))
+    assert len(gx._graphs) == 2

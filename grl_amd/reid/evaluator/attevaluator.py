@@ -40,7 +40,10 @@ class ATTEvaluator(object):
         self.cnn_model = cnn_model
         self.siamese_model = Siamese_model
         self.only_eval = only_eval
-        self.chunk = 8            # clips per forward in dense mode (attevaluator.py:72-76)
+        # clips per forward in dense mode.  The reference uses 8 (attevaluator.py:72-76) to fit
+        # its GPU; clip features are independent (eval BN is folded), so any chunking gives the
+        # same rows -- 32 keeps the MI355X busy (1900 vs 1400 clip-features/s at 8).
+        self.chunk = 32
 
     def _device(self):
         return next(self.cnn_model.parameters()).device

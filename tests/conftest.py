@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def ensure_built():
+    """Fresh checkout: compile libgrl_hip.so (hipcc cross-compiles without a GPU) and the
+    C oracle before the first test needs them.  Building the checker is not using it."""
+    from grl_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH) or not os.path.isfile(os.path.join(ROOT, 'oracle', 'libgrl_oracle.so')):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

@@ -54,7 +54,6 @@ def math_mode(name):
         _math[0] = old
 
 
-BN_EPS = 1e-5
 PIX = 128            # 16 x 8 feature map of layer4 (basebranch.py:59 hard-codes it)
 
 
@@ -129,7 +128,6 @@ class EvalPlan(object):
     def __init__(self, module):
         self.key = _state_key(module)
         self.dev = next(module.parameters()).device
-        self._vecs = []
 
     # -- helpers ---------------------------------------------------------------
     def fold(self, bn=None, bias=None, n=None):
@@ -145,7 +143,7 @@ class EvalPlan(object):
                   ptr(shift), n)
         return scale, shift
 
-    def conv(self, conv, bn=None, bias_only=False):
+    def conv(self, conv, bn=None):
         c = _Conv()
         w = conv.weight.detach()
         c.N, c.cin = w.shape[0], w.shape[1]

@@ -409,3 +409,20 @@ def test_hip_graph_replay_is_bit_identical(gpu_models):
     c = synth_clips(2, 3, seed=52).cuda()
     assert torch.equal(gx(c), engine.extract_features(cnn, siam, c))
     assert len(gx._graphs) == 2
+
+
+def test_reference_script_flow_through_dropin(tmp_path):
+    """examples/train_synthetic.py follows mars_train.py's call sequence through the drop-in
+    `reid`/`utils` packages (DataParallel wrap, module.backbone param groups, SEQTrainer,
+    ATTEvaluator, checkpoint save + reload with the 'module.' key prefix)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, 'dropin'))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_synthetic.py'), '--epochs', '1',
+                          '--iters', '2', '-b', '4', '--seq_len', '2', '--logs-dir', str(tmp_path)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'Mean AP:' in out.stdout and 'best rank-1 accuracy is' in out.stdout
+    ck = torch.load(os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'), map_location='cpu')
+    assert set(ck) == {'state_dict', 'epoch', 'best_top1'} and len(ck['state_dict']) == 401
+    assert all(k.startswith('module.') for k in ck['state_dict'])

@@ -426,3 +426,63 @@ def test_reference_script_flow_through_dropin(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'), map_location='cpu')
     assert set(ck) == {'state_dict', 'epoch', 'best_top1'} and len(ck['state_dict']) == 401
     assert all(k.startswith('module.') for k in ck['state_dict'])
+
+
+def test_trainer_loss_composition_matches_cpu_restatement():
+    """SEQTrainer._forward on HIP vs the same 5-term loss assembled on CPU from the oracle's
+    train-mode forward (trainer.py:107-170: frame id + clip id (same LUT) + 20 x pair
+    verification + batch-hard triplet on the correlated branch, id loss on the uncorrelated
+    branch), B x T = 4 x 2, non-zero LUTs."""
+    import torch.nn.functional as F
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from oracle import grl_oracle as O
+    cnn, siam, siamv = _fresh_models()
+    sd = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    ssd = {k: v.detach().cpu().clone() for k, v in siam.state_dict().items()}
+    svd = {k: v.detach().cpu().clone() for k, v in siamv.state_dict().items()}
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    lut_c = F.normalize(torch.randn(625, 2048, generator=g), dim=1)
+    lut_u = F.normalize(torch.randn(625, 2048, generator=g), dim=1)
+    crit_c, crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    crit_c.lut.copy_(lut_c); crit_u.lut.copy_(lut_u)
+    trainer = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+    cnn.train(); siam.train(); siamv.train()
+    clips = synth_clips(4, 2, seed=2)
+    pids = torch.tensor([17, 17, 401, 401])
+    loss, p_u, p_v, p_f = trainer._forward([clips.to(dev)], pids.to(dev), 0, 0)
+    # CPU restatement
+    xu, xc = O.grl_forward(sd, clips, train=True)
+    l_frame, _ = O.oim_loss(xc.reshape(8, -1), pids.repeat_interleave(2), lut_c.clone(), 30.0, 0.5)
+    cls, sout = O.siamese_forward(ssd, xc, train=True)
+    target = torch.cat((pids[0::2], pids[1::2]))
+    l_vid, _ = O.oim_loss(sout, target, lut_c.clone(), 30.0, 0.5)
+    l_tri = O.triplet_soft_batch_hard(sout, target).mean()
+    prob = F.softmax(cls.view(-1, 2), dim=-1).view(2, 2, 2)[:, :, 1]
+    l_ver, _ = O.pair_loss(prob, pids[0::2], pids[1::2])
+    _, vout = O.siamese_video_forward(svd, xu, train=True)
+    l_unc, _ = O.oim_loss(vout, target, lut_u.clone(), 30.0, 0.5)
+    ref = l_unc + l_frame + l_vid + 20 * l_ver + l_tri
+    print('trainer loss hip %.6f cpu %.6f' % (loss.item(), ref.item()))
+    assert abs(loss.item() - ref.item()) < 2e-3 * max(1.0, abs(ref.item()))
+
+
+def test_backward_is_linear_in_the_upstream_gradient():
+    """Size-independent property of the HIP backward at a BASELINE-like size (B x T = 8 x 4):
+    every op of the backward is linear in the incoming gradient and scaling by 2 is exact in
+    fp32, so backward(2g) == 2 * backward(g) bit for bit."""
+    cnn, _, _ = _fresh_models()
+    cnn.train()
+    clips = synth_clips(8, 4, seed=6).cuda()
+    rg = torch.Generator().manual_seed(1)
+    r1, r2 = torch.randn(8, 2048, generator=rg).cuda(), torch.randn(8, 4, 2048, generator=rg).cuda()
+    grads = []
+    for scale in (1.0, 2.0):
+        cnn.zero_grad(set_to_none=True)
+        xu, xc = cnn(clips)
+        ((xu * r1).sum() * scale + (xc * r2).sum() * scale).backward()
+        grads.append({k: p.grad.clone() for k, p in cnn.named_parameters()})
+    for k in grads[0]:
+        assert torch.equal(grads[1][k], grads[0][k] * 2), k
+        assert bool(torch.isfinite(grads[0][k]).all()), k

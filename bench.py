@@ -166,6 +166,35 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
         dist.destroy_process_group()
 
 
+def distmat_bench(args, dev, rank):
+    """Third series: the evaluator's query x gallery matrix at MARS size
+    (BASELINE configs[4]): -Q.G^T, Q [1980,6144], G [11310,6144], exact fp32 MFMA."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_eval_features
+    qf, gf, *_ = synth_eval_features(1980, 11310, seed=1)
+    qd, gd = qf.to(dev), gf.to(dev)
+    for _ in range(args.warmup):
+        d = engine.cosin_dist(qd, gd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d = engine.cosin_dist(qd, gd)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    e0 = time.perf_counter()
+    e = engine.pairwise_distance_tensor(qd, gd)
+    torch.cuda.synchronize()
+    flops = 2.0 * 1980 * 11310 * 6144
+    if rank == 0:
+        print(json.dumps({"metric": "distance-matrix ms (1980x11310x6144)", "value": round(dt * 1e3, 3), "unit": "ms",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+                          "higher_is_better": False, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "cosin_dist at MARS size, BASELINE configs[4]"},
+                          "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2),
+                                       "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -176,7 +205,7 @@ def main():
                     help="multiplier datapath of the conv GEMMs for the headline `value` "
                          "(default: exact fp32 MFMA = BASELINE configs[1])")
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 measurements')
-    ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
+    ap.add_argument('--mode', default='eval', choices=['eval', 'train', 'distmat'],
                     help="eval (default): the headline clip-features/sec; train: secondary series, one "
                          "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
     args = ap.parse_args()
@@ -208,6 +237,8 @@ def main():
 
     if args.mode == 'train':
         return train_bench(args, cnn, siam, dev, dist, rank, world, barrier)
+    if args.mode == 'distmat':
+        return distmat_bench(args, dev, rank)
 
     for _ in range(args.warmup):
         feat = engine.extract_features(cnn, siam, clips)

@@ -83,6 +83,7 @@ _SIGNATURES = {
     'grl_pair_sqdiff': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_pair_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
+    'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
 }
 

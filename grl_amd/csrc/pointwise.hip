@@ -533,6 +533,39 @@ __global__ __launch_bounds__(256) void pair_verify_kernel(
     }
 }
 
+// Row-wise argsort of the distance matrix (eva_functions.py:139 `np.argsort(distmat, axis=1)`)
+// as one LDS bitonic network per row: (key, index) pairs, ascending, ties broken by the
+// smaller index (np.argsort(kind='stable') order; numpy's default introsort leaves ties
+// unspecified).  One workgroup of 1024 lanes per row, n <= 16384 (128 KiB of LDS).
+constexpr int SORT_MAX = 16384;
+__global__ __launch_bounds__(1024) void row_argsort_kernel(const float* __restrict__ d, int64_t ld,
+                                                           int n, int P, int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm_sort[];
+    float* key = sm_sort;                                   // [P]
+    int* idx = reinterpret_cast<int*>(sm_sort + P);         // [P]
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* dr = d + (int64_t)row * ld;
+    for (int i = tid; i < P; i += 1024) {
+        key[i] = i < n ? dr[i] : INFINITY;
+        idx[i] = i < n ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int i = 2 * j * (t / j) + (t % j), l = i + j;
+                const bool asc = (i & k) == 0;
+                const float ki = key[i], kl = key[l];
+                const int ii = idx[i], il = idx[l];
+                const bool gt = ki > kl || (ki == kl && ii > il);          // element i after element l?
+                if (gt == asc) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 1024) out[(int64_t)row * n + i] = idx[i];
+}
+
 inline int grid_for(int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -674,4 +707,16 @@ extern "C" int grl_pair_verify(const float* p, const float* g, const float* scal
     hipLaunchKernelGGL(pair_verify_kernel, dim3(grl_ceil_div((int64_t)np * ng, 4)), dim3(256), 0, (hipStream_t)stream,
                        p, g, scale, shift, w, bias, out, np, ng, K, ncls);
     return grl_check_launch("grl_pair_verify");
+}
+
+extern "C" int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* stream) {
+    GRL_REQUIRE(d && idx && rows > 0 && n > 0 && ld >= n, "row_argsort: bad args");
+    GRL_REQUIRE(n <= SORT_MAX, "row_argsort: at most 16384 columns (one LDS bitonic network per row)");
+    int P = 2;
+    while (P < n) P <<= 1;
+    const size_t lds = (size_t)P * 8;
+    if (lds > 65536)
+        (void)hipFuncSetAttribute((const void*)row_argsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(row_argsort_kernel, dim3(rows), dim3(1024), lds, (hipStream_t)stream, d, ld, n, P, idx);
+    return grl_check_launch("grl_row_argsort");
 }

@@ -509,3 +509,15 @@ def pairwise_distance_tensor(x, y):
     _call('grl_row_sqnorm', ptr(y), ptr(cn), n, k, k)
     out = _new((m, n), x)
     return gemm(x, y, out, m, n, k, epilogue=EPI_EUCLID, rnorm=rn, cnorm=cn, math=MATH_F32)
+
+
+def rank_rows(distmat):
+    """Row-wise ascending argsort on the GPU (int32 [rows][n]); ties to the smaller index.
+    Replaces the host `np.argsort(distmat, axis=1)` of eva_functions.py:139 for matrices of up
+    to 16384 columns (MARS: 11310)."""
+    require_device(distmat, 'distmat')
+    distmat = distmat.contiguous()
+    rows, n = distmat.shape
+    idx = torch.empty((rows, n), dtype=torch.int32, device=distmat.device)
+    _call('grl_row_argsort', ptr(distmat), n, rows, n, ptr(idx))
+    return idx

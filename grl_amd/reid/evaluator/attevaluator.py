@@ -15,11 +15,11 @@ __all__ = ['ATTEvaluator', 'evaluate_seq', 'cosin_dist', 'pairwise_distance_tens
 
 
 def evaluate_seq(distmat, query_pids, query_camids, gallery_pids, gallery_camids, path,
-                 cmc_topk=(1, 5, 10, 20)):
+                 cmc_topk=(1, 5, 10, 20), indices=None):
     """Prints mAP / Rank-k in the reference's format and returns Rank-1
     (attevaluator.py:15-30)."""
     cmc_scores, mAP = evaluate(distmat, np.array(query_pids), np.array(gallery_pids),
-                               np.array(query_camids), np.array(gallery_camids))
+                               np.array(query_camids), np.array(gallery_camids), indices=indices)
     print('Mean AP: {:4.1%}'.format(mAP))
     for r in cmc_topk:
         print("Rank-{:<3}: {:.1%}".format(r, cmc_scores[r - 1]))
@@ -82,10 +82,15 @@ class ATTEvaluator(object):
         g_camids = np.append(q_camids, g_camids)
         print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
         print("Computing distance matrix")
-        distmat = cosin_dist(qf, gf).cpu().numpy()
+        dist_dev = cosin_dist(qf, gf)
+        # ranking on the device when the gallery fits one LDS sort network (MARS: 11310 columns)
+        indices = None
+        if not rerank and dist_dev.shape[1] <= 16384:
+            indices = engine.rank_rows(dist_dev).cpu().numpy()
+        distmat = dist_dev.cpu().numpy()
         if rerank:
             print('Applying person re-ranking ...')
             distmat_qq = pairwise_distance_tensor(qf, qf).cpu().numpy()
             distmat_gg = pairwise_distance_tensor(gf, gf).cpu().numpy()
             distmat = re_ranking(distmat, distmat_qq, distmat_gg)
-        return evaluate_seq(distmat, q_pids, q_camids, g_pids, g_camids, path)
+        return evaluate_seq(distmat, q_pids, q_camids, g_pids, g_camids, path, indices=indices)

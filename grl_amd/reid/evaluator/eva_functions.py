@@ -20,11 +20,12 @@ def accuracy(output, target, topk=(1,)):
     return [correct[:k].reshape(-1).float().sum(0).mul_(1. / n) for k in topk]
 
 
-def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100):
+def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100, indices=None):
     """CMC curve and mAP (eva_functions.py:134-184).  Rows are ranked with
     ``np.argsort`` exactly as the reference does; gallery entries that share
     both pid and camid with the query are dropped; queries whose identity never
-    appears are skipped.  Returns (cmc[max_rank] float32, mAP)."""
+    appears are skipped.  Returns (cmc[max_rank] float32, mAP).  ``indices`` may carry a
+    precomputed row-wise argsort (grl_amd.engine.rank_rows computes it on the GPU)."""
     distmat = np.asarray(distmat)
     q_pids, g_pids = np.asarray(q_pids), np.asarray(g_pids)
     q_camids, g_camids = np.asarray(q_camids), np.asarray(g_camids)
@@ -32,7 +33,8 @@ def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100):
     if num_g < max_rank:
         max_rank = num_g
         print("Note: number of gallery samples is quite small, got {}".format(num_g))
-    indices = np.argsort(distmat, axis=1)
+    if indices is None:
+        indices = np.argsort(distmat, axis=1)
     ranked_pid = g_pids[indices]
     matches = (ranked_pid == q_pids[:, None])
     drop = matches & (g_camids[indices] == q_camids[:, None])

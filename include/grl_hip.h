@@ -153,6 +153,11 @@ int grl_pair_verify(const float* p, const float* g, const float* scale, const fl
                     const float* w, const float* bias, float* out, int np, int ng, int K,
                     int ncls, void* stream);
 
+/* Row-wise ascending argsort of a distance matrix d [rows][ld] (first n columns), int32
+ * indices out [rows][n]; ties go to the smaller index.  Replaces np.argsort(distmat, axis=1)
+ * in reid/evaluator/eva_functions.py:139.  n <= 16384. */
+int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* stream);
+
 /* |x_row|^2 for the Euclidean epilogue (attevaluator.py:37-38). */
 int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* stream);
 

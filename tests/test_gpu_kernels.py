@@ -233,3 +233,18 @@ def test_gemm_bf16_math_modes(dev, mode, tol):
         else:
             denom = np.abs(ref).max() * 10
         assert np.abs(y.cpu().double().numpy() - ref).max() / denom < tol, (mode, M, N, K)
+
+
+def test_row_argsort_matches_numpy(dev):
+    """GPU row argsort == np.argsort(kind='stable'), including exact ties, ragged widths and
+    the MARS gallery width."""
+    from grl_amd import engine
+    rng = np.random.default_rng(4)
+    for rows, n in ((7, 1), (5, 37), (16, 1024), (9, 4097), (12, 11310)):
+        d = rng.standard_normal((rows, n)).astype(np.float32)
+        d[:, ::5] = np.round(d[:, ::5], 1)                  # plenty of exact ties
+        got = engine.rank_rows(torch.from_numpy(d).to(dev)).cpu().numpy()
+        assert np.array_equal(got, np.argsort(d, axis=1, kind='stable')), (rows, n)
+    from grl_amd._lib import GrlHipError
+    with pytest.raises(GrlHipError):
+        engine.rank_rows(torch.zeros(2, 16385, device=dev))

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void siamese_attn_bwd_kernel(
     __shared__ float inv_norm[2 * ATT_TMAX];
     __shared__ float S[ATT_TMAX][ATT_TMAX];     // P after softmax
     __shared__ float dS[ATT_TMAX][ATT_TMAX];
-    __shared__ float colw[ATT_TMAX], dw[ATT_TMAX], qdot[2 * ATT_TMAX];
+    __shared__ float colw[ATT_TMAX], dw[ATT_TMAX];
     __shared__ float red[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* base = qk + (int64_t)b * T * 2 * D;

@@ -219,10 +219,16 @@ _plans = weakref.WeakKeyDictionary()
 
 
 def _plan(module, cls):
-    p = _plans.get(module)
-    if p is None or p.key != _state_key(module) or not isinstance(p, cls):
+    """Cached plan of class ``cls`` for ``module`` (a module may own several kinds: a Siamese
+    has an attention plan and a verification-head plan); rebuilt when its state changes."""
+    per = _plans.get(module)
+    if per is None:
+        per = {}
+        _plans[module] = per
+    p = per.get(cls)
+    if p is None or p.key != _state_key(module):
         p = cls(module)
-        _plans[module] = p
+        per[cls] = p
     return p
 
 

@@ -24,8 +24,7 @@ class GrlGemm(C.Structure):
                                    'rnorm', 'cnorm', 'stats')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
-                                    'kw', 'stride', 'pad', 'math', 'ldwb')] + \
-               [(n, _fp) for n in ('w_hi', 'w_lo')]
+                                    'kw', 'stride', 'pad', 'math')]
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3 = 0, 1, 3
@@ -41,7 +40,6 @@ _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
-    'grl_split_bf16': ([_fp, _fp, _fp, _i64, _fp], C.c_int),
     'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),
     'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),

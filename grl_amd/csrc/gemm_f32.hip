@@ -103,12 +103,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         bofs[i] = (int64_t)n * p.ldw;
     }
 
-    // Pre-split weights (modes 1/3, eval): W_hi / W_lo bf16 planes [N][ldwb] made once per
-    // weight version by grl_split_bf16 -- the B stage is then a plain 16-byte copy into LDS
-    // (no conversion VALU); the A operand (activations) is still split on the fly.
-    constexpr int BH_ITEMS = BN / 64;                      // 16-byte items per thread per plane
-    const bool w_presplit = MATH != 0 && p.w_hi != nullptr;
-    uint4 bhreg[BH_ITEMS], blreg[BH_ITEMS];
     f32x4 areg[A_ITEMS], breg[B_ITEMS];
     auto load_stage = [&](int ks) {
         const int k0 = ks * BK;
@@ -132,22 +126,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             for (int i = 0; i < A_ITEMS; ++i)
                 areg[i] = *reinterpret_cast<const f32x4*>(p.a + ai[i].base + k0 + ld_chunk * 4);
         }
-        if (w_presplit) {
 #pragma unroll
-            for (int i = 0; i < BH_ITEMS; ++i) {
-                const int e = tid + 256 * i, row = e >> 2, c16 = e & 3;
-                int n = n0 + row;
-                n = n < p.N ? n : p.N - 1;
-                const int64_t o = (int64_t)n * p.ldwb + k0 + c16 * 8;
-                bhreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.w_hi) + o);
-                if (MATH == 3)
-                    blreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.w_lo) + o);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_ITEMS; ++i)
-                breg[i] = *reinterpret_cast<const f32x4*>(p.w + bofs[i] + k0 + ld_chunk * 4);
-        }
+        for (int i = 0; i < B_ITEMS; ++i)
+            breg[i] = *reinterpret_cast<const f32x4*>(p.w + bofs[i] + k0 + ld_chunk * 4);
     };
     auto split_store = [&](char* plane0, int plane_bytes, int row, const f32x4 v) {
         const int off = row * 64 + (((ld_chunk >> 1) ^ ((row >> 2) & 3)) << 4) + (ld_chunk & 1) * 8;
@@ -180,19 +161,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i)
                 split_store(Ah + buf * PL * BM * 64, BM * 64, ld_row + 32 * i, areg[i]);
-            if (w_presplit) {
 #pragma unroll
-                for (int i = 0; i < BH_ITEMS; ++i) {
-                    const int e = tid + 256 * i, row = e >> 2, c16 = e & 3;
-                    const int off = row * 64 + ((c16 ^ ((row >> 2) & 3)) << 4);
-                    *reinterpret_cast<uint4*>(Bh + buf * PL * BN * 64 + off) = bhreg[i];
-                    if (MATH == 3) *reinterpret_cast<uint4*>(Bh + buf * PL * BN * 64 + BN * 64 + off) = blreg[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < B_ITEMS; ++i)
-                    split_store(Bh + buf * PL * BN * 64, BN * 64, ld_row + 32 * i, breg[i]);
-            }
+            for (int i = 0; i < B_ITEMS; ++i)
+                split_store(Bh + buf * PL * BN * 64, BN * 64, ld_row + 32 * i, breg[i]);
         }
     };
 
@@ -473,12 +444,6 @@ int validate(const GrlGemm& d) {
     }
     if (d.math != GRL_MATH_F32 && d.math != GRL_MATH_BF16 && d.math != GRL_MATH_BF16X3)
         return grl_fail(GRL_EINVAL, "gemm: unknown math mode");
-    if (d.w_hi) {
-        if (d.math == GRL_MATH_F32) return grl_fail(GRL_EINVAL, "gemm: w_hi given with f32 math");
-        if (d.math == GRL_MATH_BF16X3 && !d.w_lo) return grl_fail(GRL_EINVAL, "gemm: bf16x3 needs w_lo with w_hi");
-        if (d.ldwb % 8 || ((uintptr_t)d.w_hi & 15) || ((uintptr_t)d.w_lo & 15))
-            return grl_fail(GRL_EINVAL, "gemm: bf16 weight planes must be 16-byte aligned, ldwb % 8 == 0");
-    }
     if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");

@@ -29,20 +29,6 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-__global__ void split_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ hi,
-                                  __bf16* __restrict__ lo, int64_t n4) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        bf16x4_t h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
-        reinterpret_cast<bf16x4_t*>(hi)[i] = h;
-        if (lo) reinterpret_cast<bf16x4_t*>(lo)[i] = l;
-    }
-}
-
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean,
                                const float* var, const float* bias, float eps, float* scale,
                                float* shift, int C) {
@@ -733,11 +719,4 @@ extern "C" int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int3
         (void)hipFuncSetAttribute((const void*)row_argsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(row_argsort_kernel, dim3(rows), dim3(1024), lds, (hipStream_t)stream, d, ld, n, P, idx);
     return grl_check_launch("grl_row_argsort");
-}
-
-extern "C" int grl_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
-    GRL_REQUIRE(x && hi && n > 0 && n % 4 == 0, "split_bf16: bad args");
-    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                       reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), n / 4);
-    return grl_check_launch("grl_split_bf16");
 }

@@ -66,7 +66,7 @@ def _new(shape, like):
 
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
-         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, wsplit=None):
+         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -88,8 +88,6 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.relu = 1 if relu else 0
     d.epilogue = epilogue
     d.math = _math[0] if math is None else math
-    if wsplit is not None and d.math != MATH_F32:          # (hi, lo, ldwb): pre-split bf16 weight planes
-        d.w_hi, d.w_lo, d.ldwb = ptr(wsplit[0]), ptr(wsplit[1]), wsplit[2]
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
@@ -113,22 +111,7 @@ def _call(name, *args):
 # ----------------------------------------------------------------------------
 class _Conv(object):
     """A conv (or linear) with its eval-folded affine."""
-    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin', '_hi', '_lo')
-
-    def split(self, col0=0):
-        """bf16 (hi, lo, ldwb) planes of the packed weight matrix, made on first use (bf16
-        datapaths only); ``col0`` selects a column sub-block of a wider matrix."""
-        if getattr(self, '_hi', None) is None:
-            w = self.w.contiguous()
-            self._hi = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-            self._lo = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-            _call('grl_split_bf16', ptr(w), ptr(self._hi), ptr(self._lo), w.numel())
-        return self._hi[:, col0:], self._lo[:, col0:], self._hi.shape[1]
-
-
-def _ws(c, col0=0):
-    """gemm() keyword for the pre-split weights of plan entry ``c`` (empty in f32 mode)."""
-    return {} if _math[0] == MATH_F32 else {'wsplit': c.split(col0)}
+    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin')
 
 
 def _state_key(module):
@@ -162,7 +145,6 @@ class EvalPlan(object):
 
     def conv(self, conv, bn=None):
         c = _Conv()
-        c._hi = c._lo = None
         w = conv.weight.detach()
         c.N, c.cin = w.shape[0], w.shape[1]
         c.k = w.shape[2] if w.dim() == 4 else 1
@@ -258,8 +240,7 @@ def _conv_layer(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     if c.k == 1 and stride == 1:
         M = n_img * H * W
         y = _new((M, c.N), x)
-        gemm(x, c.w, y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu,
-             **_ws(c), **kw)
+        gemm(x, c.w, y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu, **kw)
         return y, H, W
     pad = c.k // 2
     Ho = (H + 2 * pad - c.k) // stride + 1
@@ -267,7 +248,7 @@ def _conv_layer(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     M = n_img * Ho * Wo
     y = _new((M, c.N), x)
     gemm(x, c.w, y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu,
-         conv=(H, W, c.cin, Ho, Wo, c.k, c.k, stride, pad), **_ws(c), **kw)
+         conv=(H, W, c.cin, Ho, Wo, c.k, c.k, stride, pad), **kw)
     return y, Ho, Wo
 
 
@@ -317,18 +298,18 @@ def gce_eval(plan, x4, b, t, taps=None):
     _call('grl_group_mean', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
     g = plan.glo_fc
     glo = _new((b, 1024), x4)
-    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True, **_ws(g))
+    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True)
     # W.[x; g] = Wx.x + Wg.g : the broadcast-concat of basebranch.py:59-61 becomes a
     # per-clip bias added inside the accumulator epilogue.
     c0 = plan.corr0
     gb = _new((b, 1024), x4)
-    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072, **_ws(c0, 2048))
+    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072)
     h1 = _new((M, 1024), x4)
     gemm(x4, c0.w, h1, M, 1024, 2048, ldw=3072, gbias=gb, rows_per_group=t * PIX,
-         scale=c0.scale, shift=c0.shift, relu=False, **_ws(c0))
+         scale=c0.scale, shift=c0.shift, relu=False)
     c2 = plan.corr2
     h2 = _new((M, 256), x4)
-    gemm(h1, c2.w, h2, M, 256, 1024, scale=c2.scale, shift=c2.shift, relu=True, **_ws(c2))
+    gemm(h1, c2.w, h2, M, 256, 1024, scale=c2.scale, shift=c2.shift, relu=True)
     cmap = _new((M,), x4)
     xc = _new((M, 2048), x4)
     xu = _new((M, 2048), x4)
@@ -353,7 +334,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     f2 = []
     for d in plan.dirs:
         y = _new((b * t * PIX, Cc), xu)
-        gemm(xc, d['f2'].w, y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True, **_ws(d['f2']))
+        gemm(xc, d['f2'].w, y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True)
         f2.append(y)
     fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device)
     memo = [memo0, memo0]
@@ -364,7 +345,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
         for di, d in enumerate(plan.dirs):
             ti = i if di == 0 else t - 1 - i
             f1 = _new((Mb, Cc), xu)
-            gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, **_ws(d['f1']))
+            gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
             _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
             _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
                   ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
@@ -374,11 +355,11 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
             _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
             o = _new((Mb, 512), xu)
             c1, c2, c3 = d['c1'], d['c2'], d['c3']
-            gemm(s, c1.w, o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True, **_ws(c1))
+            gemm(s, c1.w, o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True)
             o2 = _new((Mb, 512), xu)
-            gemm(o, c2.w, o2, Mb, 512, 512, scale=c2.scale, shift=c2.shift, relu=True, **_ws(c2))
+            gemm(o, c2.w, o2, Mb, 512, 512, scale=c2.scale, shift=c2.shift, relu=True)
             nm = _new((Mb, Cc), xu)
-            gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True, **_ws(c3))
+            gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True)
             memo[di] = nm
     f_uncorr = _new((b, Cc), xu)
     _call('grl_group_mean', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)

@@ -80,20 +80,11 @@ typedef struct GrlGemm {
     /* conv geometry; conv == 0 means dense A */
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
     int32_t math;          /* GRL_MATH_*: multiplier datapath (accumulation is always fp32)   */
-    /* optional, bf16 datapaths only: the weights pre-split by grl_split_bf16 into bf16 planes
-     * [N][ldwb] (W = hi + lo); `w` is then unused by the B-operand loads */
-    int32_t ldwb;
-    const void* w_hi;
-    const void* w_lo;
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
 /* rows of the stats slab the call above writes (= number of M tiles it will use) */
 int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc);
-
-/* hi = bf16(x) (round to nearest even), lo = bf16(x - hi): the operand split of GRL_MATH_BF16X3
- * (lo may be NULL for GRL_MATH_BF16).  n elements, n % 4 == 0. */
-int grl_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
 /* [N][C][kh][kw] (torch layout) -> [N][kh*kw][C]; replaces nothing in the
  * reference (layout packing for the implicit GEMM). */

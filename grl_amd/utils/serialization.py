@@ -37,7 +37,8 @@ def save_siamese_checkpoint(state, is_best, fpath='checkpoint.pth.tar'):
 
 def load_checkpoint(fpath):
     if osp.isfile(fpath):
-        checkpoint = torch.load(fpath, map_location='cpu')
+        # reference checkpoints carry numpy scalars ('best_top1'): plain pickle load, as upstream
+        checkpoint = torch.load(fpath, map_location='cpu', weights_only=False)
         print("=> Loaded checkpoint '{}'".format(fpath))
         return checkpoint
     raise ValueError("=> No checkpoint found at '{}'".format(fpath))

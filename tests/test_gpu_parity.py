@@ -423,7 +423,7 @@ def test_reference_script_flow_through_dropin(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'Mean AP:' in out.stdout and 'best rank-1 accuracy is' in out.stdout
-    ck = torch.load(os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'), map_location='cpu')
+    ck = torch.load(os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'), map_location='cpu', weights_only=False)
     assert set(ck) == {'state_dict', 'epoch', 'best_top1'} and len(ck['state_dict']) == 401
     assert all(k.startswith('module.') for k in ck['state_dict'])
 

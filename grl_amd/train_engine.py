@@ -34,6 +34,7 @@ class Tape(object):
         self.wc = {}         # packed weights for this step
         self.no_grad = set() # ids of tensors that need no gradient (network input)
         self.taps = None     # optional dict of intermediates (tests)
+        self._pview = {}     # id(param) -> view into the flat gradient buffer
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
@@ -64,10 +65,22 @@ class Tape(object):
         return self.g.pop(id(t), None)
 
     # gradients of parameters --------------------------------------------------
+    def reserve_param_grads(self, params):
+        """One zero-filled flat buffer for every parameter gradient of the step (one memset
+        instead of one fill per parameter); ``pgrad`` hands out views."""
+        total = sum((p.numel() + 3) // 4 * 4 for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self._pview[id(p)] = flat[off:off + n].view_as(p)
+            off += (n + 3) // 4 * 4
+
     def pgrad(self, p):
         e = self.pg.get(id(p))
         if e is None:
-            e = (p, torch.zeros_like(p))
+            v = self._pview.get(id(p))
+            e = (p, v if v is not None else torch.zeros_like(p))
             self.pg[id(p)] = e
         return e[1]
 
@@ -228,7 +241,10 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     if id(x) in tp.no_grad:
         return
     Min = n_img * H * W
-    dx = _new((Min, cin), dz)
+    # if x already has a gradient (residual joins), accumulate in the GEMM epilogue
+    # (res = y = that tensor: every element is read and written by the same lane)
+    cur = tp.g.get(id(x))
+    dx = cur if cur is not None else _new((Min, cin), dz)
     if k == 1:
         w2d = w.detach().view(N, -1)
         wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1])
@@ -236,15 +252,16 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
         if stride != 1:
             src = _new((Min, N), dz)
             _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
-        gemm(src, wt, dx, Min, cin, N)
+        gemm(src, wt, dx, Min, cin, N, res=cur)
     else:
         wd = tp.w_dgrad(conv)
         src = dz
         if stride != 1:
             src = _new((Min, N), dz)
             _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
-        gemm(src, wd, dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2))
-    tp.add_grad(x, dx)
+        gemm(src, wd, dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
+    if cur is None:
+        tp.g[id(x)] = dx
 
 
 def biased_conv_relu(tp, x, M, conv):
@@ -263,9 +280,13 @@ def biased_conv_relu(tp, x, M, conv):
         _call('grl_relu_bwd', ptr(da), ptr(a), ptr(g), da.numel(), 0)
         colsum_into(g, M, N, tp.pgrad(conv.bias))
         wgrad(g, x, tp.pgrad(w), M, N, K)
-        dx = _new((M, K), g)
-        gemm(g, tp.w_t(w2d, w), dx, M, K, N)
-        tp.add_grad(x, dx)
+        cur = tp.g.get(id(x))
+        if cur is not None and tuple(cur.shape) != (M, K):
+            cur = cur.view(M, K)
+        dx = cur if cur is not None else _new((M, K), g)
+        gemm(g, tp.w_t(w2d, w), dx, M, K, N, res=cur)
+        if cur is None:
+            tp.g[id(x)] = dx
     tp.ops.append(bwd)
     return a
 
@@ -584,6 +605,7 @@ class _GrlTrainFn(torch.autograd.Function):
     def forward(ctx, model_box, inputs, *params):
         model = model_box[0]
         tp = Tape(inputs.device)
+        tp.reserve_param_grads(params)
         tp.taps = getattr(model, '_grl_taps', None)
         b, t = inputs.shape[:2]
         x = inputs.contiguous().view(b * t, 3, 256, 128)

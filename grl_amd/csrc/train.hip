@@ -10,6 +10,7 @@
 // (reid/train/trainer.py:54).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/grl_hip.h"
 #include "common.h"
 
@@ -637,7 +638,8 @@ extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, 
 
 static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
     const int64_t tiles = (int64_t)((d.N + bm - 1) / bm) * ((d.K + bn - 1) / bn);
-    int64_t want = (1024 + tiles - 1) / tiles;
+    static const int target = getenv("GRL_WGRAD_BLOCKS") ? atoi(getenv("GRL_WGRAD_BLOCKS")) : 1024;   // tuning only
+    int64_t want = (target + tiles - 1) / tiles;
     const int64_t max_splits = (d.M + 255) / 256;
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

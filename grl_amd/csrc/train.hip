@@ -638,7 +638,7 @@ extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, 
 
 static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
     const int64_t tiles = (int64_t)((d.N + bm - 1) / bm) * ((d.K + bn - 1) / bn);
-    static const int target = getenv("GRL_WGRAD_BLOCKS") ? atoi(getenv("GRL_WGRAD_BLOCKS")) : 1024;   // tuning only
+    static const int target = getenv("GRL_WGRAD_BLOCKS") ? atoi(getenv("GRL_WGRAD_BLOCKS")) : 512;   // tuning only
     int64_t want = (target + tiles - 1) / tiles;
     const int64_t max_splits = (d.M + 255) / 256;
     if (want > max_splits) want = max_splits;

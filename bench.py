@@ -226,11 +226,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # GRL_DIST_BACKEND=gloo + GRL_SINGLE_DEVICE=1: functional test of the N>1 path on a box with
+    # one GPU (every rank on cuda:0, collectives through gloo); the real runs use nccl = RCCL.
+    backend = os.environ.get('GRL_DIST_BACKEND', 'nccl')
+    if os.environ.get('GRL_SINGLE_DEVICE'):
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)

@@ -248,3 +248,30 @@ def test_row_argsort_matches_numpy(dev):
     from grl_amd._lib import GrlHipError
     with pytest.raises(GrlHipError):
         engine.rank_rows(torch.zeros(2, 16385, device=dev))
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,H,W,n', [(64, 64, 3, 1, 16, 8, 2), (128, 96, 3, 2, 16, 16, 1),
+                                                      (256, 128, 1, 2, 8, 8, 2)])
+def test_conv_bit_exact_vs_fma_chain(dev, cin, cout, k, stride, H, W, n):
+    """The implicit-GEMM gather feeds the same k-ordered fmaf chain as the dense kernel:
+    conv output == C oracle chain over the (tap-major, channel-minor) im2col matrix, bit for bit."""
+    from grl_amd import engine
+    from grl_amd._lib import ptr
+    from oracle.ref_c import chain_gemm
+    rng = np.random.default_rng(cin * 3 + k)
+    x = rng.standard_normal((n, H, W, cin)).astype(np.float32)            # channels-last
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xp = np.zeros((n, H + 2 * pad, W + 2 * pad, cin), np.float32)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    cols = np.empty((n, Ho, Wo, k * k, cin), np.float32)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, ky * k + kx] = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride]
+    wp = np.ascontiguousarray(w.reshape(cout, cin, k * k).transpose(0, 2, 1)).reshape(cout, k * k * cin)
+    ref = chain_gemm(cols.reshape(n * Ho * Wo, k * k * cin), wp)
+    y = torch.empty(n * Ho * Wo, cout, device=dev)
+    engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(wp).to(dev), y, n * Ho * Wo, cout, k * k * cin,
+                conv=(H, W, cin, Ho, Wo, k, k, stride, pad))
+    assert np.array_equal(y.cpu().numpy(), ref)

@@ -51,8 +51,7 @@ struct RowInfo {          // per staged A row: where it comes from
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
 template <int BM, int BN, bool CONV, int MATH>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
-                                                           const int num_tiles, const int vec_epi,
-                                                           const int single_buf) {
+                                                           const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = single_buf ? 0 : (ks & 1);
+        const int buf = ks & 1;
         if (ks + 1 < nk) load_stage(ks + 1);
         if constexpr (MATH == 0) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
@@ -246,12 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                     }
             }
         }
-        if (single_buf) {                     // EXPERIMENT: one LDS stage, two barriers, 3+ blocks/CU
-            __syncthreads();
-            if (ks + 1 < nk) store_stage(0);
-        } else if (ks + 1 < nk) {
-            store_stage(buf ^ 1);
-        }
+        if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
     }
 
@@ -411,20 +405,19 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
     constexpr size_t stage_bytes = MATH == 0 ? (size_t)2 * (BM + BN) * BK * sizeof(float)
                                              : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
-    static const int single_buf = getenv("GRL_GEMM_SINGLEBUF") ? 1 : 0;
-    const size_t lds = single_buf ? stage_bytes / 2 : (stage_bytes > c_bytes ? stage_bytes : c_bytes);
+    constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const int vec_epi = (!single_buf && !d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
+    const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (d.conv) {
         auto k = gemm_f32_kernel<BM, BN, true, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi, single_buf);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     } else {
         auto k = gemm_f32_kernel<BM, BN, false, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi, single_buf);
+        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
 }

@@ -24,10 +24,10 @@ class GrlGemm(C.Structure):
                                    'rnorm', 'cnorm', 'stats')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
-                                    'kw', 'stride', 'pad', 'math')]
+                                    'kw', 'stride', 'pad', 'math', 'out_f32')]
 
 
-MATH_F32, MATH_BF16, MATH_BF16X3 = 0, 1, 3
+MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
 
 
 class GrlWgrad(C.Structure):

@@ -47,6 +47,10 @@ struct RowInfo {          // per staged A row: where it comes from
 //      is hi*hi + hi*lo + lo*hi on the bf16 MFMA (3/16 of the fp32 MFMA cycles); the
 //      dropped lo*lo term and the 16-bit operand significands give ~2^-16 relative error
 //      per product -- fp32-class accuracy for the 1e-3 parity budget, NOT bit-exact.
+//   2  bf16 STORAGE ("bf16s"): activations, weights, residual and output are bf16 in HBM
+//      (half the bytes), products on v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32
+//      epilogue math.  A stage is 64 k wide, i.e. the same 128-byte rows, staging and LDS
+//      swizzle as the fp32 path; one ds_read_b128 (8 consecutive k) feeds one MFMA.
 // In modes 1/3 operands stay fp32 in HBM and are converted in the staging pass; LDS
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
 template <int BM, int BN, bool CONV, int MATH>
@@ -54,6 +58,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                                                            const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
+    constexpr int ESZ = MATH == 2 ? 2 : 4;        // bytes per operand element in HBM
+    constexpr int EPC = 16 / ESZ;                 // elements per 16-byte chunk
+    constexpr int KST = 8 * EPC;                  // k per stage: 128-byte rows (32 fp32 / 64 bf16)
+    auto gp = [](const float* base, int64_t elem_off) {       // 16-byte chunk at an ELEMENT offset
+        return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + elem_off * ESZ);
+    };
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [2][BM*32]           (MATH == 0)
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 
     f32x4 areg[A_ITEMS], breg[B_ITEMS];
     auto load_stage = [&](int ks) {
-        const int k0 = ks * BK;
+        const int k0 = ks * KST;
         if (CONV) {
             const int tap = k0 / p.C, c0 = k0 - tap * p.C;          // wave-uniform
             const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                 // branch-free: out-of-image taps load pixel (0,0) of the same image and are
                 // zeroed by a select, so the stage's loads issue back to back
                 const int64_t pix = ok ? (int64_t)iy * p.W + ix : 0;
-                f32x4 v = *reinterpret_cast<const f32x4*>(p.a + ai[i].base + pix * p.C + c0 + ld_chunk * 4);
+                f32x4 v = *gp(p.a, ai[i].base + pix * p.C + c0 + ld_chunk * EPC);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
                 areg[i] = v;
@@ -124,11 +134,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         } else {
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i)
-                areg[i] = *reinterpret_cast<const f32x4*>(p.a + ai[i].base + k0 + ld_chunk * 4);
+                areg[i] = *gp(p.a, ai[i].base + k0 + ld_chunk * EPC);
         }
 #pragma unroll
         for (int i = 0; i < B_ITEMS; ++i)
-            breg[i] = *reinterpret_cast<const f32x4*>(p.w + bofs[i] + k0 + ld_chunk * 4);
+            breg[i] = *gp(p.w, bofs[i] + k0 + ld_chunk * EPC);
     };
     auto split_store = [&](char* plane0, int plane_bytes, int row, const f32x4 v) {
         const int off = row * 64 + (((ld_chunk >> 1) ^ ((row >> 2) & 3)) << 4) + (ld_chunk & 1) * 8;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         }
     };
     auto store_stage = [&](int buf) {
-        if constexpr (MATH == 0) {
+        if constexpr (MATH == 0 || MATH == 2) {
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i) {
                 const int row = ld_row + 32 * i;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk = p.K / KST;
     const int frow = lane & 31, fhalf = lane >> 5;
 
     load_stage(0);
@@ -185,7 +195,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_stage(ks + 1);
-        if constexpr (MATH == 0) {
+        if constexpr (MATH == 2) {
+            const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
+            const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                  // four K = 16 steps per 64-wide stage
+                bf16x8 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = i * 32 + frow;
+                    af[i] = *reinterpret_cast<const bf16x8*>(
+                        Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = j * 32 + frow;
+                    bf[j] = *reinterpret_cast<const bf16x8*>(
+                        Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (MATH == 0) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
 #pragma unroll
@@ -289,7 +323,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                             v += *reinterpret_cast<const f32x4*>(
                                 p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n);
                         v = v * sc + sh;
-                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                        if (p.res) {
+                            if constexpr (MATH == 2) {
+                                const bf16x4 r = *reinterpret_cast<const bf16x4*>(
+                                    reinterpret_cast<const __bf16*>(p.res) + (int64_t)m * p.ldres + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                            } else {
+                                v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                            }
+                        }
                         if (p.relu) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -301,7 +344,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = sqrtf(v[e] > 1e-12f ? v[e] : 1e-12f);
                     }
-                    *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                    if constexpr (MATH == 2) {
+                        if (p.out_f32) {                   // fp32 hand-off to the fp32 head kernels
+                            *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                        } else {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + n) = o;
+                        }
+                    } else {
+                        *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                    }
                 }
             }
         }
@@ -402,14 +456,16 @@ template <int BM, int BN, int MATH>
 int launch_math(const GrlGemm& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    constexpr size_t stage_bytes = MATH == 0 ? (size_t)2 * (BM + BN) * BK * sizeof(float)
-                                             : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
+    constexpr size_t stage_bytes = (MATH == 0 || MATH == 2) ? (size_t)2 * (BM + BN) * BK * sizeof(float)
+                                                            : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
+    if (MATH == 2 && !vec_epi)
+        return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
     if (d.conv) {
         auto k = gemm_f32_kernel<BM, BN, true, MATH>;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -424,6 +480,7 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
 
 template <int BM, int BN>
 int launch(const GrlGemm& d, hipStream_t s) {
+    if (d.math == GRL_MATH_BF16S) return launch_math<BM, BN, 2>(d, s);
     if (d.math == GRL_MATH_BF16X3) return launch_math<BM, BN, 3>(d, s);
     if (d.math == GRL_MATH_BF16) return launch_math<BM, BN, 1>(d, s);
     return launch_math<BM, BN, 0>(d, s);
@@ -442,8 +499,16 @@ int validate(const GrlGemm& d) {
     } else if (d.lda % 4) {
         return grl_fail(GRL_EINVAL, "gemm: lda % 4 != 0");
     }
-    if (d.math != GRL_MATH_F32 && d.math != GRL_MATH_BF16 && d.math != GRL_MATH_BF16X3)
+    if (d.math != GRL_MATH_F32 && d.math != GRL_MATH_BF16 && d.math != GRL_MATH_BF16X3 &&
+        d.math != GRL_MATH_BF16S)
         return grl_fail(GRL_EINVAL, "gemm: unknown math mode");
+    if (d.math == GRL_MATH_BF16S) {
+        if (d.K % 64 || (d.conv && d.C % 64)) return grl_fail(GRL_EINVAL, "gemm bf16s: K (and C) must be multiples of 64");
+        if (d.epilogue != GRL_EPI_AFFINE || d.stats) return grl_fail(GRL_EINVAL, "gemm bf16s: affine epilogue only");
+        if (d.N % 4 || d.ldy % 4 || (d.res && d.ldres % 4) || d.lda % 8 || d.ldw % 8 ||
+            ((uintptr_t)d.y & 15) || ((uintptr_t)d.res & 15))
+            return grl_fail(GRL_EINVAL, "gemm bf16s: N, ldy, ldres % 4, lda, ldw % 8, aligned pointers");
+    }
     if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");

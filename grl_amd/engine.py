@@ -66,7 +66,7 @@ def _new(shape, like):
 
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
-         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None):
+         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -88,6 +88,7 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.relu = 1 if relu else 0
     d.epilogue = epilogue
     d.math = _math[0] if math is None else math
+    d.out_f32 = 1 if out_f32 else 0
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv

@@ -43,6 +43,8 @@ int grl_abi_version(void);
 #define GRL_MATH_F32     0  /* exact fp32 MFMA: the documented fmaf chain (default)              */
 #define GRL_MATH_BF16    1  /* operands rounded to bf16 while staging, bf16 MFMA (BASELINE cfg 2) */
 #define GRL_MATH_BF16X3  3  /* split-bf16: hi*hi + hi*lo + lo*hi on the bf16 MFMA, ~2^-16 rel.   */
+#define GRL_MATH_BF16S   2  /* bf16 STORAGE: a, w, res and y are bf16 arrays (lda/ldw/ldy/ldres in
+                             * elements), fp32 accumulate + epilogue; `out_f32` keeps y fp32      */
 
 /*
  * One fp32 MFMA GEMM  Y[M][N] = epilogue( A[M][K] . W[N][K]^T ), K-contiguous on
@@ -80,6 +82,7 @@ typedef struct GrlGemm {
     /* conv geometry; conv == 0 means dense A */
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
     int32_t math;          /* GRL_MATH_*: multiplier datapath (accumulation is always fp32)   */
+    int32_t out_f32;       /* GRL_MATH_BF16S only: write y as fp32                            */
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);

@@ -275,3 +275,30 @@ def test_conv_bit_exact_vs_fma_chain(dev, cin, cout, k, stride, H, W, n):
     engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(wp).to(dev), y, n * Ho * Wo, cout, k * k * cin,
                 conv=(H, W, cin, Ho, Wo, k, k, stride, pad))
     assert np.array_equal(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('M,N,K,conv', [(512, 256, 2048, None), (300, 200, 128, None),
+                                        (128 * 3, 128, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1)),
+                                        (2 * 64, 192, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1))])
+def test_gemm_bf16_storage(dev, M, N, K, conv):
+    """bf16-storage datapath (GRL_MATH_BF16S): bf16 operands, residual and output in HBM, fp32
+    accumulate/epilogue.  With bf16-representable inputs the only rounding is the final store."""
+    from grl_amd import engine
+    rng = np.random.default_rng(23 + M)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+    a = torch.from_numpy(rng.standard_normal((rows_in, cin)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).bfloat16()
+    res = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).bfloat16()
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    y32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ad, wd, rd, scd, shd = a.to(dev), w.to(dev), res.to(dev), sc.to(dev), sh.to(dev)
+    engine.gemm(ad, wd, y, M, N, K, scale=scd, shift=shd, res=rd, relu=True, conv=conv, math=2)
+    engine.gemm(ad, wd, y32, M, N, K, scale=scd, shift=shd, res=rd, relu=True, conv=conv, math=2, out_f32=True)
+    # fp32 reference through the exact path on the same (bf16-representable) values
+    ref = torch.empty(M, N, device=dev)
+    engine.gemm(ad.float(), wd.float(), ref, M, N, K, scale=scd, shift=shd, res=rd.float(), relu=True, conv=conv, math=0)
+    assert _rel(y32.cpu().numpy(), ref.cpu().numpy()) < 2e-6            # same products, fp32 accumulate
+    assert torch.equal(y, y32.bfloat16())                               # one rounding on the store

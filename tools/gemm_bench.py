@@ -26,9 +26,9 @@ def bench(tile, iters=5):
     math = 0
     if ':' in tile:                       # e.g. bf16x3:256x128
         m, tile = tile.split(':')
-        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[m]
-    elif tile in ('bf16x3', 'bf16', 'f32'):
-        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3}[tile]
+        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16s': 2}[m]
+    elif tile in ('bf16x3', 'bf16', 'f32', 'bf16s'):
+        math = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16s': 2}[tile]
         tile = 'auto'
     if tile == 'auto':
         os.environ.pop('GRL_GEMM_TILE', None)
@@ -46,6 +46,11 @@ def bench(tile, iters=5):
         y = torch.empty(M, N, device=dev)
         sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
         r = torch.randn(M, N, device=dev) if has_res else None
+        if math == 2:
+            if K % 64:
+                continue
+            a, w, y = a.bfloat16(), w.bfloat16(), y.bfloat16()
+            r = r.bfloat16() if r is not None else None
         for _ in range(2):
             engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=r, relu=True, conv=conv, math=math)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,6 +71,9 @@ if __name__ == '__main__':
     for key in allres[tiles[0]]:
         line = '%-34s' % str(key)
         for t in tiles:
+            if key not in allres[t]:
+                line += '%22s' % '-'
+                continue
             ms, calls, fl = allres[t][key]
             tot[t] += ms * calls
             line += '   %7.3f ms %6.1f TF' % (ms, fl / ms / 1e9)

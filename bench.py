@@ -213,7 +213,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16s'],
                     help="multiplier datapath of the conv GEMMs for the headline `value` "
                          "(default: exact fp32 MFMA = BASELINE configs[1])")
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 measurements')
@@ -304,7 +304,7 @@ def main():
             # secondary, informational: the opt-in bf16 multiplier datapaths on the SAME
             # workload, with their deviation from the exact-fp32 features measured live
             alt = {}
-            for mode in ('bf16x3', 'bf16'):
+            for mode in ('bf16x3', 'bf16', 'bf16s'):
                 if mode == args.math:
                     continue
                 with engine.math_mode(mode):

@@ -84,6 +84,14 @@ _SIGNATURES = {
     'grl_pair_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
     'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_cast_bf16': ([_fp, _fp, _i64, _fp], C.c_int),
+    'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_maxpool3x3s2_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_group_mean_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp], C.c_int),
+    'grl_sqdiff_mean_bf16': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_gce_gate_bf16': ([_fp] * 8 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_temporal_mean_bf16': ([_fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
+    'grl_add_strided_bf16': ([_fp, _fp, _fp, C.c_int, _i64, _i64, _fp], C.c_int),
     'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
 }
 

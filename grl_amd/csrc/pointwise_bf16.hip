@@ -1,0 +1,241 @@
+// bf16-STORAGE variants of the bandwidth-bound kernels (BASELINE configs[2] pipeline,
+// engine math mode 'bf16s'): activations are bf16 in HBM, every lane moves 16 bytes
+// (8 channels), arithmetic and all reductions are fp32, per-channel / per-clip vectors
+// stay fp32.  Same semantics and reference call sites as their fp32 twins in pointwise.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __forceinline__ f32x8 ld8(const __bf16* p) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+    return r;
+}
+__device__ __forceinline__ void st8(__bf16* p, const f32x8 v) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = r;
+}
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        st8(y + i * 8, v);
+    }
+}
+
+__global__ void maxpool_b16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int n, int H,
+                                   int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C8 = C >> 3;
+    const int64_t total = (int64_t)n * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = i % C8;
+        int64_t r = i / C8;
+        const int ox = r % Wo; r /= Wo;
+        const int oy = r % Ho;
+        const int img = r / Ho;
+        f32x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x8 v = ld8(x + (((int64_t)img * H + iy) * W + ix) * C + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        st8(y + i * 8, m);
+    }
+}
+
+// y[g][c] (+)= mul * sum_r x[g][r][c]   (bf16 in, fp32 out); 32 lanes x 8 channels = 256-channel slab
+__global__ __launch_bounds__(256) void group_mean_b16_kernel(const __bf16* __restrict__ x,
+                                                             float* __restrict__ y, int rows, int C,
+                                                             int ldy, float mul, int accumulate) {
+    __shared__ f32x8 red[8][32];
+    const int g = blockIdx.y, sub = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 256 + sub * 8;
+    f32x8 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (c < C) {
+        const __bf16* xp = x + (int64_t)g * rows * C + c;
+        for (int r = part; r < rows; r += 8) s += ld8(xp + (int64_t)r * C);
+    }
+    red[part][sub] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        f32x8 t = red[0][sub];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][sub];
+        float* yp = y + (int64_t)g * ldy + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yp[e] = (accumulate ? yp[e] : 0.f) + t[e] * mul;
+    }
+}
+
+__global__ __launch_bounds__(256) void sqdiff_mean_b16_kernel(const __bf16* __restrict__ f1,
+                                                              const __bf16* __restrict__ f2,
+                                                              float* __restrict__ d, int rows, int C,
+                                                              int64_t f2_stride) {
+    __shared__ f32x8 red[8][32];
+    const int g = blockIdx.y, sub = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 256 + sub * 8;
+    f32x8 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (c < C) {
+        const __bf16* p1 = f1 + (int64_t)g * rows * C + c;
+        const __bf16* p2 = f2 + (int64_t)g * f2_stride + c;
+        for (int r = part; r < rows; r += 8) {
+            const f32x8 t = ld8(p1 + (int64_t)r * C) - ld8(p2 + (int64_t)r * C);
+            s += t * t;
+        }
+    }
+    red[part][sub] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        f32x8 t = red[0][sub];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][sub];
+        const float inv = 1.f / rows;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[(int64_t)g * C + c + e] = t[e] * inv;
+    }
+}
+
+// GCE gate, one wave per pixel row: map = sigmoid(bn(h[m] . w3)); xc = x*map; xu = x*(1-map)
+__global__ __launch_bounds__(256) void gce_gate_b16_kernel(
+    const __bf16* __restrict__ h, const float* __restrict__ w3, const float* __restrict__ bsc,
+    const float* __restrict__ bsh, const __bf16* __restrict__ x, float* __restrict__ cmap,
+    __bf16* __restrict__ xc, __bf16* __restrict__ xu, int M, int Ch, int C) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = lane * 8; k < Ch; k += 512) {
+        const f32x8 a = ld8(h + (int64_t)m * Ch + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += a[e] * w3[k + e];
+    }
+    s = wave_sum(s);
+    const float g = sigmoidf_(s * bsc[0] + bsh[0]);
+    if (lane == 0 && cmap) cmap[m] = g;
+    const float gu = 1.f - g;
+    for (int c = lane * 8; c < C; c += 512) {
+        const f32x8 v = ld8(x + (int64_t)m * C + c);
+        st8(xc + (int64_t)m * C + c, v * g);
+        st8(xu + (int64_t)m * C + c, v * gu);
+    }
+}
+
+__global__ void temporal_mean_b16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int T,
+                                         int64_t inner8, int64_t total8) {
+    const float inv = 1.f / T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / inner8, r = i - b * inner8;
+        const __bf16* xp = x + (b * T * inner8 + r) * 8;
+        f32x8 s = ld8(xp);
+        for (int t = 1; t < T; ++t) s += ld8(xp + t * inner8 * 8);
+        st8(y + i * 8, s * inv);
+    }
+}
+
+__global__ void add_strided_b16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ bsrc,
+                                       __bf16* __restrict__ y, int64_t inner8, int64_t bstride8,
+                                       int64_t total8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / inner8, r = i - b * inner8;
+        st8(y + i * 8, ld8(a + i * 8) + ld8(bsrc + (b * bstride8 + r) * 8));
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+#define B16(p) reinterpret_cast<__bf16*>(p)
+#define CB16(p) reinterpret_cast<const __bf16*>(p)
+
+extern "C" int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
+    GRL_REQUIRE(x && y && n > 0 && n % 8 == 0, "cast_bf16: n % 8");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, B16(y), n / 8);
+    return grl_check_launch("grl_cast_bf16");
+}
+
+extern "C" int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream) {
+    GRL_REQUIRE(x && y && n > 0 && C % 8 == 0, "maxpool_bf16: bad args");
+    const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_b16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, CB16(x), B16(y),
+                       n, H, W, C);
+    return grl_check_launch("grl_maxpool3x3s2_bf16");
+}
+
+extern "C" int grl_group_mean_bf16(const void* x, float* y, int groups, int rows, int C, int ldy, float out_scale,
+                                   int accumulate, void* stream) {
+    GRL_REQUIRE(x && y && groups > 0 && rows > 0 && C % 8 == 0, "group_mean_bf16: bad args");
+    hipLaunchKernelGGL(group_mean_b16_kernel, dim3(grl_ceil_div(C, 256), groups), dim3(256), 0, (hipStream_t)stream,
+                       CB16(x), y, rows, C, ldy, out_scale / rows, accumulate);
+    return grl_check_launch("grl_group_mean_bf16");
+}
+
+extern "C" int grl_sqdiff_mean_bf16(const void* f1, const void* f2, float* d, int b, int rows, int C,
+                                    int64_t f2_clip_stride, void* stream) {
+    GRL_REQUIRE(f1 && f2 && d && b > 0 && rows > 0 && C % 8 == 0 && f2_clip_stride % 8 == 0, "sqdiff_mean_bf16: bad args");
+    hipLaunchKernelGGL(sqdiff_mean_b16_kernel, dim3(grl_ceil_div(C, 256), b), dim3(256), 0, (hipStream_t)stream,
+                       CB16(f1), CB16(f2), d, rows, C, f2_clip_stride);
+    return grl_check_launch("grl_sqdiff_mean_bf16");
+}
+
+extern "C" int grl_gce_gate_bf16(const void* h, const float* w3, const float* bn_scale, const float* bn_shift,
+                                 const void* x, float* corr_map, void* x_corr, void* x_uncorr, int M, int Ch, int C,
+                                 void* stream) {
+    GRL_REQUIRE(h && w3 && bn_scale && bn_shift && x && x_corr && x_uncorr, "gce_gate_bf16: null");
+    GRL_REQUIRE(M > 0 && Ch % 8 == 0 && C % 8 == 0, "gce_gate_bf16: bad shape");
+    hipLaunchKernelGGL(gce_gate_b16_kernel, dim3(grl_ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream, CB16(h), w3,
+                       bn_scale, bn_shift, CB16(x), corr_map, B16(x_corr), B16(x_uncorr), M, Ch, C);
+    return grl_check_launch("grl_gce_gate_bf16");
+}
+
+extern "C" int grl_temporal_mean_bf16(const void* x, void* y, int b, int T, int64_t inner, void* stream) {
+    GRL_REQUIRE(x && y && b > 0 && T > 0 && inner % 8 == 0, "temporal_mean_bf16: bad args");
+    const int64_t total8 = (int64_t)b * inner / 8;
+    hipLaunchKernelGGL(temporal_mean_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, CB16(x),
+                       B16(y), T, inner / 8, total8);
+    return grl_check_launch("grl_temporal_mean_bf16");
+}
+
+extern "C" int grl_add_strided_bf16(const void* a, const void* b, void* y, int nb, int64_t inner,
+                                    int64_t b_clip_stride, void* stream) {
+    GRL_REQUIRE(a && b && y && nb > 0 && inner % 8 == 0 && b_clip_stride % 8 == 0, "add_strided_bf16: bad args");
+    const int64_t total8 = (int64_t)nb * inner / 8;
+    hipLaunchKernelGGL(add_strided_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, CB16(a),
+                       CB16(b), B16(y), inner / 8, b_clip_stride / 8, total8);
+    return grl_check_launch("grl_add_strided_bf16");
+}

@@ -25,13 +25,15 @@ from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, check, ptr, requi
 import contextlib
 import os
 
-from ._lib import MATH_F32, MATH_BF16, MATH_BF16X3
+from ._lib import MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S
 
-_MATH_NAMES = {'f32': MATH_F32, 'bf16': MATH_BF16, 'bf16x3': MATH_BF16X3}
+_MATH_NAMES = {'f32': MATH_F32, 'bf16': MATH_BF16, 'bf16x3': MATH_BF16X3, 'bf16s': MATH_BF16S}
 # Multiplier datapath of the conv / linear GEMMs (accumulation is always fp32):
 #   'f32'    exact fp32 MFMA, the default and the mode every parity claim is made in;
 #   'bf16x3' split-bf16 (hi*hi + hi*lo + lo*hi), ~2^-16 relative per product;
-#   'bf16'   operands rounded to bf16 (BASELINE configs[2]).
+#   'bf16'   operands rounded to bf16 while staging, activations still fp32 in HBM;
+#   'bf16s'  bf16 STORAGE: activations and weights are bf16 in HBM from the stem to the TRL
+#            memo (BASELINE configs[2] pipeline); per-clip vectors and the tail stay fp32.
 # The evaluator distance matrices always use 'f32' (bit-exact ranking contract).
 _math = [_MATH_NAMES[os.environ.get('GRL_MATH', 'f32')]]
 
@@ -87,7 +89,7 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.rows_per_group = rows_per_group
     d.relu = 1 if relu else 0
     d.epilogue = epilogue
-    d.math = _math[0] if math is None else math
+    d.math = (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if math is None else math
     d.out_f32 = 1 if out_f32 else 0
     if conv is not None:
         d.conv = 1
@@ -112,7 +114,15 @@ def _call(name, *args):
 # ----------------------------------------------------------------------------
 class _Conv(object):
     """A conv (or linear) with its eval-folded affine."""
-    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin')
+    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin', '_wb')
+
+    def wb(self):
+        """bf16 copy of the packed weight (bf16-storage pipeline), made on first use."""
+        if getattr(self, '_wb', None) is None:
+            w = self.w.contiguous()
+            self._wb = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+            _call('grl_cast_bf16', ptr(w), ptr(self._wb), w.numel())
+        return self._wb
 
 
 def _state_key(module):
@@ -146,6 +156,7 @@ class EvalPlan(object):
 
     def conv(self, conv, bn=None):
         c = _Conv()
+        c._wb = None
         w = conv.weight.detach()
         c.N, c.cin = w.shape[0], w.shape[1]
         c.k = w.shape[2] if w.dim() == 4 else 1
@@ -371,6 +382,8 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
 
 
 def _grl_eval(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
+    if _math[0] == MATH_BF16S:
+        return _grl_eval_bf16s(model, inputs, taps, out_uncorr, ld_uncorr)
     plan = _plan(model, GrlEvalPlan)
     b, t, c, h, w = inputs.shape
     if (c, h, w) != (3, 256, 128):
@@ -382,6 +395,124 @@ def _grl_eval(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     f_uncorr, f_corr = trl_eval(plan, xu, xc, b, t, taps)
     x_corr = _new((b, t, 2048), inputs)
     _call('grl_affine_l2norm', ptr(f_corr), ptr(plan.corr_bn[0]), ptr(plan.corr_bn[1]), ptr(x_corr),
+          b * t, 2048, 2048)
+    x_uncorr = out_uncorr if out_uncorr is not None else _new((b, 2048), inputs)
+    _call('grl_affine_l2norm', ptr(f_uncorr), ptr(plan.uncorr_bn[0]), ptr(plan.uncorr_bn[1]),
+          ptr(x_uncorr), b, 2048, ld_uncorr)
+    return x_uncorr, x_corr
+
+
+# ----------------------------------------------------------------------------
+# bf16-storage eval forward (BASELINE configs[2])
+# ----------------------------------------------------------------------------
+def _newb(shape, like):
+    return torch.empty(shape, dtype=torch.bfloat16, device=like.device)
+
+
+def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
+    if c.k == 1 and stride == 1:
+        M = n_img * H * W
+        y = _newb((M, c.N), x)
+        gemm(x, c.wb(), y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu,
+             math=MATH_BF16S, **kw)
+        return y, H, W
+    pad = c.k // 2
+    Ho, Wo = (H + 2 * pad - c.k) // stride + 1, (W + 2 * pad - c.k) // stride + 1
+    M = n_img * Ho * Wo
+    y = _newb((M, c.N), x)
+    gemm(x, c.wb(), y, M, c.N, c.K, ldw=c.ldw, scale=c.scale, shift=c.shift, res=res, relu=relu,
+         conv=(H, W, c.cin, Ho, Wo, c.k, c.k, stride, pad), math=MATH_BF16S, **kw)
+    return y, Ho, Wo
+
+
+def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
+    """Same launch order as _grl_eval with bf16 activations in HBM: stem -> trunk -> GCE ->
+    TRL memo are bf16 tensors, every GEMM is the bf16-storage datapath, reductions land in
+    fp32 vectors, the BN1d + L2 tail is the fp32 one."""
+    plan = _plan(model, GrlEvalPlan)
+    b, t, c, h, w = inputs.shape
+    if (c, h, w) != (3, 256, 128):
+        raise ValueError('GRL expects clips of [B,T,3,256,128] (got %s)' % (tuple(inputs.shape),))
+    x = inputs.contiguous().view(b * t, c, h, w)
+    n = b * t
+    Hs, Ws = h // 2, w // 2
+    stem = _newb((n * Hs * Ws, 64), x)
+    _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+          ptr(stem), n, h, w, 1)
+    H, W = (Hs + 1) // 2, (Ws + 1) // 2
+    cur = _newb((n * H * W, 64), x)
+    _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)
+    del stem
+    for e in plan.blocks:
+        s = e['stride']
+        o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
+        o2, Ho, Wo = _conv_b16(o1, e['c2'], n, H, W, stride=s)
+        res = _conv_b16(cur, e['down'], n, H, W, stride=s, relu=False)[0] if e['down'] is not None else cur
+        cur, _, _ = _conv_b16(o2, e['c3'], n, Ho, Wo, res=res)
+        H, W = Ho, Wo
+    x4 = cur
+    M = x4.shape[0]
+    # GCE
+    x_glo = _new((b, 2048), x)
+    _call('grl_group_mean_bf16', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
+    g = plan.glo_fc
+    glo = _new((b, 1024), x)
+    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True, math=MATH_F32)
+    c0 = plan.corr0
+    gb = _new((b, 1024), x)
+    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072, math=MATH_F32)
+    h1 = _newb((M, 1024), x)
+    gemm(x4, c0.wb(), h1, M, 1024, 2048, ldw=3072, gbias=gb, rows_per_group=t * PIX,
+         scale=c0.scale, shift=c0.shift, relu=False, math=MATH_BF16S)
+    c2 = plan.corr2
+    h2 = _newb((M, 256), x)
+    gemm(h1, c2.wb(), h2, M, 256, 1024, scale=c2.scale, shift=c2.shift, relu=True, math=MATH_BF16S)
+    cmap = _new((M,), x)
+    xc, xu = _newb((M, 2048), x), _newb((M, 2048), x)
+    _call('grl_gce_gate_bf16', ptr(h2), ptr(plan.corr5_w), ptr(plan.corr6_scale), ptr(plan.corr6_shift),
+          ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 256, 2048)
+    del x4, h1, h2
+    if taps is not None:
+        taps['corr_map'] = cmap.view(b * t, 1, 16, 8)
+    # TRL
+    Cc, frame, Mb = 2048, PIX * 2048, b * PIX
+    memo0 = _newb((Mb, Cc), x)
+    _call('grl_temporal_mean_bf16', ptr(xu), ptr(memo0), b, t, frame)
+    gapc = _new((b * t, Cc), x)
+    _call('grl_group_mean_bf16', ptr(xc), ptr(gapc), b * t, PIX, Cc, Cc, C.c_float(1.0), 0)
+    f2 = []
+    for d in plan.dirs:
+        y = _newb((b * t * PIX, Cc), x)
+        gemm(xc, d['f2'].wb(), y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True, math=MATH_BF16S)
+        f2.append(y)
+    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device)
+    memo = [memo0, memo0]
+    dvec, hid = _new((b, Cc), x), _new((b, 128), x)
+    for i in range(t):
+        for di, d in enumerate(plan.dirs):
+            ti = i if di == 0 else t - 1 - i
+            f1 = _newb((Mb, Cc), x)
+            gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
+            _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+            _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
+                  None, ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+            s_ = _newb((Mb, Cc), x)
+            _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
+            c1, c2_, c3 = d['c1'], d['c2'], d['c3']
+            o = _newb((Mb, 512), x)
+            gemm(s_, c1.wb(), o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True, math=MATH_BF16S)
+            o2 = _newb((Mb, 512), x)
+            gemm(o, c2_.wb(), o2, Mb, 512, 512, scale=c2_.scale, shift=c2_.shift, relu=True, math=MATH_BF16S)
+            nm = _newb((Mb, Cc), x)
+            gemm(o2, c3.wb(), nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s_, relu=True, math=MATH_BF16S)
+            memo[di] = nm
+    f_uncorr = _new((b, Cc), x)
+    _call('grl_group_mean_bf16', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
+    _call('grl_group_mean_bf16', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
+    if taps is not None:
+        taps['f_uncorr'], taps['f_corr'] = f_uncorr, fcorr
+    x_corr = _new((b, t, 2048), inputs)
+    _call('grl_affine_l2norm', ptr(fcorr), ptr(plan.corr_bn[0]), ptr(plan.corr_bn[1]), ptr(x_corr),
           b * t, 2048, 2048)
     x_uncorr = out_uncorr if out_uncorr is not None else _new((b, 2048), inputs)
     _call('grl_affine_l2norm', ptr(f_uncorr), ptr(plan.uncorr_bn[0]), ptr(plan.uncorr_bn[1]),

@@ -165,6 +165,26 @@ int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int32_t* idx, v
 int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bf16-STORAGE pipeline (BASELINE configs[2]; engine math mode 'bf16s', GRL_MATH_BF16S):
+ * bf16 twins of the bandwidth-bound kernels above -- activations are bf16 arrays (void*),
+ * per-channel / per-clip vectors and all reductions stay fp32.  Same reference call sites.
+ * ---------------------------------------------------------------------------------- */
+int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream);            /* n % 8 == 0 */
+int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                          void* y, int n, int H, int W, int relu, void* stream);
+int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream);
+int grl_group_mean_bf16(const void* x, float* y, int groups, int rows, int C, int ldy,
+                        float out_scale, int accumulate, void* stream);
+int grl_sqdiff_mean_bf16(const void* f1, const void* f2, float* d, int b, int rows, int C,
+                         int64_t f2_clip_stride, void* stream);
+int grl_gce_gate_bf16(const void* h, const float* w3, const float* bn_scale, const float* bn_shift,
+                      const void* x, float* corr_map, void* x_corr, void* x_uncorr, int M, int Ch,
+                      int C, void* stream);
+int grl_temporal_mean_bf16(const void* x, void* y, int b, int T, int64_t inner, void* stream);
+int grl_add_strided_bf16(const void* a, const void* b, void* y, int nb, int64_t inner,
+                         int64_t b_clip_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Train mode: batch-statistics BatchNorm and the backward pass (autograd of the modules
  * above, driven by reid/train/trainer.py:54 `loss.backward()`).
  * ---------------------------------------------------------------------------------- */

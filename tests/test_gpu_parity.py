@@ -268,7 +268,7 @@ def test_trainer_steps_run_on_hip():
     assert bool(torch.isfinite(feat).all())
 
 
-@pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16', 5e-2), ('bf16s', 1e-1)])
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16', 5e-2), ('bf16s', 2e-2)])
 def test_eval_forward_alternative_math_modes(golden, gpu_models, mode, tol):
     """The opt-in bf16 datapaths against the reference golden: split-bf16 stays inside the
     north star's 1e-3 fp32 parity budget; plain bf16 (BASELINE configs[2]) gets its own
@@ -375,7 +375,7 @@ def test_baseline_config2_bf16_T8_B64(gpu_models):
     ref = O.extract_features(sd, ssd, clips[30:32].cpu())
     err = _rel(small.cpu().numpy(), ref.numpy())
     print('configs[2] bf16 T=8: rel err vs fp32 oracle %.2e' % err)
-    assert err < 1e-1
+    assert err < 3e-2
 
 
 def test_baseline_config4_full_mars_rank1_map():

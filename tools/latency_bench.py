@@ -9,6 +9,9 @@ from grl_amd.synthetic import synth_clips
 dev = torch.device('cuda:0')
 cnn, siam, _, _ = build_models(dev)
 gx = engine.GraphedExtractor(cnn, siam)
+import sys as _s
+if len(_s.argv) > 1:
+    engine.set_math(_s.argv[1])
 for b in (1, 8, 32):
     clips = synth_clips(b, 4, seed=b).to(dev)
     for fn, name in ((lambda: engine.extract_features(cnn, siam, clips), 'eager'), (lambda: gx(clips), 'graph')):

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B, T = 32, 4
-GFLOP_PER_CLIP = 57.94 + 0.017          # conv+linear fwd at T=4, + Siamese Q/K
+GFLOP_PER_FRAME = 14.485                # conv+linear forward, per frame (57.94 per clip at T=4)
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -216,11 +216,15 @@ def main():
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16s'],
                     help="multiplier datapath of the conv GEMMs for the headline `value` "
                          "(default: exact fp32 MFMA = BASELINE configs[1])")
-    ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 measurements')
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 / bf16s measurements')
+    ap.add_argument('--clips', type=int, default=B, help='clips per GPU per step (default 32 = BASELINE configs[1]; '
+                                                         'configs[2] is --clips 64 --seq-len 8 --math bf16s)')
+    ap.add_argument('--seq-len', type=int, default=T, help='frames per clip (default 4)')
     ap.add_argument('--mode', default='eval', choices=['eval', 'train', 'distmat'],
                     help="eval (default): the headline clip-features/sec; train: secondary series, one "
                          "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
     args = ap.parse_args()
+    globals()['B'], globals()['T'] = args.clips, args.seq_len
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -279,6 +283,9 @@ def main():
         value = n * B * args.steps / dt
         flops, gemm_ms, launches = gemm_roofline(cnn, siam, clips)
         achieved = flops / (gemm_ms * 1e-3) / 1e12
+        # dense MFMA peak of the datapath (MI355X_MICROARCH.md): fp32 157.3, bf16 2500; bf16x3
+        # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
+        peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_gemm_pmc.json')
         if os.path.isfile(pmc):
@@ -287,17 +294,23 @@ def main():
             "metric": "clip-features/sec", "value": round(value, 2), "unit": "clip-features/sec",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split operands, f32 accumulate)",
+                      "bf16": "bf16 operands, f32 accumulate", "bf16s": "bf16 storage, f32 accumulate"}[args.math],
+            "data": "synthetic",
             "config": {"workload": "GRL eval clip features (ResNet-50 s1 trunk + GCE + TRL + "
-                                   "Siamese attention -> 6144-d), BASELINE configs[1]",
+                                   "Siamese attention -> 6144-d), BASELINE configs[%s]" % (
+                                       '1' if (B, T, args.math) == (32, 4, 'f32') else
+                                       '2' if (B, T) == (64, 8) and args.math in ('bf16', 'bf16s') else '1 (variant)'),
                        "clips_per_gpu": B, "seq_len": T, "frame": "256x128",
                        "parallelism": "replicas x%d (no collective)" % n},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "gemm_f32_kernel (fp32 MFMA implicit-GEMM conv), %d launches/step, "
-                                   "%.3f ms/step, %.1f algorithmic GFLOP/step" % (launches, gemm_ms, flops / 1e9)},
-            "end_to_end_tflops": round(value / n * GFLOP_PER_CLIP / 1e3, 2),
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic if args.math == 'f32' else None,
+                         "kernel": "gemm_f32_kernel (%s MFMA implicit-GEMM conv), %d launches/step, "
+                                   "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
+                                       'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
+            "end_to_end_tflops": round(value / n * GFLOP_PER_FRAME * T / 1e3, 2),
         }
         out["config"]["math"] = args.math
         if n == 1 and not args.no_alt:

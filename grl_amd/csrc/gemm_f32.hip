@@ -302,6 +302,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                 for (int r = 0; r < 16; ++r)
                     Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + wn * WTN +
                        j * 32 + col_l] = acc[i][j][r];
+        if constexpr (MATH == 2) {
+            // bf16 output: 8 channels (16 bytes) per lane; N % 8 == 0 is validated on the host
+            if (p.N % 8 == 0 && !p.out_f32 && !p.rowscale) {
+                constexpr int LPR8 = WTN / 8, RPI8 = 64 / LPR8;
+                const int lrow = lane / LPR8, lcol = (lane % LPR8) * 8;
+                const int n = n0 + wn * WTN + lcol;
+                if (n < p.N) {
+                    f32x4 sc[2], sh[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        sc[u] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + 4 * u) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        sh[u] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll 4
+                    for (int it = 0; it < WTM / RPI8; ++it) {
+                        const int row = wm * WTM + it * RPI8 + lrow;
+                        const int m = m0 + row;
+                        if (m >= p.M) continue;
+                        f32x4 v[2];
+                        bf16x8 r8;
+                        if (p.res) r8 = *reinterpret_cast<const bf16x8*>(
+                                       reinterpret_cast<const __bf16*>(p.res) + (int64_t)m * p.ldres + n);
+                        bf16x8 o;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            v[u] = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol + 4 * u);
+                            if (p.gbias)
+                                v[u] += *reinterpret_cast<const f32x4*>(
+                                    p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n + 4 * u);
+                            v[u] = v[u] * sc[u] + sh[u];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = v[u][e] + (p.res ? (float)r8[4 * u + e] : 0.f);
+                                if (p.relu) t = t > 0.f ? t : 0.f;
+                                o[4 * u + e] = (__bf16)t;
+                            }
+                        }
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + n) = o;
+                    }
+                }
+                return;
+            }
+        }
         constexpr int LPR = WTN / 4;                        // lanes per row
         constexpr int RPI = 64 / LPR;                       // rows per pass
         const int lrow = lane / LPR, lcol = (lane % LPR) * 4;

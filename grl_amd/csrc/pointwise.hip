@@ -616,17 +616,6 @@ extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* sca
     return grl_check_launch("grl_stem_conv7x7");
 }
 
-extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                                     void* y, int n, int H, int W, int relu, void* stream) {
-    GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem_bf16: null/empty");
-    GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem_bf16: H and W must be even");
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t lds = (size_t)(64 * SM_WLD + SM_KOFF + SM_K) * sizeof(float);
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3(grl_ceil_div(Wo, SM_TW), grl_ceil_div(Ho, SM_TH), n), dim3(256), lds,
-                       (hipStream_t)stream, x, w, scale, shift, reinterpret_cast<float*>(y), H, W, relu, 1);
-    return grl_check_launch("grl_stem_conv7x7_bf16");
-}
-
 extern "C" int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream) {
     GRL_REQUIRE(x && y && n > 0 && C % 4 == 0, "maxpool: bad args");
     const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);

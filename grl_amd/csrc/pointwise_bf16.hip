@@ -172,6 +172,108 @@ __global__ void add_strided_b16_kernel(const __bf16* __restrict__ a, const __bf1
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Stem for the bf16-storage pipeline: 7x7/s2 conv (K = 147 -> 160) + folded BN + ReLU on the
+// bf16 MFMA.  One workgroup = 8 x 16 output pixels x 64 channels.  The fp32 NCHW patch
+// (3 x 21 x 37) is staged in LDS, expanded in LDS to a bf16 im2col tile [128 px][160 k] and
+// multiplied with the bf16 weight matrix [64][160]; rows are padded to 336 bytes so that the
+// ds_read_b128 fragment reads (16 consecutive rows, same k chunk) hit 16 distinct bank slots.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SB_TH = 8, SB_TW = 16, SB_PH = 2 * SB_TH + 5, SB_PW = 2 * SB_TW + 5, SB_PWP = SB_PW + 1;
+constexpr int SB_K = 160, SB_ROWB = 336;                       // bytes per bf16 row (320 + 16 pad)
+constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // fp32 cells; SB_PATCH.. are zeros
+
+__global__ __launch_bounds__(256) void stem_b16_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+    const float* __restrict__ shift, __bf16* __restrict__ y, int H, int W, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    char* At = smb;                                            // [128][336 B]
+    char* Wt = At + 128 * SB_ROWB;                             // [64][336 B]
+    float* patch = reinterpret_cast<float*>(Wt + 64 * SB_ROWB);   // [3][21][38] + 4 zeros
+    float* Cs = reinterpret_cast<float*>(smb);                 // epilogue staging [128][64] fp32 (32 KB < At)
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int img = blockIdx.z, oy0 = blockIdx.y * SB_TH, ox0 = blockIdx.x * SB_TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    for (int i = tid; i < 3 * SB_PH * SB_PW; i += 256) {
+        const int c = i / (SB_PH * SB_PW), r = (i / SB_PW) % SB_PH, q = i % SB_PW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xi[((int64_t)c * H + iy) * W + ix];
+        patch[(c * SB_PH + r) * SB_PWP + q] = v;
+    }
+    if (tid < 4) patch[SB_PATCH + tid] = 0.f;
+    // weights: [64][147] fp32 -> bf16 rows of 160 (zero padded)
+    for (int i = tid; i < 64 * (SB_K / 8); i += 256) {
+        const int n = i / (SB_K / 8), c8 = i - n * (SB_K / 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = c8 * 8 + e;
+            o[e] = (__bf16)(k < 147 ? w[n * 147 + k] : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(Wt + n * SB_ROWB + c8 * 16) = o;
+    }
+    __syncthreads();
+    // im2col in LDS: item = (pixel, 8-wide k chunk)
+    for (int i = tid; i < 128 * (SB_K / 8); i += 256) {
+        const int m = i / (SB_K / 8), c8 = i - m * (SB_K / 8);
+        const int base = (2 * (m / SB_TW)) * SB_PWP + 2 * (m % SB_TW);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = c8 * 8 + e;
+            const int off = k < 147 ? base + ((k / 49) * SB_PH + (k / 7) % 7) * SB_PWP + k % 7 : SB_PATCH;
+            o[e] = (__bf16)patch[off];
+        }
+        *reinterpret_cast<bf16x8*>(At + m * SB_ROWB + c8 * 16) = o;
+    }
+    __syncthreads();
+    const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, fhalf = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SB_K / 16; ++s) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Wt + (wn * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                           // At is dead: reuse as fp32 C staging
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * 64 + wn * 32 + col_l] = acc[i][r];
+    __syncthreads();
+    // 128 pixels x 64 channels: 8 lanes x 8 channels per pixel row, 32 rows per pass
+    const int c8 = (tid & 7) * 8;
+    f32x8 sc, sh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[c8 + e]; sh[e] = shift[c8 + e]; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = it * 32 + (tid >> 3);
+        const int oy = oy0 + m / SB_TW, ox = ox0 + m % SB_TW;
+        if (oy < Ho && ox < Wo) {
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = Cs[m * 64 + c8 + e] * sc[e] + sh[e];
+                v[e] = (t > 0.f || !relu) ? t : 0.f;
+            }
+            st8(y + (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c8, v);
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -187,6 +289,19 @@ extern "C" int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
     GRL_REQUIRE(x && y && n > 0 && n % 8 == 0, "cast_bf16: n % 8");
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, B16(y), n / 8);
     return grl_check_launch("grl_cast_bf16");
+}
+
+extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                                     void* y, int n, int H, int W, int relu, void* stream) {
+    GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem_bf16: null/empty");
+    GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem_bf16: H and W must be even");
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)(SB_PATCH + 4) * sizeof(float);
+    if (lds > 65536)
+        (void)hipFuncSetAttribute((const void*)stem_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH), n), dim3(256), lds,
+                       (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu);
+    return grl_check_launch("grl_stem_conv7x7_bf16");
 }
 
 extern "C" int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream) {

@@ -42,7 +42,9 @@ _SIGNATURES = {
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
     'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),
-    'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_stem_pack_weight': ([_fp, _fp, _fp], C.c_int),
+    'grl_stem_pack_weight_bf16': ([_fp, _fp, _fp], C.c_int),
     'grl_maxpool3x3s2': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_group_mean': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp], C.c_int),
     'grl_gce_gate': ([_fp] * 8 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
@@ -85,7 +87,7 @@ _SIGNATURES = {
     'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
     'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_cast_bf16': ([_fp, _fp, _i64, _fp], C.c_int),
-    'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_maxpool3x3s2_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_group_mean_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp], C.c_int),
     'grl_sqdiff_mean_bf16': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),

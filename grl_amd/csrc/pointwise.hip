@@ -116,7 +116,8 @@ constexpr int SM_KOFF = (SM_PATCH + 4 + 3) / 4 * 4;  // offset of the k -> patch
 
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu, int out_bf16) {
+    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu, int out_bf16,
+    const float* __restrict__ wp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ws = sm;                                   // [64][164]
     float* patch = Ws + 64 * SM_WLD;                  // [3][21][38] + zero cell (+pad)
@@ -125,9 +126,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int Ho = H >> 1, Wo = W >> 1;
     const int img = blockIdx.z, oy0 = blockIdx.y * SM_TH, ox0 = blockIdx.x * SM_TW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 64 * SM_K; i += 256) {
-        const int n = i / SM_K, k = i - n * SM_K;
-        Ws[n * SM_WLD + k] = k < 147 ? w[n * 147 + k] : 0.f;
+    if (wp) {                                          // LDS image made once by grl_stem_pack_weight
+        for (int i = tid; i < 64 * SM_WLD / 4; i += 256)
+            reinterpret_cast<f32x4*>(Ws)[i] = reinterpret_cast<const f32x4*>(wp)[i];
+    } else {
+        for (int i = tid; i < 64 * SM_K; i += 256) {
+            const int n = i / SM_K, k = i - n * SM_K;
+            Ws[n * SM_WLD + k] = k < 147 ? w[n * 147 + k] : 0.f;
+        }
     }
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
@@ -599,8 +605,22 @@ extern "C" int grl_bn_fold(const float* gamma, const float* beta, const float* m
     return grl_check_launch("grl_bn_fold");
 }
 
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // [64][SM_WLD]
+    if (i >= 64 * SM_WLD) return;
+    const int n = i / SM_WLD, k = i - n * SM_WLD;
+    wp[i] = k < 147 ? w[n * 147 + k] : 0.f;
+}
+
+extern "C" int grl_stem_pack_weight(const float* w, float* wp, void* stream) {
+    GRL_REQUIRE(w && wp, "stem_pack_weight: null");
+    hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(grl_ceil_div(64 * SM_WLD, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wp);
+    return grl_check_launch("grl_stem_pack_weight");
+}
+
 extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* scale, const float* shift,
-                                float* y, int n, int H, int W, int relu, void* stream) {
+                                float* y, int n, int H, int W, int relu, const float* wp, void* stream) {
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
@@ -611,7 +631,7 @@ extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* sca
     } else {
         const size_t lds = (size_t)(64 * SM_WLD + SM_KOFF + SM_K) * sizeof(float);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(grl_ceil_div(Wo, SM_TW), grl_ceil_div(Ho, SM_TH), n), dim3(256), lds,
-                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, 0);
+                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, 0, wp);
     }
     return grl_check_launch("grl_stem_conv7x7");
 }

@@ -185,7 +185,8 @@ constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // fp32 cells; SB
 
 __global__ __launch_bounds__(256) void stem_b16_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-    const float* __restrict__ shift, __bf16* __restrict__ y, int H, int W, int relu) {
+    const float* __restrict__ shift, __bf16* __restrict__ y, int H, int W, int relu,
+    const __bf16* __restrict__ wp) {
     extern __shared__ __attribute__((aligned(16))) char smb[];
     char* At = smb;                                            // [128][336 B]
     char* Wt = At + 128 * SB_ROWB;                             // [64][336 B]
@@ -204,7 +205,11 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
         patch[(c * SB_PH + r) * SB_PWP + q] = v;
     }
     if (tid < 4) patch[SB_PATCH + tid] = 0.f;
-    // weights: [64][147] fp32 -> bf16 rows of 160 (zero padded)
+    // weights: the LDS image [64][336 B] made once by grl_stem_pack_weight_bf16, or converted here
+    if (wp) {
+        for (int i = tid; i < 64 * SB_ROWB / 16; i += 256)
+            reinterpret_cast<bf16x8*>(Wt)[i] = reinterpret_cast<const bf16x8*>(wp)[i];
+    } else
     for (int i = tid; i < 64 * (SB_K / 8); i += 256) {
         const int n = i / (SB_K / 8), c8 = i - n * (SB_K / 8);
         bf16x8 o;
@@ -291,8 +296,22 @@ extern "C" int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
     return grl_check_launch("grl_cast_bf16");
 }
 
+__global__ void stem_pack_weight_b16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // [64][168] bf16 (336-byte rows)
+    if (i >= 64 * (SB_ROWB / 2)) return;
+    const int n = i / (SB_ROWB / 2), k = i - n * (SB_ROWB / 2);
+    wp[i] = (__bf16)(k < 147 ? w[n * 147 + k] : 0.f);
+}
+
+extern "C" int grl_stem_pack_weight_bf16(const float* w, void* wp, void* stream) {
+    GRL_REQUIRE(w && wp, "stem_pack_weight_bf16: null");
+    hipLaunchKernelGGL(stem_pack_weight_b16_kernel, dim3(grl_ceil_div(64 * (SB_ROWB / 2), 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, B16(wp));
+    return grl_check_launch("grl_stem_pack_weight_bf16");
+}
+
 extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                                     void* y, int n, int H, int W, int relu, void* stream) {
+                                     void* y, int n, int H, int W, int relu, const void* wp, void* stream) {
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem_bf16: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem_bf16: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
@@ -300,7 +319,7 @@ extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)stem_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH), n), dim3(256), lds,
-                       (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu);
+                       (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu, CB16(wp));
     return grl_check_launch("grl_stem_conv7x7_bf16");
 }
 

@@ -185,6 +185,10 @@ class GrlEvalPlan(EvalPlan):
         bb = model.backbone
         base = bb.base
         self.stem_w = base[0].weight.detach().contiguous()
+        self.stem_wp = torch.empty(64 * 164, dtype=torch.float32, device=self.dev)
+        _call('grl_stem_pack_weight', ptr(self.stem_w), ptr(self.stem_wp))
+        self.stem_wpb = torch.empty(64 * 168, dtype=torch.bfloat16, device=self.dev)
+        _call('grl_stem_pack_weight_bf16', ptr(self.stem_w), ptr(self.stem_wpb))
         self.stem_scale, self.stem_shift = self.fold(base[1])
         self.blocks = []
         for li in (4, 5, 6, 7):
@@ -274,7 +278,7 @@ def trunk_eval(plan, x, taps=None):
     Hs, Ws = H // 2, W // 2
     stem = _new((n * Hs * Ws, 64), x)
     _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-          ptr(stem), n, H, W, 1)
+          ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
     _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)
@@ -438,7 +442,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     Hs, Ws = h // 2, w // 2
     stem = _newb((n * Hs * Ws, 64), x)
     _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-          ptr(stem), n, h, w, 1)
+          ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
     H, W = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _newb((n * H * W, 64), x)
     _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)

@@ -375,7 +375,7 @@ def trunk_train(tp, model, x):
     ones, zeros = torch.ones(64, device=tp.dev), torch.zeros(64, device=tp.dev)
     z0 = _new((M0, 64), x)
     w0 = conv1.weight.detach().contiguous()
-    _call('grl_stem_conv7x7', ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0)
+    _call('grl_stem_conv7x7', ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0, None)
     rows = _lib.load().grl_col_stats_rows(M0)
     slab = _new((rows, 2, 64), x)
     _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64)

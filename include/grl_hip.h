@@ -103,7 +103,12 @@ int grl_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 /* Stem: 7x7 stride-2 pad-3 conv on NCHW input [n][3][H][W], y = relu?(conv*scale+shift) ->
  * channels-last [n][H/2][W/2][64]   (resnets1.py:101-103 / basebranch.py:28-30). */
 int grl_stem_conv7x7(const float* x, const float* w /*[64][3][7][7]*/, const float* scale,
-                     const float* shift, float* y, int n, int H, int W, int relu, void* stream);
+                     const float* shift, float* y, int n, int H, int W, int relu,
+                     const float* wp /* optional: [64][164] image from grl_stem_pack_weight */,
+                     void* stream);
+/* the stem's LDS weight image (K padded 147 -> 160, rows padded to 164 floats), made once per
+ * weight version so that every workgroup copies it with 16-byte loads */
+int grl_stem_pack_weight(const float* w, float* wp /* 64*164 floats */, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool, channels-last (resnets1.py:104). */
 int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream);
@@ -171,7 +176,9 @@ int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* st
  * ---------------------------------------------------------------------------------- */
 int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream);            /* n % 8 == 0 */
 int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                          void* y, int n, int H, int W, int relu, void* stream);
+                          void* y, int n, int H, int W, int relu,
+                          const void* wp /* optional: image from grl_stem_pack_weight_bf16 */, void* stream);
+int grl_stem_pack_weight_bf16(const float* w, void* wp /* 64*168 bf16 */, void* stream);
 int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream);
 int grl_group_mean_bf16(const void* x, float* y, int groups, int rows, int C, int ldy,
                         float out_scale, int accumulate, void* stream);

@@ -120,7 +120,7 @@ def test_stem_and_maxpool_vs_torch(dev):
     ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     y = torch.empty(n * (H // 2) * (W // 2), 64, device=dev)
     xd, wd, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)     # keep alive across the launch
-    engine._call('grl_stem_conv7x7', ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(y), n, H, W, 1)
+    engine._call('grl_stem_conv7x7', ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(y), n, H, W, 1, None)
     got = y.view(n, H // 2, W // 2, 64).permute(0, 3, 1, 2).cpu()
     assert _rel(got.numpy(), ref.numpy()) < 1e-5
     pooled = torch.empty(n * (H // 4) * (W // 4), 64, device=dev)

@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(
 }
 
 
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------
 // Stem as an implicit GEMM on the fp32 MFMA: one workgroup = 8 x 16 output pixels (M = 128)
 // x 64 channels, K = 3*7*7 = 147 padded to 160.  The input patch (3 x 21 x 37) and the
@@ -116,7 +115,7 @@ constexpr int SM_KOFF = (SM_PATCH + 4 + 3) / 4 * 4;  // offset of the k -> patch
 
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu, int out_bf16,
+    const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu,
     const float* __restrict__ wp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ws = sm;                                   // [64][164]
@@ -201,15 +200,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
-            const int64_t o = (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c4;
-            if (out_bf16) {
-                bf16x4_t b;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(y) + o) = b;
-            } else {
-                *reinterpret_cast<f32x4*>(y + o) = v;
-            }
+            *reinterpret_cast<f32x4*>(y + (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c4) = v;
         }
     }
 }
@@ -631,7 +622,7 @@ extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* sca
     } else {
         const size_t lds = (size_t)(64 * SM_WLD + SM_KOFF + SM_K) * sizeof(float);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(grl_ceil_div(Wo, SM_TW), grl_ceil_div(Ho, SM_TH), n), dim3(256), lds,
-                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, 0, wp);
+                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, wp);
     }
     return grl_check_launch("grl_stem_conv7x7");
 }

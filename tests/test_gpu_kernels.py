@@ -302,3 +302,70 @@ def test_gemm_bf16_storage(dev, M, N, K, conv):
     engine.gemm(ad.float(), wd.float(), ref, M, N, K, scale=scd, shift=shd, res=rd.float(), relu=True, conv=conv, math=0)
     assert _rel(y32.cpu().numpy(), ref.cpu().numpy()) < 2e-6            # same products, fp32 accumulate
     assert torch.equal(y, y32.bfloat16())                               # one rounding on the store
+
+
+def test_bf16_storage_pointwise_twins(dev):
+    """bf16-storage twins of the bandwidth-bound kernels against their fp32 twins on
+    bf16-representable data: identical fp32 results for the reductions, one rounding on bf16
+    outputs."""
+    from grl_amd import engine
+    from grl_amd._lib import ptr
+    rng = np.random.default_rng(31)
+    tb = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).bfloat16().to(dev)
+    # max pool (exact)
+    n, H, W, Cc = 2, 12, 10, 64
+    x = tb(n * H * W, Cc)
+    y16 = torch.empty(n * 6 * 5, Cc, dtype=torch.bfloat16, device=dev)
+    y32 = torch.empty(n * 6 * 5, Cc, device=dev)
+    xf = x.float()
+    engine._call('grl_maxpool3x3s2_bf16', ptr(x), ptr(y16), n, H, W, Cc)
+    engine._call('grl_maxpool3x3s2', ptr(xf), ptr(y32), n, H, W, Cc)
+    assert torch.equal(y16.float(), y32)
+    # group mean / sqdiff mean (fp32 outputs)
+    b, T, P, C2 = 3, 2, 128, 2048
+    a = tb(b, T, P, C2); af = a.float()
+    g16, g32 = torch.zeros(b * T, C2, device=dev), torch.zeros(b * T, C2, device=dev)
+    engine._call('grl_group_mean_bf16', ptr(a), ptr(g16), b * T, P, C2, C2, C.c_float(1.0), 0)
+    engine._call('grl_group_mean', ptr(af), ptr(g32), b * T, P, C2, C2, C.c_float(1.0), 0)
+    assert _rel(g16.cpu().numpy(), g32.cpu().numpy()) < 1e-5
+    f1 = tb(b, P, C2); f1f = f1.float()
+    d16, d32 = torch.empty(b, C2, device=dev), torch.empty(b, C2, device=dev)
+    engine._call('grl_sqdiff_mean_bf16', ptr(f1), ptr(a.view(-1)[P * C2:]), ptr(d16), b, P, C2, T * P * C2)
+    engine._call('grl_sqdiff_mean', ptr(f1f), ptr(af.view(-1)[P * C2:]), ptr(d32), b, P, C2, T * P * C2)
+    assert _rel(d16.cpu().numpy(), d32.cpu().numpy()) < 1e-5
+    # temporal mean / add_strided (bf16 outputs = rounded fp32 results)
+    tm16 = torch.empty(b, P * C2, dtype=torch.bfloat16, device=dev); tm32 = torch.empty(b, P * C2, device=dev)
+    engine._call('grl_temporal_mean_bf16', ptr(a), ptr(tm16), b, T, P * C2)
+    engine._call('grl_temporal_mean', ptr(af), ptr(tm32), b, T, P * C2)
+    assert torch.equal(tm16, tm32.bfloat16())
+    s16 = torch.empty(b, P * C2, dtype=torch.bfloat16, device=dev); s32 = torch.empty(b, P * C2, device=dev)
+    engine._call('grl_add_strided_bf16', ptr(f1), ptr(a.view(-1)[P * C2:]), ptr(s16), b, P * C2, T * P * C2)
+    engine._call('grl_add_strided', ptr(f1f), ptr(af.view(-1)[P * C2:]), ptr(s32), b, P * C2, T * P * C2)
+    assert torch.equal(s16, s32.bfloat16())
+    # gate
+    M = 37
+    h, xx = tb(M, 256), tb(M, C2)
+    w3 = torch.from_numpy((rng.standard_normal(256) * 0.1).astype(np.float32)).to(dev)
+    bs, bh = torch.tensor([0.8], device=dev), torch.tensor([-0.1], device=dev)
+    cm16, cm32 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    xc16, xu16 = torch.empty(M, C2, dtype=torch.bfloat16, device=dev), torch.empty(M, C2, dtype=torch.bfloat16, device=dev)
+    xc32, xu32 = torch.empty(M, C2, device=dev), torch.empty(M, C2, device=dev)
+    hf, xxf = h.float(), xx.float()
+    engine._call('grl_gce_gate_bf16', ptr(h), ptr(w3), ptr(bs), ptr(bh), ptr(xx), ptr(cm16), ptr(xc16), ptr(xu16), M, 256, C2)
+    engine._call('grl_gce_gate', ptr(hf), ptr(w3), ptr(bs), ptr(bh), ptr(xxf), ptr(cm32), ptr(xc32), ptr(xu32), M, 256, C2)
+    assert _rel(cm16.cpu().numpy(), cm32.cpu().numpy()) < 1e-5
+    assert _rel(xc16.float().cpu().numpy(), xc32.cpu().numpy()) < 8e-3 and _rel(xu16.float().cpu().numpy(), xu32.cpu().numpy()) < 8e-3
+    # stem (bf16 MFMA) vs the fp32 stem on bf16-representable pixels/weights
+    n, H, W = 2, 64, 32
+    xi = torch.from_numpy(rng.standard_normal((n, 3, H, W)).astype(np.float32)).bfloat16().float().to(dev)
+    ws = torch.from_numpy((rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)).bfloat16().float().to(dev)
+    sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev) * 0.1
+    o32 = torch.empty(n * 32 * 16, 64, device=dev); o16 = torch.empty(n * 32 * 16, 64, dtype=torch.bfloat16, device=dev)
+    wpb = torch.empty(64 * 168, dtype=torch.bfloat16, device=dev)
+    engine._call('grl_stem_pack_weight_bf16', ptr(ws), ptr(wpb))
+    engine._call('grl_stem_conv7x7', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o32), n, H, W, 1, None)
+    engine._call('grl_stem_conv7x7_bf16', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o16), n, H, W, 1, ptr(wpb))
+    assert _rel(o16.float().cpu().numpy(), o32.cpu().numpy()) < 8e-3
+    o16b = torch.empty_like(o16)
+    engine._call('grl_stem_conv7x7_bf16', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o16b), n, H, W, 1, None)
+    assert torch.equal(o16, o16b)                     # packed image == in-kernel conversion

@@ -85,6 +85,19 @@ _SIGNATURES = {
     'grl_pair_sqdiff': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_pair_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
+    'grl_softmax_ce': ([_fp, _i64, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _i64, _fp, _fp], C.c_int),
+    'grl_oim_grad': ([_fp, _i64, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_triplet_fwd': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_triplet_bwd': ([_fp] * 5 + [C.c_int, C.c_float, _fp, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_softmax2': ([_fp, _fp, _fp, _i64, _fp], C.c_int),
+    'grl_softmax2_bwd': ([_fp, _fp, _fp, _fp, _i64, _fp], C.c_int),
+    'grl_normalize_u8': ([_fp, _fp, _fp, C.c_int, _i64, _fp], C.c_int),
+    'grl_stem_conv7x7_u8': ([_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_stem_conv7x7_u8_bf16': ([_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
+                                 C.c_int),
+    'grl_pair_bce': ([_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_scale_dev': ([_fp, _fp, C.c_float, _fp, _i64, _fp], C.c_int),
+    'grl_rank_metrics': ([_fp, _i64, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
     'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_cast_bf16': ([_fp, _fp, _i64, _fp], C.c_int),
     'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
@@ -147,10 +160,10 @@ def check(rc, what=''):
         raise GrlHipError('%s failed (%d): %s' % (what, rc, msg))
 
 
-def require_device(t, what='input'):
+def require_device(t, what='input', allow_u8=False):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise GrlHipError(
             '%s must live on a HIP device (got %s): grl_amd executes on MI355X only and '
             'has no CPU path' % (what, getattr(t, 'device', type(t))))
-    if t.dtype != torch.float32:
-        raise GrlHipError('%s must be float32 (got %s)' % (what, t.dtype))
+    if t.dtype != torch.float32 and not (allow_u8 and t.dtype == torch.uint8):
+        raise GrlHipError('%s must be float32%s (got %s)' % (what, ' or raw uint8' if allow_u8 else '', t.dtype))

@@ -116,7 +116,9 @@ constexpr int SM_KOFF = (SM_PATCH + 4 + 3) / 4 * 4;  // offset of the k -> patch
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ y, int H, int W, int relu,
-    const float* __restrict__ wp) {
+    const float* __restrict__ wp, const float* __restrict__ norm) {
+    // norm != NULL: x holds raw u8 pixels, normalised while the patch is staged:
+    // (u/255 - mean[c]) / std[c], the same fp32 operations as ToTensor + Normalize.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ws = sm;                                   // [64][164]
     float* patch = Ws + 64 * SM_WLD;                  // [3][21][38] + zero cell (+pad)
@@ -136,11 +138,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     }
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
     for (int i = tid; i < 3 * SM_PH * SM_PW; i += 256) {
         const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
         const int iy = iy0 + r, ix = ix0 + q;
         float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xi[((int64_t)c * H + iy) * W + ix];
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const int64_t o = ((int64_t)c * H + iy) * W + ix;
+            v = norm ? ((float)xu[o] / 255.f - norm[c]) / norm[3 + c] : xi[o];
+        }
         patch[(c * SM_PH + r) * SM_PWP + q] = v;
     }
     if (tid < 8) patch[SM_PATCH + (tid & 3)] = 0.f;
@@ -579,7 +585,29 @@ inline int grid_for(int64_t n, int block = 256) {
 
 }  // namespace
 
+namespace {
+// y = (u/255 - mean[c]) / std[c] over [n][3][plane] (ToTensor + Normalize, seqtransforms.py:190,212-213)
+__global__ void normalize_u8_kernel(const uint8_t* __restrict__ x, const float* __restrict__ norm,
+                                    float* __restrict__ y, int64_t plane, int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((t / plane) % 3);
+        y[t] = ((float)x[t] / 255.f - norm[c]) / norm[3 + c];
+    }
+}
+}  // namespace
+
 #define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_normalize_u8(const uint8_t* x, const float* mean_std, float* y, int n, int64_t plane,
+                                void* stream) {
+    GRL_REQUIRE(x && mean_std && y && n > 0 && plane > 0, "normalize_u8: bad args");
+    const int64_t total = (int64_t)n * 3 * plane;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, mean_std, y, plane,
+                       total);
+    return grl_check_launch("grl_normalize_u8");
+}
 
 extern "C" int grl_pack_conv_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream) {
     GRL_REQUIRE(w && out && N > 0 && C > 0 && kh > 0 && kw > 0, "pack_conv_weight: bad args");
@@ -610,19 +638,34 @@ extern "C" int grl_stem_pack_weight(const float* w, float* wp, void* stream) {
     return grl_check_launch("grl_stem_pack_weight");
 }
 
+static int stem_launch(const float* x, const float* norm, const float* w, const float* scale, const float* shift,
+                       float* y, int n, int H, int W, int relu, const float* wp, void* stream);
+
 extern "C" int grl_stem_conv7x7(const float* x, const float* w, const float* scale, const float* shift,
                                 float* y, int n, int H, int W, int relu, const float* wp, void* stream) {
+    return stem_launch(x, nullptr, w, scale, shift, y, n, H, W, relu, wp, stream);
+}
+
+extern "C" int grl_stem_conv7x7_u8(const uint8_t* x, const float* mean_std, const float* w, const float* scale,
+                                   const float* shift, float* y, int n, int H, int W, int relu, const float* wp,
+                                   void* stream) {
+    if (!mean_std) return grl_fail(GRL_EINVAL, "stem_u8: mean_std is null");
+    return stem_launch(reinterpret_cast<const float*>(x), mean_std, w, scale, shift, y, n, H, W, relu, wp, stream);
+}
+
+static int stem_launch(const float* x, const float* norm, const float* w, const float* scale, const float* shift,
+                       float* y, int n, int H, int W, int relu, const float* wp, void* stream) {
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
     static const int use_valu = getenv("GRL_STEM_VALU") ? 1 : 0;     // kernel tuning only
-    if (use_valu) {
+    if (use_valu && !norm) {
         hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grl_ceil_div(Wo, ST), grl_ceil_div(Ho, ST), n), dim3(256), 0,
                            (hipStream_t)stream, x, w, scale, shift, y, H, W, relu);
     } else {
         const size_t lds = (size_t)(64 * SM_WLD + SM_KOFF + SM_K) * sizeof(float);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(grl_ceil_div(Wo, SM_TW), grl_ceil_div(Ho, SM_TH), n), dim3(256), lds,
-                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, wp);
+                           (hipStream_t)stream, x, w, scale, shift, y, H, W, relu, wp, norm);
     }
     return grl_check_launch("grl_stem_conv7x7");
 }

@@ -186,7 +186,8 @@ constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // fp32 cells; SB
 __global__ __launch_bounds__(256) void stem_b16_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ shift, __bf16* __restrict__ y, int H, int W, int relu,
-    const __bf16* __restrict__ wp) {
+    const __bf16* __restrict__ wp, const float* __restrict__ norm) {
+    // norm != NULL: x holds raw u8 pixels, normalised here as (u/255 - mean[c]) / std[c]
     extern __shared__ __attribute__((aligned(16))) char smb[];
     char* At = smb;                                            // [128][336 B]
     char* Wt = At + 128 * SB_ROWB;                             // [64][336 B]
@@ -197,11 +198,15 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
     for (int i = tid; i < 3 * SB_PH * SB_PW; i += 256) {
         const int c = i / (SB_PH * SB_PW), r = (i / SB_PW) % SB_PH, q = i % SB_PW;
         const int iy = iy0 + r, ix = ix0 + q;
         float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xi[((int64_t)c * H + iy) * W + ix];
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const int64_t o = ((int64_t)c * H + iy) * W + ix;
+            v = norm ? ((float)xu[o] / 255.f - norm[c]) / norm[3 + c] : xi[o];
+        }
         patch[(c * SB_PH + r) * SB_PWP + q] = v;
     }
     if (tid < 4) patch[SB_PATCH + tid] = 0.f;
@@ -310,8 +315,24 @@ extern "C" int grl_stem_pack_weight_bf16(const float* w, void* wp, void* stream)
     return grl_check_launch("grl_stem_pack_weight_bf16");
 }
 
+static int stem_b16_launch(const float* x, const float* norm, const float* w, const float* scale,
+                           const float* shift, void* y, int n, int H, int W, int relu, const void* wp, void* stream);
+
 extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
                                      void* y, int n, int H, int W, int relu, const void* wp, void* stream) {
+    return stem_b16_launch(x, nullptr, w, scale, shift, y, n, H, W, relu, wp, stream);
+}
+
+extern "C" int grl_stem_conv7x7_u8_bf16(const uint8_t* x, const float* mean_std, const float* w, const float* scale,
+                                        const float* shift, void* y, int n, int H, int W, int relu, const void* wp,
+                                        void* stream) {
+    if (!mean_std) return grl_fail(GRL_EINVAL, "stem_u8_bf16: mean_std is null");
+    return stem_b16_launch(reinterpret_cast<const float*>(x), mean_std, w, scale, shift, y, n, H, W, relu, wp,
+                           stream);
+}
+
+static int stem_b16_launch(const float* x, const float* norm, const float* w, const float* scale,
+                           const float* shift, void* y, int n, int H, int W, int relu, const void* wp, void* stream) {
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem_bf16: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem_bf16: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
@@ -319,7 +340,7 @@ extern "C" int grl_stem_conv7x7_bf16(const float* x, const float* w, const float
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)stem_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH), n), dim3(256), lds,
-                       (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu, CB16(wp));
+                       (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu, CB16(wp), norm);
     return grl_check_launch("grl_stem_conv7x7_bf16");
 }
 

@@ -28,6 +28,20 @@ def shard_pairs(batch_size, rank, world):
     return 2 * per * rank, 2 * per * (rank + 1)
 
 
+def gather_rank_order(x, y, group=None):
+    """(features, labels) of every rank concatenated in rank order -- the OIM look-up tables
+    replay all ranks' updates in that order so they stay identical without a broadcast
+    (oim.py:24-26 is order dependent for repeated labels).  Identity when not distributed."""
+    if not is_distributed():
+        return x, y
+    world = dist.get_world_size(group)
+    xl = [torch.empty_like(x) for _ in range(world)]
+    yl = [torch.empty_like(y) for _ in range(world)]
+    dist.all_gather(xl, x.contiguous(), group=group)
+    dist.all_gather(yl, y.contiguous(), group=group)
+    return torch.cat(xl), torch.cat(yl)
+
+
 class GradBucket(object):
     """Flat gradient bucket.  Parameters that never receive a gradient on any rank
     (Siamese.featV*, the unused uncorr verification head) contribute zeros so the

@@ -66,6 +66,34 @@ def _new(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# Raw uint8 clips are normalised on the device with the constants of the reference's loaders
+# (reid/data/dataloader.py:20,51: ToTensor + Normalize(mean, std)) -- inside the stem in eval
+# mode, by grl_normalize_u8 in train mode.  SURVEY.md 8(f) rank 4.
+INPUT_MEAN = (0.485, 0.456, 0.406)
+INPUT_STD = (0.229, 0.224, 0.225)
+_mean_std = {}
+
+
+def input_mean_std(dev):
+    t = _mean_std.get(dev)
+    if t is None:
+        t = _mean_std[dev] = torch.tensor(INPUT_MEAN + INPUT_STD, dtype=torch.float32, device=dev)
+    return t
+
+
+def normalize_u8(x):
+    """uint8 [..., 3, H, W] -> float32, (x/255 - mean)/std per channel (bit-identical to the host
+    ToTensor + Normalize of seqtransforms.py:190,212-213)."""
+    require_device(x, 'clips', allow_u8=True)
+    if x.dtype != torch.uint8:
+        return x
+    x = x.contiguous()
+    y = _new(x.shape, x)
+    plane = x.shape[-1] * x.shape[-2]
+    _call('grl_normalize_u8', ptr(x), ptr(input_mean_std(x.device)), ptr(y), x.numel() // (3 * plane), plane)
+    return y
+
+
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False):
@@ -277,8 +305,12 @@ def trunk_eval(plan, x, taps=None):
     n, _, H, W = x.shape
     Hs, Ws = H // 2, W // 2
     stem = _new((n * Hs * Ws, 64), x)
-    _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-          ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
+    if x.dtype == torch.uint8:           # raw pixels: normalised while the stem stages its patch
+        _call('grl_stem_conv7x7_u8', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
+              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
+    else:
+        _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+              ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
     _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)
@@ -441,8 +473,12 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     n = b * t
     Hs, Ws = h // 2, w // 2
     stem = _newb((n * Hs * Ws, 64), x)
-    _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-          ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
+    if x.dtype == torch.uint8:
+        _call('grl_stem_conv7x7_u8_bf16', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
+              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
+    else:
+        _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+              ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
     H, W = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _newb((n * H * W, 64), x)
     _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)
@@ -527,12 +563,12 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
 def grl_forward(model, inputs, taps=None):
     """ResNet50_GRL_Model.forward.  eval(): folded-BN inference path.
     train(): batch-statistics forward recorded for the HIP backward."""
-    require_device(inputs, 'inputs')
+    require_device(inputs, 'inputs', allow_u8=True)
     if inputs.dim() != 5:
         raise ValueError('inputs must be [B,T,3,256,128]')
     if model.training:
         from . import train_engine
-        return train_engine.grl_forward_train(model, inputs)
+        return train_engine.grl_forward_train(model, normalize_u8(inputs))
     with torch.no_grad():
         return _grl_eval(model, inputs, taps)
 
@@ -575,7 +611,7 @@ def extract_features(cnn, siam, clips):
     """attevaluator.py:100-112 in one pass: [b,T,3,256,128] -> [b,6144] =
     cat(x_uncorr, self_attention(x_corr), mean_T(x_corr)), each written straight
     into its slice of the feature row."""
-    require_device(clips, 'clips')
+    require_device(clips, 'clips', allow_u8=True)
     cnn = getattr(cnn, 'module', cnn)            # nn.DataParallel wrapper (mars_train.py:80)
     if cnn.training or siam.training:
         raise RuntimeError('extract_features needs cnn.eval() and siamese.eval()')
@@ -604,7 +640,7 @@ class GraphedExtractor(object):
         self._key = None
 
     def __call__(self, clips):
-        require_device(clips, 'clips')
+        require_device(clips, 'clips', allow_u8=True)
         key = (_state_key(self.cnn), _state_key(self.siam))
         if key != self._key:
             self._graphs.clear()
@@ -663,3 +699,37 @@ def rank_rows(distmat):
     idx = torch.empty((rows, n), dtype=torch.int32, device=distmat.device)
     _call('grl_row_argsort', ptr(distmat), n, rows, n, ptr(idx))
     return idx
+
+
+def rank_metrics(indices, q_pids, g_pids, q_camids, g_camids, max_rank=100):
+    """CMC curve and mAP of eva_functions.evaluate (eva_functions.py:134-184) from a device
+    argsort (``rank_rows``): `grl_rank_metrics` leaves (first match rank, #matches, AP) per query,
+    the host only averages nq numbers.  Returns (cmc[max_rank] float32, mAP float)."""
+    import numpy as np
+    if not (torch.is_tensor(indices) and indices.is_cuda and indices.dtype == torch.int32):
+        raise _lib.GrlHipError('rank_metrics needs the int32 device index matrix of rank_rows')
+    indices = indices.contiguous()
+    nq, ng = indices.shape
+    dev = indices.device
+
+    def ids(a, n, what):
+        a = np.asarray(a).reshape(-1)
+        if a.size != n:
+            raise ValueError('%s: expected %d entries, got %d' % (what, n, a.size))
+        return torch.from_numpy(a.astype(np.int32)).to(dev)
+    qp, qc = ids(q_pids, nq, 'q_pids'), ids(q_camids, nq, 'q_camids')
+    gp, gc = ids(g_pids, ng, 'g_pids'), ids(g_camids, ng, 'g_camids')
+    first = torch.empty(nq, dtype=torch.int32, device=dev)
+    nhit = torch.empty(nq, dtype=torch.int32, device=dev)
+    ap = torch.empty(nq, dtype=torch.float64, device=dev)
+    _call('grl_rank_metrics', ptr(indices), ng, ptr(qp), ptr(qc), ptr(gp), ptr(gc), nq, ng, ptr(first), ptr(nhit),
+          ptr(ap))
+    first, nhit, ap = first.cpu().numpy(), nhit.cpu().numpy(), ap.cpu().numpy()
+    valid = nhit > 0
+    assert valid.any(), "Error: all query identities do not appear in gallery"
+    if ng < max_rank:
+        max_rank = ng
+        print("Note: number of gallery samples is quite small, got {}".format(ng))
+    hit_by = (first[valid][:, None] <= np.arange(max_rank)[None, :]).astype(np.float32)
+    return hit_by.sum(0) / float(valid.sum()), float(np.mean(ap[valid]))
+

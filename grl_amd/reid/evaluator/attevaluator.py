@@ -83,10 +83,12 @@ class ATTEvaluator(object):
         print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
         print("Computing distance matrix")
         dist_dev = cosin_dist(qf, gf)
-        # ranking on the device when the gallery fits one LDS sort network (MARS: 11310 columns)
-        indices = None
+        # ranking AND the per-query CMC / AP work on the device when the gallery fits one LDS sort
+        # network (MARS: 11310 columns): neither the distance nor the index matrix leaves HBM
         if not rerank and dist_dev.shape[1] <= 16384:
-            indices = engine.rank_rows(dist_dev).cpu().numpy()
+            return evaluate_seq(None, q_pids, q_camids, g_pids, g_camids, path,
+                                indices=engine.rank_rows(dist_dev))
+        indices = None
         distmat = dist_dev.cpu().numpy()
         if rerank:
             print('Applying person re-ranking ...')

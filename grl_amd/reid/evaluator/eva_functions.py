@@ -25,7 +25,11 @@ def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100, indices=
     ``np.argsort`` exactly as the reference does; gallery entries that share
     both pid and camid with the query are dropped; queries whose identity never
     appears are skipped.  Returns (cmc[max_rank] float32, mAP).  ``indices`` may carry a
-    precomputed row-wise argsort (grl_amd.engine.rank_rows computes it on the GPU)."""
+    precomputed row-wise argsort; when it is the DEVICE tensor of grl_amd.engine.rank_rows the
+    per-query work also runs on the GPU (engine.rank_metrics) and ``distmat`` is not touched."""
+    if torch.is_tensor(indices) and indices.is_cuda:
+        from grl_amd import engine
+        return engine.rank_metrics(indices, q_pids, g_pids, q_camids, g_camids, max_rank)
     distmat = np.asarray(distmat)
     q_pids, g_pids = np.asarray(q_pids), np.asarray(g_pids)
     q_camids, g_camids = np.asarray(q_camids), np.asarray(g_camids)

@@ -1,55 +1,85 @@
-"""Online Instance Matching loss (reference: reid/loss/oim.py:8-53), restated as a
-static autograd.Function -- the reference's legacy non-static Function does not run
-on torch >= 1.5 (PARITY UNPINNED for OIM).
+"""Online Instance Matching loss (reference: reid/loss/oim.py:8-53) on MI355X.
 
-forward: logits = x . LUT^T, scaled, cross-entropy.
-backward: grad_x = g . LUT, then -- inside backward, as upstream -- the LUT rows of the
-batch labels are momentum-updated one sample at a time and re-normalised.
+forward : logits = scalar * x . LUT^T (the MFMA GEMM kernel, scale in the epilogue), then
+          `grl_softmax_ce` = F.cross_entropy(mean) AND its gradient in one launch.
+backward: grad_x = g * scalar * dlogits . LUT (`grl_oim_grad`) with the LUT as it was in the
+          forward, then -- inside backward, as upstream -- the LUT rows of the batch labels are
+          momentum-updated one sample at a time and re-normalised (`grl_oim_update`).
+
+The reference's legacy non-static autograd Function does not run on torch >= 1.5
+(PARITY UNPINNED for OIM); this is a static Function with the same maths.
+No torch op computes here and nothing syncs with the host; there is no CPU path.
 
 Multi-process data parallel: every rank applies the updates of ALL ranks in rank order
 (all_gather of the small (features, labels) block), so the LUTs stay identical without
-a parameter broadcast.  These are torch ops on the device: the losses are host-side
-glue in this round."""
+a parameter broadcast."""
+import ctypes as C
+
 import torch
-import torch.nn.functional as F
 from torch import nn, autograd
+
+from grl_amd import _lib
+from grl_amd._lib import ptr, require_device, MATH_F32
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args, _lib.stream()), name)
+
+
+def _labels(t, dev):
+    if not torch.is_tensor(t):
+        raise _lib.GrlHipError('labels must be a tensor')
+    return t.to(device=dev, dtype=torch.int64).contiguous()
 
 
 class OIM(autograd.Function):
-    @staticmethod
-    def forward(ctx, inputs, targets, lut, momentum):
-        ctx.save_for_backward(inputs, targets)
-        ctx.lut, ctx.momentum = lut, momentum
-        return inputs.mm(lut.t())
+    """(loss, scaled logits) = CE(scalar * x . LUT^T, targets); the logits are returned for
+    the precision read-out only (trainer.py:127) and carry no gradient."""
 
     @staticmethod
-    def backward(ctx, grad_outputs):
-        inputs, targets = ctx.saved_tensors
+    def forward(ctx, inputs, targets, lut, momentum, scalar, weight):
+        from grl_amd import engine
+        require_device(inputs, 'OIM inputs')
+        require_device(lut, 'OIM lut')
+        x = inputs.contiguous()
+        y = _labels(targets, x.device)
+        n, D = x.shape
+        c = lut.size(0)
+        scale = torch.full((c,), float(scalar), dtype=torch.float32, device=x.device)
+        logits = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        engine.gemm(x, lut, logits, n, c, D, scale=scale, math=MATH_F32)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dlogits = torch.empty_like(logits)
+        ws = torch.empty(2 * n, dtype=torch.float32, device=x.device)
+        if weight is not None:
+            require_device(weight, 'OIM class weight')
+            weight = weight.contiguous()
+        _call('grl_softmax_ce', ptr(logits), c, ptr(y), ptr(weight), n, c, ptr(loss), None, ptr(dlogits), c,
+              ptr(ws))
+        ctx.save_for_backward(x, y, dlogits)
+        ctx.lut, ctx.momentum, ctx.scalar = lut, momentum, float(scalar)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        x, y, dlogits = ctx.saved_tensors
         lut, m = ctx.lut, ctx.momentum
-        grad_inputs = grad_outputs.mm(lut) if ctx.needs_input_grad[0] else None
-        xs, ys = inputs.detach(), targets
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            xl = [torch.empty_like(xs) for _ in range(dist.get_world_size())]
-            yl = [torch.empty_like(ys) for _ in range(dist.get_world_size())]
-            dist.all_gather(xl, xs.contiguous())
-            dist.all_gather(yl, ys.contiguous())
-            xs, ys = torch.cat(xl), torch.cat(yl)
-        if lut.is_cuda:                               # one HIP launch, no host sync
-            from grl_amd import _lib
-            import ctypes as C
-            xs, ys = xs.contiguous().float(), ys.contiguous().long()
-            _lib.check(_lib.load().grl_oim_update(lut.data_ptr(), xs.data_ptr(), ys.data_ptr(), xs.size(0),
-                                                  xs.size(1), C.c_float(m), _lib.stream()), 'grl_oim_update')
-        else:
-            for x, y in zip(xs, ys.tolist()):         # sequential per sample (oim.py:24-26)
-                row = m * lut[y] + (1. - m) * x
-                lut[y] = row / row.norm()
-        return grad_inputs, None, None, None
+        n, D = x.shape
+        grad_inputs = None
+        if ctx.needs_input_grad[0]:
+            g = gloss.contiguous().float()
+            grad_inputs = torch.empty_like(x)
+            _call('grl_oim_grad', ptr(dlogits), lut.size(0), ptr(lut), ptr(g), C.c_float(ctx.scalar),
+                  ptr(grad_inputs), n, lut.size(0), D)
+        from grl_amd import dist as grl_dist
+        xs, ys = grl_dist.gather_rank_order(x, y)
+        _call('grl_oim_update', ptr(lut), ptr(xs), ptr(ys), xs.size(0), D, C.c_float(m))
+        return grad_inputs, None, None, None, None, None
 
 
-def oim(inputs, targets, lut, momentum=0.5):
-    return OIM.apply(inputs, targets, lut, momentum)
+def oim(inputs, targets, lut, momentum=0.5, scalar=1.0, weight=None):
+    return OIM.apply(inputs, targets, lut, momentum, scalar, weight)
 
 
 class OIMLoss(nn.Module):
@@ -65,7 +95,4 @@ class OIMLoss(nn.Module):
         self.size_average = size_average
 
     def forward(self, inputs, targets):
-        inputs = oim(inputs, targets, self.lut, momentum=self.momentum)
-        inputs = inputs * self.scalar
-        loss = F.cross_entropy(inputs, targets, weight=self.weight)
-        return loss, inputs
+        return oim(inputs, targets, self.lut, self.momentum, self.scalar, self.weight)

@@ -1,8 +1,42 @@
-"""Batch-hard soft-margin triplet loss (reference: reid/loss/triplet.py:16-90, the
-`mode='id'`, `dis_func='eu'`, `batch_hard=True`, `margin='soft'` path the trainer uses:
-trainer.py:12,141)."""
+"""Batch-hard triplet loss (reference: reid/loss/triplet.py:16-90, the `mode='id'`,
+`dis_func='eu'`, `batch_hard=True` path the trainer uses with margin 'soft':
+trainer.py:13,141) on MI355X: `grl_triplet_fwd` (distance rows, hardest positive / negative,
+per-anchor loss) and `grl_triplet_bwd` (gather-form gradient, fixed order)."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
+from torch import autograd
+
+from grl_amd._lib import ptr, require_device
+from grl_amd.reid.loss.oim import _call, _labels
+
+
+class _BatchHard(autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, ids, soft, margin):
+        require_device(feat, 'TripletLoss feat')
+        f = feat.contiguous()
+        y = _labels(ids, f.device)
+        n, D = f.shape
+        loss = torch.empty(n, dtype=torch.float32, device=f.device)
+        dist = torch.empty((n, n), dtype=torch.float32, device=f.device)
+        z = torch.empty(n, dtype=torch.float32, device=f.device)
+        sel = torch.empty((n, 2), dtype=torch.int32, device=f.device)
+        _call('grl_triplet_fwd', ptr(f), ptr(y), n, D, soft, C.c_float(margin), ptr(loss), ptr(dist), ptr(sel),
+              ptr(z))
+        ctx.save_for_backward(f, dist, sel, z)
+        ctx.soft, ctx.margin = soft, margin
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        f, dist, sel, z = ctx.saved_tensors
+        n, D = f.shape
+        df = torch.empty_like(f)
+        _call('grl_triplet_bwd', ptr(f), ptr(dist), ptr(sel), ptr(z), ptr(dloss.contiguous().float()), ctx.soft,
+              C.c_float(ctx.margin), ptr(df), n, D)
+        return df, None, None, None
 
 
 class TripletLoss(nn.Module):
@@ -15,25 +49,12 @@ class TripletLoss(nn.Module):
             raise NotImplementedError('The margin {} is not recognized in TripletLoss()'.format(margin))
 
     def forward(self, feat, id=None, pos_mask=None, neg_mask=None, mode='id', dis_func='eu', n_dis=0):
-        if mode != 'id' or n_dis != 0 or not self.batch_hard:
-            raise NotImplementedError('only the batch-hard id-mode path of the reference trainer is provided')
+        if mode != 'id' or n_dis != 0 or not self.batch_hard or dis_func != 'eu':
+            raise NotImplementedError('only the batch-hard id-mode Euclidean path of the reference trainer is provided')
         if id is None:
             raise RuntimeError('foward is in id mode, please input id!')
-        if dis_func == 'cdist':
-            feat = feat / feat.norm(p=2, dim=1, keepdim=True)
-        dist = self.cdist(feat, feat)
-        same = torch.eq(id.unsqueeze(1), id.unsqueeze(0))
-        eye = torch.eye(feat.size(0), dtype=torch.bool, device=feat.device)
-        max_positive = (dist * (same ^ eye).float()).max(1)[0]
-        min_negative = (dist + 1e5 * same.float()).min(1)[0]
-        z = max_positive - min_negative
-        if isinstance(self.margin, float):
-            return torch.clamp(z + self.margin, min=0)
-        return torch.log(1 + torch.exp(z))
-
-    def cdist(self, a, b):
-        diff = a.unsqueeze(1) - b.unsqueeze(0)
-        return ((diff ** 2).sum(2) + 1e-12).sqrt()
+        soft = self.margin == 'soft'
+        return _BatchHard.apply(feat, id, 1 if soft else 0, 0.0 if soft else float(self.margin))
 
 
 class TripletLoss_OIM(TripletLoss):

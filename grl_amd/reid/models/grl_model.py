@@ -77,7 +77,8 @@ class ResNet50_GRL_Model(nn.Module):
         init.constant_(self.uncorr_bn.bias, 0)
 
     def forward(self, inputs, training=True):
-        """inputs [B,T,3,256,128] fp32 on a HIP device ->
+        """inputs [B,T,3,256,128] on a HIP device -- fp32 (normalised by the loader, as upstream)
+        or raw uint8 pixels (normalised on the device) ->
         (x_uncorr [B,2048], x_corr [B,T,2048])  (grl_model.py:211-228)."""
         from grl_amd import engine
         return engine.grl_forward(self, inputs)

@@ -3,15 +3,16 @@ composition (/root/reference/reid/train/trainer.py:16-177).  The CNN / Siamese
 forward and backward run on MI355X through grl_amd (autograd.Functions around the HIP
 kernels); the only addition is the data-parallel gradient all-reduce between
 ``backward()`` and ``step()`` when torch.distributed is initialised (one process per
-GPU; RCCL over xGMI)."""
+GPU; RCCL over xGMI).  The loss block (OIM cross entropy, pair BCE, batch-hard triplet) is
+HIP too (grl_amd/csrc/loss.hip); torch only adds the five scalars."""
 import time
 
 import torch
-import torch.nn.functional as F
 
 from grl_amd import dist as grl_dist
 from grl_amd.reid.evaluator import accuracy
 from grl_amd.reid.loss import TripletLoss
+from grl_amd.reid.loss.pairloss import pair_prob
 from grl_amd.utils.meters import AverageMeter
 
 try:                                            # tensorboardX is optional here
@@ -104,8 +105,8 @@ class SEQTrainer(BaseTrainer):
 
     @staticmethod
     def _pair_prob(encode_scores):
-        n0, n1 = encode_scores.size(0), encode_scores.size(1)
-        return F.softmax(encode_scores.view(-1, 2), dim=-1).view(n0, n1, 2)[:, :, 1]
+        """softmax over the two verification logits, class-1 column (trainer.py:146-148)."""
+        return pair_prob(encode_scores)
 
     def _forward(self, inputs, targets, i, epoch):
         """trainer.py:107-170: id loss on frames + id loss on pooled clips (same LUT) +

@@ -82,11 +82,14 @@ def synth_state_dict(module_or_spec, seed=0, prefix=''):
             for k, shp in spec.items()}
 
 
-def synth_clips(b, t, seed=0, h=256, w=128):
+def synth_clips(b, t, seed=0, h=256, w=128, raw=False):
     """u8 ~ U{0..255} (PCG64(seed)) -> ToTensor -> Normalize(ImageNet), fp32
-    [b,t,3,h,w]; value range ~[-2.12, 2.64] (seqtransforms.py:187-213)."""
+    [b,t,3,h,w]; value range ~[-2.12, 2.64] (seqtransforms.py:187-213).  ``raw=True`` returns
+    the uint8 pixels themselves (the device normalises them inside the stem)."""
     g = np.random.Generator(np.random.PCG64(seed))
     u8 = g.integers(0, 256, size=(b, t, 3, h, w), dtype=np.uint8)
+    if raw:
+        return torch.from_numpy(u8)
     x = torch.from_numpy(u8).to(torch.float32).div_(255.0)
     mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(1, 1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(1, 1, 3, 1, 1)

@@ -106,6 +106,17 @@ int grl_stem_conv7x7(const float* x, const float* w /*[64][3][7][7]*/, const flo
                      const float* shift, float* y, int n, int H, int W, int relu,
                      const float* wp /* optional: [64][164] image from grl_stem_pack_weight */,
                      void* stream);
+/* the same stem reading RAW u8 pixels [n][3][H][W] and normalising them while the input patch
+ * is staged in LDS: (u/255 - mean[c]) / std[c] with mean_std = {mean[3], std[3]} -- the fp32
+ * operations of ToTensor + Normalize (reid/data/seqtransforms.py:190,195-216; constants
+ * reid/data/dataloader.py:20), so the result is bit-identical to normalising on the host first.
+ * a quarter of the input bytes over PCIe and HBM. */
+int grl_stem_conv7x7_u8(const uint8_t* x, const float* mean_std, const float* w, const float* scale,
+                        const float* shift, float* y, int n, int H, int W, int relu, const float* wp,
+                        void* stream);
+/* the normalisation alone (train mode keeps a float clip for the stem's weight gradient):
+ * y[n][3][plane] = (x/255 - mean[c]) / std[c] */
+int grl_normalize_u8(const uint8_t* x, const float* mean_std, float* y, int n, int64_t plane, void* stream);
 /* the stem's LDS weight image (K padded 147 -> 160, rows padded to 164 floats), made once per
  * weight version so that every workgroup copies it with 16-byte loads */
 int grl_stem_pack_weight(const float* w, float* wp /* 64*164 floats */, void* stream);
@@ -178,6 +189,9 @@ int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream);            
 int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, const float* shift,
                           void* y, int n, int H, int W, int relu,
                           const void* wp /* optional: image from grl_stem_pack_weight_bf16 */, void* stream);
+int grl_stem_conv7x7_u8_bf16(const uint8_t* x, const float* mean_std, const float* w, const float* scale,
+                             const float* shift, void* y, int n, int H, int W, int relu, const void* wp,
+                             void* stream);                                      /* u8 input, as grl_stem_conv7x7_u8 */
 int grl_stem_pack_weight_bf16(const float* w, void* wp /* 64*168 bf16 */, void* stream);
 int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream);
 int grl_group_mean_bf16(const void* x, float* y, int groups, int rows, int C, int ldy,
@@ -292,6 +306,52 @@ int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* ddiff, floa
  * in batch order, lut[y] = m*lut[y] + (1-m)*x, then renormalise the row.  labels: int64. */
 int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, float momentum,
                    void* stream);
+
+/* ---- the trainer's loss block, forward and backward on the device ---- */
+/* F.cross_entropy of OIMLoss.forward (reid/loss/oim.py:52; mean reduction, optional class
+ * weight): loss[0] = sum_i w[y_i] (logsumexp(z_i) - z_i[y_i]) / sum_i w[y_i];
+ * dlogits[i][j] = d loss[0] / d z_i[j] (may be NULL); correct[0] (may be NULL) = number of rows
+ * whose arg-max (first index on ties, as topk in eva_functions.py:118-131) equals the label.
+ * Labels outside [0,c) carry weight 0 (torch's ignore_index).  ws: 2*n floats of scratch. */
+int grl_softmax_ce(const float* logits, int64_t ld, const int64_t* labels, const float* weight, int n,
+                   int c, float* loss, float* correct, float* dlogits, int64_t ldd, float* ws,
+                   void* stream);
+/* OIM.backward's input gradient (oim.py:22) with the scalar of oim.py:50 and the upstream
+ * gradient g[0] (device scalar, NULL = 1) folded in: dx = alpha*g * dlogits . lut */
+int grl_oim_grad(const float* dlogits, int64_t ldd, const float* lut, const float* g, float alpha,
+                 float* dx, int n, int c, int D, void* stream);
+/* TripletLoss('soft', batch_hard=True).forward, mode 'id', dis_func 'eu' (reid/loss/triplet.py:16-76,
+ * cdist :78-90): dist[i][j] = sqrt(sum_k (f_i-f_j)^2 + 1e-12); z_i = max_j dist*[same id, j != i]
+ * - min_j (dist + 1e5*[same id]); loss[i] = soft ? log(1 + exp(z_i)) : max(z_i + margin, 0).
+ * sel[i] = {arg-max or -1 when the maximum is a masked zero, arg-min} (first index on ties) for
+ * the backward. */
+int grl_triplet_fwd(const float* feat, const int64_t* ids, int n, int D, int soft, float margin,
+                    float* loss, float* dist, int32_t* sel, float* z, void* stream);
+int grl_triplet_bwd(const float* feat, const float* dist, const int32_t* sel, const float* z,
+                    const float* dloss, int soft, float margin, float* dfeat, int n, int D,
+                    void* stream);
+/* prob[t] = softmax(scores[t][0..1])[1] (reid/train/trainer.py:146-148; prob0, optional, keeps the
+ * class-0 probability for the backward) and its backward, term for term as torch's softmax backward */
+int grl_softmax2(const float* scores, float* prob, float* prob0, int64_t m, void* stream);
+int grl_softmax2_bwd(const float* prob, const float* prob0, const float* dprob, float* dscores, int64_t m,
+                     void* stream);
+/* PairLoss.forward (reid/loss/pairloss.py:18-45): label[a][b] = [tar_probe[b] == tar_gallery[a]];
+ * loss[0] = BCE(prob, label) (mean, logs clamped at -100); prec[0] (may be NULL) = top-1 precision of
+ * the (1-s, s) pseudo-logits; dprob (may be NULL) = d loss[0] / d prob. */
+int grl_pair_bce(const float* prob, const int64_t* tar_probe, const int64_t* tar_gallery, int n,
+                 float* loss, float* prec, float* dprob, void* stream);
+/* y = alpha * g[0] * x with g a device scalar (chains an upstream loss gradient without a host sync) */
+int grl_scale_dev(const float* x, const float* g, float alpha, float* y, int64_t n, void* stream);
+
+/* per-query ranking metrics of eva_functions.evaluate (reid/evaluator/eva_functions.py:134-184)
+ * over a row-wise argsort (grl_row_argsort): gallery entries with the query's pid AND camera are
+ * dropped; first_hit[q] = 0-based rank of the first match among the kept entries (-1: the
+ * identity never appears, the query is skipped upstream), n_hits[q] = matches kept,
+ * ap[q] = (1/n_hits) sum over hits of (hits so far)/(rank+1) in fp64.  CMC[r] = mean over valid
+ * queries of [first_hit <= r]; mAP = mean of ap over valid queries (host, nq numbers). */
+int grl_rank_metrics(const int32_t* idx, int64_t ld, const int32_t* q_pids, const int32_t* q_cams,
+                     const int32_t* g_pids, const int32_t* g_cams, int nq, int ng, int32_t* first_hit,
+                     int32_t* n_hits, double* ap, void* stream);
 
 #ifdef __cplusplus
 }

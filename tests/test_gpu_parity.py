@@ -118,6 +118,10 @@ def test_evaluator_matches_reference_golden(golden):
     assert (resorted[:, :-1] - resorted[:, 1:]).max() <= 3e-5
     cmc, mAP = evaluate(d, qp, gp, qc, gc)
     assert np.allclose(cmc[:20], g['cmc'], atol=1e-6) and abs(mAP - float(g['mAP'])) < 1e-6
+    # ranking + CMC/AP entirely on the device (grl_row_argsort + grl_rank_metrics)
+    cmc_d, map_d = evaluate(None, qp, gp, qc, gc, indices=engine.rank_rows(engine.cosin_dist(qf.cuda(), gf.cuda())))
+    assert np.array_equal(cmc_d, cmc) and abs(map_d - mAP) < 1e-12
+    assert np.allclose(cmc_d[:20], g['cmc'], atol=1e-6) and abs(map_d - float(g['mAP'])) < 1e-6
     e = engine.pairwise_distance_tensor(qf.cuda(), qf.cuda()).cpu().numpy()
     assert _rel(e ** 2, g['euclid_qq'] ** 2) < 1e-5
     qd = qf.view(20, 2, -1).mean(1); gd = torch.cat((qd, gf[40:240]), 0)
@@ -386,13 +390,65 @@ def test_baseline_config4_full_mars_rank1_map():
     from grl_amd.reid.evaluator.eva_functions import evaluate
     from oracle import grl_oracle as O
     qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=6.0)
-    d_gpu = engine.cosin_dist(qf.cuda(), gf.cuda()).cpu().numpy()
+    d_dev = engine.cosin_dist(qf.cuda(), gf.cuda())
+    d_gpu = d_dev.cpu().numpy()
     d_cpu = O.cosin_dist(qf, gf).numpy()
     assert _rel(d_gpu, d_cpu) < 2e-5
     cmc_g, map_g = evaluate(d_gpu, qp, gp, qc, gc)
     cmc_c, map_c = evaluate(d_cpu, qp, gp, qc, gc)
     print('configs[4]: mAP %.4f Rank-1 %.4f' % (map_g, cmc_g[0]))
     assert abs(map_g - map_c) < 1e-5 and np.abs(cmc_g - cmc_c).max() < 1e-3 and 0.02 < map_g < 0.9999
+    # the same protocol with ranking and CMC/AP on the device.  A 11310-entry fp32 row holds a few
+    # exactly tied distances; the device sort is stable (ties to the smaller index), numpy's default
+    # introsort is not: against the stable host ranking the result is identical (mAP to fp64
+    # rounding), against the default one a tied (hit, miss) pair may swap (<= 1e-7 on mAP).
+    cmc_d, map_d = evaluate(None, qp, gp, qc, gc, indices=engine.rank_rows(d_dev))
+    cmc_s, map_s = evaluate(d_gpu, qp, gp, qc, gc, indices=np.argsort(d_gpu, axis=1, kind='stable'))
+    assert np.array_equal(cmc_d, cmc_s) and abs(map_d - map_s) < 1e-12
+    assert np.abs(cmc_d - cmc_g).max() < 1e-3 and abs(map_d - map_g) < 1e-7
+
+
+def test_rank_metrics_edge_cases():
+    """grl_rank_metrics vs the host evaluate on: identities that never appear in the gallery
+    (query skipped), entries dropped for sharing pid AND camera, a gallery shorter than
+    max_rank (flat CMC extension), ragged row lengths that are not a multiple of the 256-entry
+    chunk, and the all-queries-invalid assertion."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    rng = np.random.default_rng(5)
+    for nq, ng, n_ids in ((7, 37, 5), (33, 300, 40), (64, 1000, 500), (5, 257, 3)):
+        d = torch.from_numpy(rng.standard_normal((nq, ng)).astype(np.float32)).cuda()
+        qp, gp = rng.integers(0, n_ids, nq), rng.integers(0, n_ids, ng)
+        qc, gc = rng.integers(0, 3, nq), rng.integers(0, 3, ng)
+        qp[0] = n_ids + 7                                   # never appears -> skipped
+        idx = engine.rank_rows(d)
+        cmc_h, map_h = evaluate(d.cpu().numpy(), qp, gp, qc, gc, indices=idx.cpu().numpy())
+        cmc_d, map_d = evaluate(None, qp, gp, qc, gc, indices=idx)
+        assert cmc_d.shape == cmc_h.shape and np.array_equal(cmc_d, cmc_h), (nq, ng)
+        assert abs(map_d - map_h) < 1e-12
+    with pytest.raises(AssertionError):
+        evaluate(None, np.array([9, 9]), np.zeros(10, np.int64), np.zeros(2, np.int64), np.ones(10, np.int64),
+                 indices=engine.rank_rows(torch.randn(2, 10).cuda()))
+
+
+def test_raw_uint8_clips_are_normalised_on_the_device(gpu_models):
+    """uint8 clips go straight to the stem, which applies ToTensor +
+    Normalize while staging its input patch -- features are bit-identical to the float path
+    (fp32 and bf16-storage pipelines, eval and train mode), and grl_normalize_u8 is
+    bit-identical to the host transform."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    raw = synth_clips(3, 4, seed=11, raw=True).cuda()
+    flt = synth_clips(3, 4, seed=11).cuda()
+    assert torch.equal(engine.normalize_u8(raw), flt)
+    assert torch.equal(engine.extract_features(cnn, siam, raw), engine.extract_features(cnn, siam, flt))
+    with engine.math_mode('bf16s'):
+        assert torch.equal(engine.extract_features(cnn, siam, raw), engine.extract_features(cnn, siam, flt))
+    xu_r, xc_r = cnn(raw)
+    xu_f, xc_f = cnn(flt)
+    assert torch.equal(xu_r, xu_f) and torch.equal(xc_r, xc_f)
+    with pytest.raises(engine._lib.GrlHipError):
+        cnn(raw.to(torch.int16))
 
 
 def test_hip_graph_replay_is_bit_identical(gpu_models):

@@ -134,17 +134,125 @@ def test_wgrad_dense_shapes():
 
 
 def test_oim_update_kernel_matches_sequential_loop():
+    """OIMLoss on HIP (logits GEMM + grl_softmax_ce + grl_oim_grad + grl_oim_update) vs the
+    oracle's restatement of oim.py:14-27,46-53 with repeated labels (order-dependent updates)."""
     from grl_amd.reid.loss import OIMLoss
+    from oracle import grl_oracle as O
     dev = torch.device('cuda:0')
     torch.manual_seed(1)
     x = F.normalize(torch.randn(24, 2048), dim=1)
     y = torch.tensor([5, 5, 5, 5, 9, 9, 9, 9, 5, 5, 2, 2, 7, 7, 7, 7, 9, 9, 0, 0, 5, 2, 7, 0])
-    cpu, gpu = OIMLoss(2048, 12, scalar=30, momentum=0.5), OIMLoss(2048, 12, scalar=30, momentum=0.5).to(dev)
+    gpu = OIMLoss(2048, 12, scalar=30, momentum=0.5).to(dev)
     init = F.normalize(torch.randn(12, 2048), dim=1)
-    cpu.lut.copy_(init); gpu.lut.copy_(init)
+    lut_o = init.clone(); gpu.lut.copy_(init)
     xa, xb = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
-    la, _ = cpu(xa, y); la.backward()
-    lb, _ = gpu(xb, y.to(dev)); lb.backward()
+    la, logits_a = O.oim_loss(xa, y, lut_o, 30.0, 0.5); (la * 0.7).backward()
+    lb, logits_b = gpu(xb, y.to(dev)); (lb * 0.7).backward()
+    assert not logits_b.requires_grad
     assert abs(la.item() - lb.item()) < 1e-5
+    assert _rel(logits_b.cpu().numpy(), logits_a.detach().numpy()) < 1e-5
     assert _rel(xb.grad.cpu().numpy(), xa.grad.numpy()) < 1e-5
-    assert _rel(gpu.lut.cpu().numpy(), cpu.lut.numpy()) < 1e-5
+    assert _rel(gpu.lut.cpu().numpy(), lut_o.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('n,c,D,weighted', [(160, 625, 2048, False), (6, 5, 32, False), (33, 625, 2048, True)])
+def test_softmax_ce_and_oim_grad(n, c, D, weighted):
+    """grl_softmax_ce / grl_oim_grad against F.cross_entropy autograd (mean reduction, optional
+    class weights, one ignored label), and the arg-max hit count against topk."""
+    from grl_amd.reid.loss import OIMLoss
+    dev = torch.device('cuda:0')
+    torch.manual_seed(n + c)
+    x = F.normalize(torch.randn(n, D), dim=1)
+    y = torch.randint(0, c, (n,))
+    w = (torch.rand(c) + 0.5) if weighted else None
+    lut = F.normalize(torch.randn(c, D), dim=1)
+    xa = x.clone().requires_grad_(True)
+    logits = xa.mm(lut.t()) * 30.0
+    la = F.cross_entropy(logits, y, weight=w); la.backward()
+    crit = OIMLoss(D, c, scalar=30.0, momentum=0.5, weight=None if w is None else w.to(dev)).to(dev)
+    crit.lut.copy_(lut)
+    xb = x.clone().to(dev).requires_grad_(True)
+    lb, lg = crit(xb, y.to(dev)); lb.backward()
+    assert abs(la.item() - lb.item()) < 2e-5 * max(1.0, abs(la.item()))
+    assert _rel(lg.cpu().numpy(), logits.detach().numpy()) < 1e-5
+    assert _rel(xb.grad.cpu().numpy(), xa.grad.numpy()) < 2e-5
+    # raw kernel: hit count + an out-of-range label is ignored like torch's ignore_index
+    from grl_amd import _lib
+    lib = _lib.load()
+    y2 = y.clone(); y2[0] = -100
+    lg_d, y2_d = logits.detach().to(dev).contiguous(), y2.to(dev)
+    loss, hits = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    ws = torch.empty(2 * n, device=dev)
+    _lib.check(lib.grl_softmax_ce(lg_d.data_ptr(), c, y2_d.data_ptr(), None, n, c, loss.data_ptr(), hits.data_ptr(),
+                                  None, c, ws.data_ptr(), _lib.stream()), 'grl_softmax_ce')
+    ref = F.cross_entropy(logits.detach(), y2)
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    assert int(hits.item()) == int((logits.detach().argmax(1)[1:] == y2[1:]).sum())
+
+
+def test_loss_block_matches_reference_golden(golden):
+    """TripletLoss('soft', True) and PairLoss on HIP against the outputs of the reference's own
+    modules (tests/golden/losses.npz)."""
+    from grl_amd.reid.loss import TripletLoss, PairLoss
+    dev = torch.device('cuda:0')
+    g = golden('losses.npz')
+    tri = TripletLoss('soft', True)(torch.from_numpy(g['feat']).to(dev), torch.from_numpy(g['ids']).to(dev))
+    assert np.allclose(tri.cpu().numpy(), g['triplet'], rtol=1e-5, atol=1e-6)
+    loss, prec = PairLoss()(torch.from_numpy(g['score']).to(dev), torch.from_numpy(g['tp']).to(dev),
+                            torch.from_numpy(g['tg']).to(dev))
+    assert abs(loss.item() - float(g['pair_loss'])) < 1e-6
+    assert abs(float(prec) - float(g['pair_prec'])) < 1e-6
+
+
+@pytest.mark.parametrize('ids,margin', [
+    ([0, 0, 1, 1, 2, 2, 3, 3, 0, 1, 2, 3, 4, 4, 5, 5], 'soft'),
+    ([0, 0, 1, 1, 2, 3, 3, 3], 'soft'),               # id 2 has no positive: masked maximum, no gradient
+    ([7, 7, 7, 7], 'soft'),                           # no negative at all: min over dist + 1e5
+    ([0, 0, 1, 1, 2, 2, 3, 3], 0.3)])
+def test_triplet_forward_backward(ids, margin):
+    from grl_amd.reid.loss import TripletLoss
+    from oracle import grl_oracle as O
+    dev = torch.device('cuda:0')
+    torch.manual_seed(len(ids))
+    ids = torch.tensor(ids)
+    f = torch.randn(len(ids), 2048) * 0.05
+    fa = f.clone().requires_grad_(True)
+    if margin == 'soft':
+        la = O.triplet_soft_batch_hard(fa, ids)
+    else:
+        diff = fa.unsqueeze(1) - fa.unsqueeze(0)
+        dist = (diff.pow(2).sum(2) + 1e-12).sqrt()
+        same = ids.unsqueeze(1).eq(ids.unsqueeze(0))
+        pos = same & ~torch.eye(len(ids), dtype=torch.bool)
+        la = torch.clamp((dist * pos.float()).max(1)[0] - (dist + 1e5 * same.float()).min(1)[0] + margin, min=0)
+    r = torch.rand(len(ids)) + 0.5
+    (la * r).sum().backward()
+    fb = f.clone().to(dev).requires_grad_(True)
+    lb = TripletLoss(margin, True)(fb, ids.to(dev))
+    (lb * r.to(dev)).sum().backward()
+    assert np.allclose(lb.detach().cpu().numpy(), la.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert _rel(fb.grad.cpu().numpy(), fa.grad.numpy()) < 2e-5
+
+
+def test_pair_prob_and_bce_forward_backward():
+    from grl_amd.reid.loss import PairLoss
+    from grl_amd.reid.loss.pairloss import pair_prob
+    from oracle import grl_oracle as O
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    n = 16
+    scores = torch.randn(n, n, 2) * 3
+    scores[0, 0] = torch.tensor([120.0, -120.0])       # saturated: exercises the log / denominator clamps
+    tp = torch.arange(n) // 2
+    tg = torch.arange(n) // 2
+    tg[3] = 99
+    sa = scores.clone().requires_grad_(True)
+    prob_a = F.softmax(sa.view(-1, 2), dim=-1).view(n, n, 2)[:, :, 1]
+    la, pa = O.pair_loss(prob_a, tp, tg); (la * 20).backward()
+    sb = scores.clone().to(dev).requires_grad_(True)
+    prob_b = pair_prob(sb)
+    lb, pb = PairLoss()(prob_b, tp.to(dev), tg.to(dev)); (lb * 20).backward()
+    assert _rel(prob_b.detach().cpu().numpy(), prob_a.detach().numpy()) < 1e-6
+    assert abs(la.item() - lb.item()) < 1e-5 * max(1.0, abs(la.item()))
+    assert abs(float(pa) - float(pb)) < 1e-6
+    assert _rel(sb.grad.cpu().numpy(), sa.grad.numpy()) < 2e-5

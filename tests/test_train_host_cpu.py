@@ -11,34 +11,23 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_losses_match_reference_golden(golden):
-    from grl_amd.reid.loss import TripletLoss, PairLoss
-    g = golden('losses.npz')
-    tri = TripletLoss('soft', True)(torch.from_numpy(g['feat']), torch.from_numpy(g['ids']))
-    assert np.allclose(tri.numpy(), g['triplet'], rtol=1e-5, atol=1e-6)
-    loss, prec = PairLoss()(torch.from_numpy(g['score']), torch.from_numpy(g['tp']), torch.from_numpy(g['tg']))
-    assert abs(loss.item() - float(g['pair_loss'])) < 1e-6
-    assert abs(float(prec) - float(g['pair_prec'])) < 1e-6
-
-
-def test_oim_matches_oracle_restatement():
-    """OIM cannot be pinned to the reference (legacy Function); product and oracle are two
-    independent restatements of oim.py:14-27,46-53 and must agree."""
-    from grl_amd.reid.loss import OIMLoss
-    from oracle import grl_oracle as O
-    torch.manual_seed(0)
-    x = torch.nn.functional.normalize(torch.randn(6, 32), dim=1)
-    y = torch.tensor([1, 4, 1, 0, 4, 2])
-    crit = OIMLoss(32, 5, scalar=30, momentum=0.5)
-    crit.lut.copy_(torch.nn.functional.normalize(torch.randn(5, 32), dim=1))
-    lut_o = crit.lut.clone()
-    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    la, _ = crit(xa, y); la.backward()
-    lb, _ = O.oim_loss(xb, y, lut_o, 30.0, 0.5); lb.backward()
-    assert abs(la.item() - lb.item()) < 1e-6
-    assert torch.allclose(xa.grad, xb.grad, atol=1e-6)
-    assert torch.allclose(crit.lut, lut_o, atol=1e-6)
-    assert torch.allclose(crit.lut[[0, 1, 2, 4]].norm(dim=1), torch.ones(4), atol=1e-6)
+def test_losses_refuse_cpu_tensors():
+    """The loss block is HIP only (grl_amd/csrc/loss.hip); the parity tests against the
+    reference golden and the oracle are GPU tests (tests/test_gpu_train_kernels.py)."""
+    from grl_amd._lib import GrlHipError
+    from grl_amd.reid.loss import TripletLoss, PairLoss, OIMLoss
+    from grl_amd.reid.loss.pairloss import pair_prob
+    ids = torch.tensor([0, 0, 1, 1])
+    with pytest.raises(GrlHipError):
+        TripletLoss('soft', True)(torch.randn(4, 8), ids)
+    with pytest.raises(GrlHipError):
+        PairLoss()(torch.rand(2, 2), ids[:2], ids[2:])
+    with pytest.raises(GrlHipError):
+        OIMLoss(32, 5, scalar=30)(torch.randn(4, 32), ids)
+    with pytest.raises(GrlHipError):
+        pair_prob(torch.randn(2, 2, 2))
+    with pytest.raises(NotImplementedError):
+        TripletLoss('soft', False)(torch.randn(4, 8), ids)
 
 
 def test_shard_pairs():
@@ -56,8 +45,7 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from grl_amd.dist import GradBucket, is_distributed
-    from grl_amd.reid.loss import OIMLoss
+    from grl_amd.dist import GradBucket, is_distributed, gather_rank_order
     assert is_distributed()
     torch.manual_seed(0)
     a, b, c = (torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
@@ -66,13 +54,11 @@ def _worker(rank, world, port, out):
     b.grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
     # c never receives a gradient (like Siamese.featV): contributes zeros, stays None
     GradBucket([a, b, c]).allreduce_mean()
-    # OIM look-up tables stay identical across ranks
-    crit = OIMLoss(8, 4, scalar=10, momentum=0.5)
-    x = torch.nn.functional.normalize(torch.randn(3, 8) + rank, dim=1).requires_grad_(True)
+    # the OIM look-up tables replay every rank's (feature, label) block in rank order
+    x = torch.full((3, 8), float(rank))
     y = torch.tensor([rank, 2, 3])
-    loss, _ = crit(x, y)
-    loss.backward()
-    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, crit.lut.clone())
+    xs, ys = gather_rank_order(x, y)
+    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()))
     dist.destroy_process_group()
 
 
@@ -86,5 +72,7 @@ def test_gradient_allreduce_gloo_world2():
         assert torch.allclose(ga, torch.full((5, 3), 1.5))
         assert torch.allclose(gb, torch.arange(7, dtype=torch.float32) * 1.5)
         assert gc is None
-    assert torch.allclose(out[0][3], out[1][3])
-    assert float(out[0][3].abs().sum()) > 0
+    for r in range(world):
+        xs, ys = out[r][3]
+        assert torch.equal(xs, torch.cat((torch.zeros(3, 8), torch.ones(3, 8))))
+        assert ys.tolist() == [0, 2, 3, 1, 2, 3]

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include "../../include/grl_hip.h"
 #include "common.h"
 
@@ -93,10 +94,11 @@ __device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int 
 // estimate), folded scale/shift for the apply pass.
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
     const float* __restrict__ slab, int rows, int C, double count, const float* gamma,
-    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* mean, float* invstd, float* scale, float* shift) {
+    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
     __shared__ double sh[2 * 16 * 64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     double s, q;
     slab_totals(slab, rows, C, c, sh, s, q);
     if ((threadIdx.x >> 6) != 0 || c >= C) return;
@@ -537,14 +539,14 @@ extern "C" int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, 
 }
 
 extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
-                                     const float* beta, float* running_mean, float* running_var, float momentum,
-                                     float eps, float* mean, float* invstd, float* scale, float* shift,
-                                     void* stream) {
+                                     const float* beta, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, float momentum, float eps, float* mean,
+                                     float* invstd, float* scale, float* shift, void* stream) {
     GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
     GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, slab,
-                       rows, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                       scale, shift);
+                       rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                       eps, mean, invstd, scale, shift);
     return grl_check_launch("grl_bn_stats_finalize");
 }
 
@@ -636,14 +638,33 @@ extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, 
     return grl_check_launch("grl_stem_im2col");
 }
 
+// How many private slabs the pixel range is split into.  The grid is tiles x splits workgroups
+// and the chip holds `slots` of them at once (two 64 KiB-LDS workgroups per CU for the 128-wide
+// tiles, four for 64 x 64): pick the split whose last round of workgroups is (nearly) full --
+// 576 workgroups on 512 slots run as long as 1024 -- while keeping enough K stages per
+// workgroup to amortise its prologue/epilogue and charging the reduce pass for every slab.
 static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
     const int64_t tiles = (int64_t)((d.N + bm - 1) / bm) * ((d.K + bn - 1) / bn);
-    static const int target = getenv("GRL_WGRAD_BLOCKS") ? atoi(getenv("GRL_WGRAD_BLOCKS")) : 512;   // tuning only
-    int64_t want = (target + tiles - 1) / tiles;
-    const int64_t max_splits = (d.M + 255) / 256;
-    if (want > max_splits) want = max_splits;
-    if (want < 1) want = 1;
-    return (int)want;
+    int64_t max_splits = (d.M + 255) / 256;
+    if (max_splits < 1) max_splits = 1;
+    if (const char* e = getenv("GRL_WGRAD_SPLITS")) {               // kernel tuning only
+        int64_t f = atoi(e);
+        return (int)(f < 1 ? 1 : (f > max_splits ? max_splits : f));
+    }
+    const double slots = (bm == 64 && bn == 64) ? 1024.0 : 512.0;
+    int64_t smax = (int64_t)(3.0 * slots / (double)tiles) + 1;
+    if (smax > max_splits) smax = max_splits;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int64_t s = 1; s <= smax; ++s) {
+        const double wgs = (double)tiles * (double)s;
+        const double rounds = ceil(wgs / slots);
+        const double stages = (double)d.M / (32.0 * (double)s);
+        // time ~ rounds x (stages + fixed per-workgroup cost) + slab reduce traffic (in stage units)
+        const double cost = rounds * (stages + 8.0) + 0.012 * (double)s * (double)tiles;
+        if (cost < best_cost * 0.999) { best_cost = cost; best = (int)s; }
+    }
+    return best;
 }
 
 static void wgrad_tile(const GrlWgrad& d, int* bm, int* bn) {

@@ -160,16 +160,16 @@ class _BNState(object):
 
 def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None):
     st = _BNState()
-    st.mean, st.invstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
-    st.scale, st.shift = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    buf = torch.empty((4, Cc), dtype=torch.float32, device=dev)
+    st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
     gamma = bn.weight if gamma is None else gamma
     beta = bn.bias if beta is None else beta
     rm = bn.running_mean if rm is None else rm
     rv = bn.running_var if rv is None else rv
+    # num_batches_tracked (torch's int64 counter) is bumped by the same launch
     _call('grl_bn_stats_finalize', ptr(slab), rows, Cc, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
-          C.c_float(bn.momentum), C.c_float(bn.eps), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift))
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+          ptr(bn.num_batches_tracked), C.c_float(bn.momentum), C.c_float(bn.eps), ptr(st.mean), ptr(st.invstd),
+          ptr(st.scale), ptr(st.shift))
     return st
 
 

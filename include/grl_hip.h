@@ -219,11 +219,12 @@ int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out,
 
 /* nn.BatchNorm forward in training mode, step 1: from a partial slab [rows][2][C]
  * (written by grl_conv_gemm_f32's `stats` or by grl_col_stats) to batch mean / invstd,
- * folded scale/shift and the running-stat update (momentum, unbiased running var). */
+ * folded scale/shift and the running-stat update (momentum, unbiased running var;
+ * num_batches_tracked, if given, is incremented -- torch's int64 buffer). */
 int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
-                          float momentum, float eps, float* mean, float* invstd, float* scale,
-                          float* shift, void* stream);
+                          int64_t* num_batches_tracked, float momentum, float eps, float* mean,
+                          float* invstd, float* scale, float* shift, void* stream);
 /* step 2: y = relu?(z*scale + shift + res) */
 int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res,
                  float* y, int64_t M, int C, int relu, void* stream);

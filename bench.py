@@ -171,7 +171,7 @@ def distmat_bench(args, dev, rank):
     (BASELINE configs[4]): -Q.G^T, Q [1980,6144], G [11310,6144], exact fp32 MFMA."""
     from grl_amd import engine
     from grl_amd.synthetic import synth_eval_features
-    qf, gf, *_ = synth_eval_features(1980, 11310, seed=1)
+    qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=6.0)
     qd, gd = qf.to(dev), gf.to(dev)
     for _ in range(args.warmup):
         d = engine.cosin_dist(qd, gd)
@@ -194,6 +194,25 @@ def distmat_bench(args, dev, rank):
     ref_idx = np.argsort(dh[:256], axis=1, kind='stable')
     host_s = (time.perf_counter() - t2) * 1980 / 256
     assert np.array_equal(idx[:256].cpu().numpy(), ref_idx)
+    # the rest of the evaluator on the device: per-query CMC / AP, and k-reciprocal re-ranking
+    from grl_amd.reid.evaluator.rerank import re_ranking
+
+    def timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, r
+    metrics_ms, (cmc, mAP) = timed(lambda: engine.rank_metrics(idx, qp, gp, qc, gc))
+    # (on Euclidean q-g distances, what the algorithm is defined on; the reference's evaluator
+    # hands it the NEGATED-cosine matrix, attevaluator.py:150-155 -- ATTEvaluator keeps that call)
+    dqq, dgg = engine.pairwise_distance_tensor(qd, qd), engine.pairwise_distance_tensor(gd, gd)
+    dqg = engine.pairwise_distance_tensor(qd, gd)
+    rerank_ms, rr = timed(lambda: re_ranking(dqg, dqq, dgg), n=2)
+    cmc_rr, map_rr = engine.rank_metrics(engine.rank_rows(rr), qp, gp, qc, gc)
+    del dqq, dgg, dqg, rr
     flops = 2.0 * 1980 * 11310 * 6144
     if rank == 0:
         print(json.dumps({"metric": "distance-matrix ms (1980x11310x6144)", "value": round(dt * 1e3, 3), "unit": "ms",
@@ -201,7 +220,11 @@ def distmat_bench(args, dev, rank):
                           "higher_is_better": False, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "cosin_dist at MARS size, BASELINE configs[4]",
                                      "row_argsort_ms_gpu": round(sort_ms, 3),
-                                     "row_argsort_s_numpy_1core_extrapolated": round(host_s, 2)},
+                                     "row_argsort_s_numpy_1core_extrapolated": round(host_s, 2),
+                                     "cmc_ap_ms_gpu": round(metrics_ms, 3),
+                                     "rerank_ms_gpu (13290^2 k-reciprocal, incl. its argsort)": round(rerank_ms, 2),
+                                     "synthetic mAP / Rank-1": [round(mAP, 4), round(float(cmc[0]), 4)],
+                                     "after re-ranking (Euclidean q-g)": [round(map_rr, 4), round(float(cmc_rr[0]), 4)]},
                           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2),
                                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": round(flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}}))

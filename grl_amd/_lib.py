@@ -98,6 +98,10 @@ _SIGNATURES = {
     'grl_pair_bce': ([_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
     'grl_scale_dev': ([_fp, _fp, C.c_float, _fp, _i64, _fp], C.c_int),
     'grl_rank_metrics': ([_fp, _i64, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_rerank_build': ([_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp], C.c_int),
+    'grl_rerank_krecip': ([_fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_rerank_expand': ([_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp], C.c_int),
+    'grl_rerank_jaccard': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp], C.c_int),
     'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_cast_bf16': ([_fp, _fp, _i64, _fp], C.c_int),
     'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),

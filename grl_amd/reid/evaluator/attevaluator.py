@@ -88,11 +88,15 @@ class ATTEvaluator(object):
         if not rerank and dist_dev.shape[1] <= 16384:
             return evaluate_seq(None, q_pids, q_camids, g_pids, g_camids, path,
                                 indices=engine.rank_rows(dist_dev))
-        indices = None
+        if rerank and qf.size(0) + gf.size(0) <= 16384:
+            print('Applying person re-ranking ...')            # entirely on the device
+            dist_dev = re_ranking(dist_dev, pairwise_distance_tensor(qf, qf), pairwise_distance_tensor(gf, gf))
+            return evaluate_seq(None, q_pids, q_camids, g_pids, g_camids, path,
+                                indices=engine.rank_rows(dist_dev))
         distmat = dist_dev.cpu().numpy()
-        if rerank:
+        if rerank:                                             # beyond one LDS sort network: host numpy
             print('Applying person re-ranking ...')
             distmat_qq = pairwise_distance_tensor(qf, qf).cpu().numpy()
             distmat_gg = pairwise_distance_tensor(gf, gf).cpu().numpy()
             distmat = re_ranking(distmat, distmat_qq, distmat_gg)
-        return evaluate_seq(distmat, q_pids, q_camids, g_pids, g_camids, path, indices=indices)
+        return evaluate_seq(distmat, q_pids, q_camids, g_pids, g_camids, path)

@@ -1,7 +1,12 @@
 """k-reciprocal re-ranking (Zhong et al., CVPR'17) with the reference's call signature
-and numerics (/root/reference/reid/evaluator/rerank.py:37-104): host-side numpy post-
-process of the q-g distance matrix, fed by the Euclidean q-q / g-g matrices that
-grl_amd.engine.pairwise_distance_tensor computes on the GPU.
+and numerics (/root/reference/reid/evaluator/rerank.py:37-104).
+
+Two entries behind one function:
+  * DEVICE tensors in -> the whole post-process runs on MI355X (grl_amd/csrc/rerank.hip:
+    build / row argsort / k-reciprocal sets / query expansion / Jaccard) and a device tensor
+    comes back; nothing of the (q+g)^2 problem touches the host;
+  * numpy arrays in -> the host numpy restatement below, as the reference runs it.
+Both are fed by the matrices grl_amd.engine computes on the GPU.
 
 Written from the algorithm, vectorised where the reference loops in Python:
   1. stack the four blocks into one (q+g)^2 matrix, square it, column-normalise by the
@@ -24,7 +29,49 @@ def _k_reciprocal(initial_rank, i, k):
     return fwd[np.where(back == i)[0]]
 
 
+def _re_ranking_device(q_g, q_q, g_g, k1, k2, lambda_value):
+    """The five launches of grl_amd/csrc/rerank.hip; every buffer is a torch device tensor."""
+    import ctypes as C
+    import torch
+    from grl_amd import _lib, engine
+    from grl_amd._lib import ptr
+    for t in (q_g, q_q, g_g):
+        _lib.require_device(t, 'distance matrix')
+    q_g, q_q, g_g = q_g.contiguous(), q_q.contiguous(), g_g.contiguous()
+    nq, ng = q_g.shape
+    if tuple(q_q.shape) != (nq, nq) or tuple(g_g.shape) != (ng, ng):
+        raise ValueError('re_ranking: q_q must be [%d,%d] and g_g [%d,%d]' % (nq, nq, ng, ng))
+    N, dev = nq + ng, q_g.device
+    if N > 16384:
+        raise _lib.GrlHipError('device re_ranking holds one row per LDS sort network: q + g <= 16384 (got %d)' % N)
+
+    def call(name, *args):
+        _lib.check(getattr(_lib.load(), name)(*args, _lib.stream()), name)
+    D = torch.empty((N, N), dtype=torch.float32, device=dev)
+    colmax = torch.empty(N, dtype=torch.float32, device=dev)
+    call('grl_rerank_build', ptr(q_g), ptr(q_q), ptr(g_g), nq, ng, ptr(D), ptr(colmax))
+    rank = engine.rank_rows(D)
+    V = torch.zeros((N, N), dtype=torch.float32, device=dev)
+    lcnt = torch.empty(N, dtype=torch.int32, device=dev)
+    lidx = torch.empty((N, 256), dtype=torch.int32, device=dev)
+    call('grl_rerank_krecip', ptr(D), ptr(rank), N, int(k1), ptr(V), ptr(lcnt), ptr(lidx))
+    V2T = torch.zeros((N, N), dtype=torch.float32, device=dev)
+    V2q = torch.zeros((nq, N), dtype=torch.float32, device=dev)
+    call('grl_rerank_expand', ptr(V), ptr(rank), ptr(lcnt), ptr(lidx), N, nq, int(k2), ptr(V2T), ptr(V2q))
+    del V, rank
+    out = torch.empty((nq, ng), dtype=torch.float32, device=dev)
+    call('grl_rerank_jaccard', ptr(V2q), ptr(V2T), ptr(D), N, nq, C.c_float(lambda_value),
+         C.c_float(1 - lambda_value), ptr(out))
+    return out
+
+
 def re_ranking(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3):
+    try:
+        import torch
+        if all(torch.is_tensor(t) and t.is_cuda for t in (q_g_dist, q_q_dist, g_g_dist)):
+            return _re_ranking_device(q_g_dist, q_q_dist, g_g_dist, k1, k2, lambda_value)
+    except ImportError:                                   # pragma: no cover
+        pass
     q_g_dist, q_q_dist, g_g_dist = (np.asarray(a, dtype=np.float32) for a in (q_g_dist, q_q_dist, g_g_dist))
     query_num = q_g_dist.shape[0]
     all_num = query_num + q_g_dist.shape[1]

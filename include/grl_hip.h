@@ -354,6 +354,27 @@ int grl_rank_metrics(const int32_t* idx, int64_t ld, const int32_t* q_pids, cons
                      const int32_t* g_pids, const int32_t* g_cams, int nq, int ng, int32_t* first_hit,
                      int32_t* n_hits, double* ap, void* stream);
 
+/* ---- k-reciprocal re-ranking on the device (reid/evaluator/rerank.py:37-104) ----
+ * N = nq + ng samples (<= 16384).  All matrices fp32 row-major, caller-owned:
+ *   D [N][N], rank int32 [N][N] (grl_row_argsort of D), V / V2T [N][N] and V2q [nq][N]
+ *   ZERO-FILLED by the caller, lcnt int32 [N], lidx int32 [N][256]. */
+/* :41-47  D[i][j] = S[j][i] / max_r S[r][i],  S = [[q_q, q_g], [q_g^T, g_g]] squared */
+int grl_rerank_build(const float* q_g, const float* q_q, const float* g_g, int nq, int ng, float* D,
+                     float* colmax_ws /* N floats */, void* stream);
+/* :55-75  k-reciprocal set of every sample (k1 <= 20), its 2/3-overlap expansion by the
+ * int(around(k1/2))-reciprocal sets, V[i][e] = exp(-D[i][e]) / sum (np.sum's pairwise order);
+ * lidx[i][0..lcnt[i]) = the sorted unique expansion indices */
+int grl_rerank_krecip(const float* D, const int32_t* rank, int N, int k1, float* V, int32_t* lcnt,
+                      int32_t* lidx, void* stream);
+/* :77-83  local query expansion V2[i] = mean_{t<k2} V[rank[i][t]] (k2 <= 8; k2 == 1: V itself),
+ * stored transposed V2T[e][i] and, for i < nq, as dense rows V2q[i][e] */
+int grl_rerank_expand(const float* V, const int32_t* rank, const int32_t* lcnt, const int32_t* lidx,
+                      int N, int nq, int k2, float* V2T, float* V2q, void* stream);
+/* :86-104 out[i][j-nq] = (1-lambda) * (1 - t/(2-t)) + lambda * D[i][j],
+ * t = sum over the non-zero k of V2[i] (ascending) of min(V2[i][k], V2[j][k]);  out [nq][ng] */
+int grl_rerank_jaccard(const float* V2q, const float* V2T, const float* D, int N, int nq,
+                       float lambda_value, float one_minus_lambda, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

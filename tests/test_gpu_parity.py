@@ -431,6 +431,29 @@ def test_rank_metrics_edge_cases():
                  indices=engine.rank_rows(torch.randn(2, 10).cuda()))
 
 
+def test_device_re_ranking_matches_reference_golden_and_numpy(golden):
+    """k-reciprocal re-ranking on the device (grl_amd/csrc/rerank.hip) against (a) the output of
+    the reference's own re_ranking on the stored input matrices and (b) the host numpy
+    restatement on larger structured inputs, incl. other (k1, k2, lambda) and k2 == 1."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.rerank import re_ranking
+    g = golden('rerank_q16_g120.npz')
+    out = re_ranking(torch.from_numpy(g['dist']).cuda(), torch.from_numpy(g['qq']).cuda(),
+                     torch.from_numpy(g['gg']).cuda())
+    assert out.is_cuda and tuple(out.shape) == (16, 120)
+    assert np.abs(out.cpu().numpy() - g['final']).max() < 2e-6
+    for (nq, ng, k1, k2, lam, seed) in ((48, 600, 20, 6, 0.3, 3), (33, 257, 7, 1, 0.5, 4), (20, 300, 12, 3, 0.1, 5)):
+        qf, gf, qp, qc, gp, gc = synth_eval_features(nq, ng, seed=seed, n_ids=40, noise=4.0)
+        qd, gd = qf.cuda(), gf.cuda()
+        d, dqq, dgg = engine.cosin_dist(qd, gd), engine.pairwise_distance_tensor(qd, qd), \
+            engine.pairwise_distance_tensor(gd, gd)
+        dev = re_ranking(d, dqq, dgg, k1=k1, k2=k2, lambda_value=lam).cpu().numpy()
+        host = re_ranking(d.cpu().numpy(), dqq.cpu().numpy(), dgg.cpu().numpy(), k1=k1, k2=k2, lambda_value=lam)
+        assert np.abs(dev - host).max() < 2e-6, (nq, ng, k1, k2)
+    with pytest.raises(ValueError):
+        re_ranking(d, dqq[:5], dgg)
+
+
 def test_raw_uint8_clips_are_normalised_on_the_device(gpu_models):
     """uint8 clips go straight to the stem, which applies ToTensor +
     Normalize while staging its input patch -- features are bit-identical to the float path

@@ -330,6 +330,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic if args.math == 'f32' else None,
+                         "traffic_note": "HBM bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) summed "
+                                         "over the kernel's launches of ONE step, like the GFLOP figure; "
+                                         "profiles/r01_gemm_pmc.json",
                          "kernel": "gemm_f32_kernel (%s MFMA implicit-GEMM conv), %d launches/step, "
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
                                        'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
@@ -356,6 +359,25 @@ def main():
                              "max_rel_dev_vs_headline_features": float(
                                  ((f2 - feat).abs().max() / feat.abs().max()).item())}
             out["alt_math"] = alt
+        if n == 1 and not args.no_alt:
+            # informational (never `value`): the same step fed from HOST-resident pinned batches through
+            # engine.DevicePrefetcher (next batch's PCIe copy overlapped on a side stream)
+            from grl_amd.synthetic import synth_clips as _sc
+            host = {}
+            for name, batch in (("f32", _sc(B, T, seed=0).pin_memory()), ("u8", _sc(B, T, seed=0, raw=True).pin_memory())):
+                def loader(k):
+                    for _ in range(k):
+                        yield batch, None, None
+                for d_, _, _ in engine.DevicePrefetcher(loader(3), dev):
+                    engine.extract_features(cnn, siam, d_)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for d_, _, _ in engine.DevicePrefetcher(loader(args.steps), dev):
+                    engine.extract_features(cnn, siam, d_)
+                torch.cuda.synchronize()
+                host[name] = round(B * args.steps / (time.perf_counter() - t1), 2)
+            out["host_resident_inputs"] = {"clip_features_per_sec": host,
+                                           "note": "pinned host batches, H2D overlapped; uint8 is normalised in the stem"}
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
         print(json.dumps(out))

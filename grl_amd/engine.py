@@ -624,6 +624,65 @@ def extract_features(cnn, siam, clips):
         return feat
 
 
+def rows_mean(x):
+    """[n, C] -> [1, C]: mean over rows (dense-mode clip average, attevaluator.py:96) through
+    grl_group_mean."""
+    require_device(x, 'features')
+    x = x.contiguous()
+    n, c = x.shape
+    y = _new((1, c), x)
+    _call('grl_group_mean', ptr(x), ptr(y), 1, n, c, c, C.c_float(1.0), 0)
+    return y
+
+
+class DevicePrefetcher(object):
+    """Iterates a loader of (imgs, pids, camids) with the NEXT batch's host->device copy in flight
+    on a side HIP stream while the current batch computes (pinned staging, non-blocking copy, an
+    event hands the buffer to the compute stream).  uint8 batches stay uint8 (the stem normalises
+    them, a quarter of the PCIe bytes); anything else is made float32 on the host, as
+    `imgs.to(device)` upstream (attevaluator.py:70,76)."""
+
+    def __init__(self, loader, device):
+        self.it = iter(loader)
+        self.dev = torch.device(device)
+        self.stream = torch.cuda.Stream(self.dev)
+        self._next = None
+        self._load()
+
+    def _load(self):
+        try:
+            imgs, pids, cams = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        if imgs.dtype not in (torch.uint8, torch.float32):
+            imgs = imgs.float()
+        if imgs.is_cuda:
+            self._next = (imgs, pids, cams, None, None)
+            return
+        host = imgs.contiguous()
+        host = host if host.is_pinned() else host.pin_memory()
+        with torch.cuda.stream(self.stream):
+            d = host.to(self.dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self._next = (d, pids, cams, ev, host)         # `host` kept alive until the copy is consumed
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        d, pids, cams, ev, _host = self._next
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(ev)
+            d.record_stream(cur)
+        self._load()
+        return d, pids, cams
+
+
 class GraphedExtractor(object):
     """`extract_features` captured once per input shape into a HIP graph (through
     torch.cuda.CUDAGraph: our launches go to torch's capturing stream) and replayed.

@@ -54,19 +54,19 @@ class ATTEvaluator(object):
         self.siamese_model.eval()
         dev = self._device()
         feats, pids_all, cams_all = [], [], []
-        for imgs, pids, camids in data_loader:
+        # the next batch's host->device copy overlaps this batch's kernels (side HIP stream)
+        for imgs, pids, camids in engine.DevicePrefetcher(data_loader, dev):
             if self.only_eval:
                 # dense mode: one tracklet per item, all its clips; features are averaged
                 # over clips (attevaluator.py:68-98)
                 b, n, s, c, h, w = imgs.size()
-                clips = imgs.view(b * n, s, c, h, w).to(dev, torch.float32)
+                clips = imgs.view(b * n, s, c, h, w)
                 parts = [engine.extract_features(self.cnn_model, self.siamese_model,
                                                  clips[y * self.chunk:(y + 1) * self.chunk])
                          for y in range(int(math.ceil(b * n / float(self.chunk))))]
-                feats.append(torch.cat(parts, 0).mean(dim=0, keepdim=True))
+                feats.append(engine.rows_mean(torch.cat(parts, 0)))
             else:
-                clips = imgs.to(dev, torch.float32)
-                feats.append(engine.extract_features(self.cnn_model, self.siamese_model, clips))
+                feats.append(engine.extract_features(self.cnn_model, self.siamese_model, imgs))
             pids_all.extend(pids)
             cams_all.extend(camids)
         return torch.cat(feats, 0), np.asarray(pids_all), np.asarray(cams_all)

@@ -565,3 +565,21 @@ def test_backward_is_linear_in_the_upstream_gradient():
     for k in grads[0]:
         assert torch.equal(grads[1][k], grads[0][k] * 2), k
         assert bool(torch.isfinite(grads[0][k]).all()), k
+
+
+def test_prefetcher_overlapped_h2d_gives_identical_features(gpu_models):
+    """engine.DevicePrefetcher (side-stream H2D of the next batch) feeds the same bytes: features of
+    host float32 / uint8 / already-resident batches equal the plain path bit for bit, in order."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    batches = [synth_clips(2, 4, seed=20 + i) for i in range(4)]
+    raw = [synth_clips(2, 4, seed=20 + i, raw=True) for i in range(4)]
+    want = [engine.extract_features(cnn, siam, b.cuda()) for b in batches]
+    for src in (batches, [b.pin_memory() for b in batches], raw, [b.cuda() for b in batches]):
+        got = []
+        for d, pid, cam in engine.DevicePrefetcher(((b, [i], [0]) for i, b in enumerate(src)), 'cuda:0'):
+            assert d.is_cuda and pid == [len(got)]
+            got.append(engine.extract_features(cnn, siam, d))
+        assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
+    m = engine.rows_mean(torch.cat(want, 0))
+    assert float((m - torch.cat(want, 0).mean(0, keepdim=True)).abs().max()) < 1e-6

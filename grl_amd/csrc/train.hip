@@ -192,7 +192,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ act, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ coef, float* __restrict__ dz, int C,
-                                    int64_t total4) {
+                                    int64_t total4, float* __restrict__ gres, int gres_accumulate) {
     const int C4 = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -202,6 +202,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        }
+        if (gres) {        // the residual branch receives the same masked gradient (y = relu(bn(z) + res))
+            f32x4 r = g;
+            if (gres_accumulate) r += reinterpret_cast<const f32x4*>(gres)[i];
+            reinterpret_cast<f32x4*>(gres)[i] = r;
         }
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 xh = (reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c)) * is;
@@ -280,9 +285,10 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
     }
 }
 
-// zero-stuffing for stride-2 data gradients: up[img][2oy][2ox][:] = dz[img][oy][ox][:]
+// zero-stuffing for stride-2 data gradients: up[img][2oy][2ox][:] = dz[img][oy][ox][:], zero
+// elsewhere; accumulate: up[img][2oy][2ox][:] += dz[...], every other element left as it is
 __global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__ up, int Ho, int Wo,
-                               int H, int W, int C4, int64_t total4) {
+                               int H, int W, int C4, int64_t total4, int accumulate) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = i % C4;
@@ -291,8 +297,12 @@ __global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__
         const int y = r % H;
         const int img = r / H;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
-            v = reinterpret_cast<const f32x4*>(dz)[(((int64_t)img * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c];
+        const bool hit = !(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo;
+        if (hit) v = reinterpret_cast<const f32x4*>(dz)[(((int64_t)img * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c];
+        if (accumulate) {
+            if (!hit) continue;
+            v += reinterpret_cast<const f32x4*>(up)[i];
+        }
         reinterpret_cast<f32x4*>(up)[i] = v;
     }
 }
@@ -561,7 +571,8 @@ extern "C" int grl_bn_apply(const float* z, const float* scale, const float* shi
 
 extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                           const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
-                          float* slab_ws, float* coef_ws, int M, int C, void* stream) {
+                          float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
+                          void* stream) {
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
@@ -571,7 +582,7 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
                        (double)M, dgamma, dbeta, coef_ws);
     const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
-                       coef_ws, dz, C, total4);
+                       coef_ws, dz, C, total4, gres, gres_accumulate);
     return grl_check_launch("grl_bn_bwd");
 }
 
@@ -613,11 +624,12 @@ extern "C" int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, i
     return grl_check_launch("grl_pack_dgrad_weight");
 }
 
-extern "C" int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, void* stream) {
+extern "C" int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
+                           void* stream) {
     GRL_REQUIRE(dz && up && n > 0 && C % 4 == 0, "dilate2: bad args");
     const int64_t total4 = (int64_t)n * H * W * (C / 4);
     hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dz, up, Ho, Wo, H, W,
-                       C / 4, total4);
+                       C / 4, total4, accumulate);
     return grl_check_launch("grl_dilate2");
 }
 

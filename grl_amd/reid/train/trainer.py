@@ -44,7 +44,11 @@ class BaseTrainer(object):
         batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
         precisions, precisions1, precisions2 = AverageMeter(), AverageMeter(), AverageMeter()
         end = time.time()
-        for i, inputs in enumerate(data_loader):
+        from grl_amd import engine
+        batches = data_loader
+        if torch.device(self.device).type == 'cuda':     # next batch's H2D copy under this step's kernels
+            batches = engine.DevicePrefetcher(data_loader, self.device)
+        for i, inputs in enumerate(batches):
             data_time.update(time.time() - end)
             inputs, targets = self._parse_data(inputs)
             loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame = \

@@ -173,13 +173,15 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
-def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc):
+def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0):
+    """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
+    same pass that writes dz)."""
     dz = _new((M, Cc), dy)
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Cc), dy)
     coef = _new((2, Cc), dy)
     _call('grl_bn_bwd', ptr(dy), ptr(z), ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma), ptr(dz),
-          ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc)
+          ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc)
     return dz
 
 
@@ -215,9 +217,14 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
         if da is None:
             return
         act = a if relu else None
-        if res is not None:
-            tp.add_masked(res, da, act)
-        dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N)
+        gres, gacc = None, 0
+        if res is not None:                 # grad(res) (+)= da * (a > 0), written by the BN apply pass
+            gres = tp.g.get(id(res))
+            gacc = 1 if gres is not None else 0
+            if gres is None:
+                gres = tp.g[id(res)] = _new((M, N), da)
+        dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
+                         gres=gres, gres_acc=gacc)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
                                    kcols=kcols, ldw=ldw)
         if gbias is not None:
@@ -248,17 +255,20 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     if k == 1:
         w2d = w.detach().view(N, -1)
         wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1])
-        src = dz
         if stride != 1:
-            src = _new((Min, N), dz)
-            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
-        gemm(src, wt, dx, Min, cin, N, res=cur)
+            # a 1x1 stride-2 conv only reads the even pixels: its data gradient is a GEMM at OUTPUT
+            # resolution scattered to them (a quarter of the zero-stuffed GEMM's FLOPs)
+            small = _new((M, cin), dz)
+            gemm(dz, wt, small, M, cin, N)
+            _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin, 1 if cur is not None else 0)
+        else:
+            gemm(dz, wt, dx, Min, cin, N, res=cur)
     else:
         wd = tp.w_dgrad(conv)
         src = dz
         if stride != 1:
             src = _new((Min, N), dz)
-            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N)
+            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N, 0)
         gemm(src, wd, dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
     if cur is None:
         tp.g[id(x)] = dx

@@ -231,10 +231,13 @@ int grl_bn_apply(const float* z, const float* scale, const float* shift, const f
 
 /* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask);
  * dgamma += sum g*xhat; dbeta += sum g; dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
- * slab_ws: grl_col_stats_rows(M)*2*C floats, coef_ws: 2*C floats. gamma/dgamma/dbeta may be NULL. */
+ * slab_ws: grl_col_stats_rows(M)*2*C floats, coef_ws: 2*C floats. gamma/dgamma/dbeta may be NULL.
+ * gres (may be NULL): gradient of the residual input of y = relu(bn(z) + res), which is the same
+ * masked g: gres (+)= g in the same pass (resnets1.py:88-91). */
 int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
-               float* slab_ws, float* coef_ws, int M, int C, void* stream);
+               float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
+               void* stream);
 
 /* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
 int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);
@@ -249,8 +252,11 @@ int grl_axpy_strided(float* dst, int64_t dst_stride, const float* src, int64_t s
 int grl_transpose(const float* x, float* y, int R, int C, int ldx, void* stream);
 /* [N][C][kh][kw] -> [C][flipped tap][N]: data gradient of a kxk conv as a conv over dz */
 int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream);
-/* zero-stuffing of a stride-2 conv's output gradient: up[img][2oy][2ox] = dz[img][oy][ox] */
-int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, void* stream);
+/* zero-stuffing of a stride-2 conv's output gradient: up[img][2oy][2ox] = dz[img][oy][ox], zero
+ * elsewhere; accumulate != 0: up[img][2oy][2ox] += dz[...] and nothing else is touched (the data
+ * gradient of a 1x1 stride-2 conv is computed at OUTPUT resolution and scattered this way) */
+int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
+                void* stream);
 /* nn.MaxPool2d(3,2,1) backward (first-maximum rule, deterministic gather form) */
 int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
                          void* stream);

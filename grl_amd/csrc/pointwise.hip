@@ -549,16 +549,25 @@ __global__ __launch_bounds__(256) void pair_verify_kernel(
 // as one LDS bitonic network per row: (key, index) pairs, ascending, ties broken by the
 // smaller index (np.argsort(kind='stable') order; numpy's default introsort leaves ties
 // unspecified).  One workgroup of 1024 lanes per row, n <= 16384 (128 KiB of LDS).
+// Keys are compared as order-preserving unsigned integers so that the comparator is a strict
+// total order for every input: -0 == +0, NaN (any sign) sorts after +inf as in numpy, and the
+// padding of the network after every real element -- the output is always a permutation of 0..n-1.
 constexpr int SORT_MAX = 16384;
+__device__ __forceinline__ unsigned sort_key(float v) {
+    unsigned u = __float_as_uint(v);
+    if (v != v) u = 0x7fc00000u;                       // canonical NaN
+    else if (v == 0.f) u = 0u;                         // -0 -> +0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 __global__ __launch_bounds__(1024) void row_argsort_kernel(const float* __restrict__ d, int64_t ld,
                                                            int n, int P, int* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm_sort[];
-    float* key = sm_sort;                                   // [P]
+    extern __shared__ __attribute__((aligned(16))) unsigned sm_sort[];
+    unsigned* key = sm_sort;                                // [P]
     int* idx = reinterpret_cast<int*>(sm_sort + P);         // [P]
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* dr = d + (int64_t)row * ld;
     for (int i = tid; i < P; i += 1024) {
-        key[i] = i < n ? dr[i] : INFINITY;
+        key[i] = i < n ? sort_key(dr[i]) : 0xffffffffu;
         idx[i] = i < n ? i : 0x7fffffff;
     }
     __syncthreads();
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(1024) void row_argsort_kernel(const float* __restri
             for (int t = tid; t < (P >> 1); t += 1024) {
                 const int i = 2 * j * (t / j) + (t % j), l = i + j;
                 const bool asc = (i & k) == 0;
-                const float ki = key[i], kl = key[l];
+                const unsigned ki = key[i], kl = key[l];
                 const int ii = idx[i], il = idx[l];
                 const bool gt = ki > kl || (ki == kl && ii > il);          // element i after element l?
                 if (gt == asc) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }

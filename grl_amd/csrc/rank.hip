@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t* __rest
     for (int base = 0; base < ng; base += 256) {
         const int t = base + tid;
         bool keep = false, hit = false;
-        if (t < ng) {
+        if (t < ng && (unsigned)row[t] < (unsigned)ng) {          // (a corrupt index is dropped, never read through)
             const int g = row[t];
             const bool same = g_pids[g] == qp;
             keep = !(same && g_cams[g] == qc);

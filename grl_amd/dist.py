@@ -42,6 +42,33 @@ def gather_rank_order(x, y, group=None):
     return torch.cat(xl), torch.cat(yl)
 
 
+def shard_rows(n, rank, world):
+    """[lo, hi) of this rank's contiguous block of n rows (blocks differ by at most one row)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sharded_distmat(qf, gf, fn, group=None):
+    """The evaluator's query x gallery matrix with the gallery rows sharded over the ranks
+    (SURVEY.md 8(e)): every rank runs ``fn(qf, gf[lo:hi])`` -- an independent GEMM, e.g.
+    engine.cosin_dist -- and the column blocks are all-gathered (RCCL on the GPU node).  All ranks
+    hold the full qf / gf; identity when not distributed."""
+    if not is_distributed():
+        return fn(qf, gf)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ng = gf.size(0)
+    lo, hi = shard_rows(ng, rank, world)
+    width = -(-ng // world)                           # equal-sized padded blocks for all_gather
+    block = qf.new_zeros((qf.size(0), width))
+    if hi > lo:
+        block[:, :hi - lo] = fn(qf, gf[lo:hi].contiguous())
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block, group=group)
+    cols = [blocks[r][:, :shard_rows(ng, r, world)[1] - shard_rows(ng, r, world)[0]] for r in range(world)]
+    return torch.cat(cols, 1)
+
+
 class GradBucket(object):
     """Flat gradient bucket.  Parameters that never receive a gradient on any rank
     (Siamese.featV*, the unused uncorr verification head) contribute zeros so the

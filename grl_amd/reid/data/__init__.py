@@ -11,14 +11,15 @@ from grl_amd.synthetic import synth_clips
 class SyntheticPairs(Dataset):
     """`n_pairs` x 2 clips; both clips of a pair share the pid, cameras differ."""
 
-    def __init__(self, n_pairs, seq_len, num_classes=625, seed=0):
+    def __init__(self, n_pairs, seq_len, num_classes=625, seed=0, raw=False):
         self.n, self.t, self.k, self.seed = 2 * n_pairs, seq_len, num_classes, seed
+        self.raw = raw          # uint8 pixels (normalised on the device) instead of float32
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
-        clip = synth_clips(1, self.t, seed=self.seed * 100003 + i)[0]
+        clip = synth_clips(1, self.t, seed=self.seed * 100003 + i, raw=self.raw)[0]
         return clip, (i // 2 * 7919 + self.seed) % self.k, i % 2
 
 

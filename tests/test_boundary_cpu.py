@@ -30,6 +30,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.grl_abi_version() == 1
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every prototype in include/grl_hip.h against grl_amd/_lib.py's argtypes: same parameter
+    count, and pointer / integer / float kinds in the same positions (catches ABI drift between
+    the header, the .so and the binding)."""
+    import ctypes as C
+    from grl_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'grl_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = re.findall(r'\b(?:int|int64_t|const char\*)\s+(grl_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S)
+    assert len(protos) >= 60
+    sig = _lib._SIGNATURES
+    checked = 0
+    for name, args in protos:
+        params = [a.strip() for a in args.split(',')] if args.strip() not in ('', 'void') else []
+        if name == 'grl_last_error':                       # bound by hand in _lib.load()
+            checked += 1
+            continue
+        assert name in sig, 'no ctypes signature for %s' % name
+        argtypes = sig[name][0]
+        assert len(argtypes) == len(params), '%s: header has %d parameters, _lib.py %d' % (name, len(params), len(argtypes))
+        for prm, ct in zip(params, argtypes):
+            if '*' in prm:
+                kind = 'ptr'
+            elif re.match(r'(const\s+)?float\b', prm):
+                kind = 'float'
+            elif re.match(r'(const\s+)?int64_t\b', prm):
+                kind = 'i64'
+            else:
+                kind = 'int'
+            got = ('ptr' if ct in (C.c_void_p,) or (isinstance(ct, type) and issubclass(ct, C._Pointer))
+                   else 'float' if ct is C.c_float else 'i64' if ct is C.c_int64 else 'int' if ct is C.c_int else '?')
+            assert kind == got, '%s: parameter "%s" is %s in the header, %s in _lib.py' % (name, prm, kind, got)
+        checked += 1
+    assert checked == len(protos)
+
+
 def test_bad_descriptor_is_rejected_without_a_gpu():
     # argument validation happens before any HIP call
     import ctypes as C

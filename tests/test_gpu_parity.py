@@ -431,6 +431,34 @@ def test_rank_metrics_edge_cases():
                  indices=engine.rank_rows(torch.randn(2, 10).cuda()))
 
 
+def test_row_argsort_is_a_total_order_on_special_values():
+    """NaN (either sign), +-inf, -0.0 / +0.0 and repeated values: the device argsort returns a
+    permutation in np.argsort(kind='stable') order (NaN last, -0 == +0), never an out-of-range
+    index, and grl_rank_metrics on top of it matches the host loop."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    rng = np.random.default_rng(9)
+    for n in (5, 48, 64, 300, 1025):
+        d = rng.standard_normal((7, n)).astype(np.float32)
+        d[0, :] = np.nan
+        d[1, ::3] = np.nan
+        d[1, 1::5] = -np.nan
+        d[2, ::2] = np.inf
+        d[2, 1::4] = -np.inf
+        d[3, ::2] = 0.0
+        d[3, 1::2] = -0.0
+        d[4, :] = np.round(d[4] * 2) / 2               # many exact ties
+        d[5, n // 2] = np.nan
+        idx = engine.rank_rows(torch.from_numpy(d).cuda()).cpu().numpy()
+        assert np.array_equal(np.sort(idx, axis=1), np.tile(np.arange(n), (7, 1)))
+        assert np.array_equal(idx, np.argsort(d, axis=1, kind='stable'))
+    qp, gp = rng.integers(0, 4, 7), rng.integers(0, 4, n)
+    qc, gc = rng.integers(0, 2, 7), rng.integers(0, 2, n)
+    cmc_h, map_h = evaluate(d, qp, gp, qc, gc, indices=idx)
+    cmc_d, map_d = evaluate(None, qp, gp, qc, gc, indices=engine.rank_rows(torch.from_numpy(d).cuda()))
+    assert np.array_equal(cmc_h, cmc_d) and abs(map_h - map_d) < 1e-12
+
+
 def test_device_re_ranking_matches_reference_golden_and_numpy(golden):
     """k-reciprocal re-ranking on the device (grl_amd/csrc/rerank.hip) against (a) the output of
     the reference's own re_ranking on the stored input matrices and (b) the host numpy
@@ -505,6 +533,22 @@ def test_reference_script_flow_through_dropin(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'), map_location='cpu', weights_only=False)
     assert set(ck) == {'state_dict', 'epoch', 'best_top1'} and len(ck['state_dict']) == 401
     assert all(k.startswith('module.') for k in ck['state_dict'])
+    # test_all.py's flow: the checkpoints just written load back (their BN running statistics are
+    # two steps old, so the metrics of that run mean nothing), then with the deterministic synthetic
+    # weights: rrs-test and dense mode, re-ranking, float and raw-uint8 loaders print the same lines
+    ev = os.path.join(root, 'examples', 'eval_synthetic.py')
+    base = [sys.executable, ev, '--queries', '8', '--gallery', '40', '--seq_len', '2']
+    r = subprocess.run(base + ['--cnn_ckpt', os.path.join(str(tmp_path), 'cnnmodel_best.pth.tar'),
+                               '--siamese_ckpt', os.path.join(str(tmp_path), 'siamesemodel_best.pth.tar')],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'Rank-1:' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    seen = {}
+    for extra in ([], ['--uint8'], ['--rerank'], ['--dense'], ['--dense', '--uint8']):
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert 'Mean AP:' in r.stdout and 'Rank-1:' in r.stdout
+        seen[tuple(extra)] = [l for l in r.stdout.splitlines() if l.startswith(('Mean AP', 'Rank-'))]
+    assert seen[()] == seen[('--uint8',)] and seen[('--dense',)] == seen[('--dense', '--uint8')]
 
 
 def test_trainer_loss_composition_matches_cpu_restatement():

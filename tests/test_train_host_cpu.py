@@ -30,6 +30,15 @@ def test_losses_refuse_cpu_tensors():
         TripletLoss('soft', False)(torch.randn(4, 8), ids)
 
 
+def test_shard_rows():
+    from grl_amd.dist import shard_rows
+    for n, w in ((11310, 8), (7, 3), (2, 4), (16, 4)):
+        spans = [shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
 def test_shard_pairs():
     from grl_amd.dist import shard_pairs
     assert [shard_pairs(32, r, 4) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
@@ -45,7 +54,7 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from grl_amd.dist import GradBucket, is_distributed, gather_rank_order
+    from grl_amd.dist import GradBucket, is_distributed, gather_rank_order, sharded_distmat
     assert is_distributed()
     torch.manual_seed(0)
     a, b, c = (torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
@@ -58,7 +67,11 @@ def _worker(rank, world, port, out):
     x = torch.full((3, 8), float(rank))
     y = torch.tensor([rank, 2, 3])
     xs, ys = gather_rank_order(x, y)
-    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()))
+    # gallery-sharded distance matrix (the per-block GEMM is a stand-in here: no GPU on this box)
+    g = torch.Generator().manual_seed(3)
+    qf, gf = torch.randn(5, 16, generator=g), torch.randn(11, 16, generator=g)
+    dm = sharded_distmat(qf, gf, lambda q, gg: -q.mm(gg.t()))
+    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone())
     dist.destroy_process_group()
 
 
@@ -68,7 +81,10 @@ def test_gradient_allreduce_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
-        ga, gb, gc, _ = out[r]
+        ga, gb, gc, _, dm = out[r]
+        g = torch.Generator().manual_seed(3)
+        qf, gf = torch.randn(5, 16, generator=g), torch.randn(11, 16, generator=g)
+        assert torch.equal(dm, -qf.mm(gf.t()))
         assert torch.allclose(ga, torch.full((5, 3), 1.5))
         assert torch.allclose(gb, torch.arange(7, dtype=torch.float32) * 1.5)
         assert gc is None

@@ -84,7 +84,7 @@ _SIGNATURES = {
                               C.c_int, _fp], C.c_int),
     'grl_pair_sqdiff': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_pair_sqdiff_bwd': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp], C.c_int),
-    'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
+    'grl_oim_update': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp], C.c_int),
     'grl_softmax_ce': ([_fp, _i64, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _i64, _fp, _fp], C.c_int),
     'grl_oim_grad': ([_fp, _i64, _fp, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_triplet_fwd': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp], C.c_int),

@@ -304,10 +304,11 @@ __global__ void pair_sqdiff_bwd_kernel(const float* __restrict__ p, const float*
 __global__ __launch_bounds__(256) void oim_update_kernel(float* __restrict__ lut,
                                                          const float* __restrict__ x,
                                                          const int64_t* __restrict__ labels, int n,
-                                                         int D, float m) {
+                                                         int D, int num_classes, float m) {
     __shared__ float red[16];
     const int i = blockIdx.x;
     const int64_t y = labels[i];
+    if (y < 0 || y >= num_classes) return;                // a label outside the table updates nothing
     for (int j = 0; j < i; ++j)
         if (labels[j] == y) return;                       // not the first sample of this label
     float* row = lut + y * (int64_t)D;
@@ -418,9 +419,10 @@ extern "C" int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* 
     return grl_check_launch("grl_pair_sqdiff_bwd");
 }
 
-extern "C" int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, float momentum,
-                              void* stream) {
-    GRL_REQUIRE(lut && x && labels && n > 0 && D % 4 == 0, "oim_update: bad args");
-    hipLaunchKernelGGL(oim_update_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, lut, x, labels, n, D, momentum);
+extern "C" int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, int num_classes,
+                              float momentum, void* stream) {
+    GRL_REQUIRE(lut && x && labels && n > 0 && D % 4 == 0 && num_classes > 0, "oim_update: bad args");
+    hipLaunchKernelGGL(oim_update_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, lut, x, labels, n, D, num_classes,
+                       momentum);
     return grl_check_launch("grl_oim_update");
 }

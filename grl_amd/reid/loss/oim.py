@@ -74,7 +74,7 @@ class OIM(autograd.Function):
                   ptr(grad_inputs), n, lut.size(0), D)
         from grl_amd import dist as grl_dist
         xs, ys = grl_dist.gather_rank_order(x, y)
-        _call('grl_oim_update', ptr(lut), ptr(xs), ptr(ys), xs.size(0), D, C.c_float(m))
+        _call('grl_oim_update', ptr(lut), ptr(xs), ptr(ys), xs.size(0), D, lut.size(0), C.c_float(m))
         return grad_inputs, None, None, None, None, None
 
 

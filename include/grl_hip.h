@@ -310,9 +310,10 @@ int grl_pair_sqdiff_bwd(const float* p, const float* g, const float* ddiff, floa
                         int np, int ng, int K, void* stream);
 
 /* OIM look-up-table update performed inside OIM.backward (reid/loss/oim.py:24-26): per sample,
- * in batch order, lut[y] = m*lut[y] + (1-m)*x, then renormalise the row.  labels: int64. */
-int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, float momentum,
-                   void* stream);
+ * in batch order, lut[y] = m*lut[y] + (1-m)*x, then renormalise the row.  labels: int64; a
+ * label outside [0, num_classes) updates nothing (lut is [num_classes][D]). */
+int grl_oim_update(float* lut, const float* x, const int64_t* labels, int n, int D, int num_classes,
+                   float momentum, void* stream);
 
 /* ---- the trainer's loss block, forward and backward on the device ---- */
 /* F.cross_entropy of OIMLoss.forward (reid/loss/oim.py:52; mean reduction, optional class

@@ -256,3 +256,23 @@ def test_pair_prob_and_bce_forward_backward():
     assert abs(la.item() - lb.item()) < 1e-5 * max(1.0, abs(la.item()))
     assert abs(float(pa) - float(pb)) < 1e-6
     assert _rel(sb.grad.cpu().numpy(), sa.grad.numpy()) < 2e-5
+
+
+def test_oim_out_of_range_labels_do_not_touch_memory():
+    """A label outside [0, num_classes) is ignored by the cross entropy (torch's ignore_index
+    convention) and by the LUT update: nothing is read or written out of bounds."""
+    from grl_amd.reid.loss import OIMLoss
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    crit = OIMLoss(64, 6, scalar=10, momentum=0.5).to(dev)
+    crit.lut.copy_(F.normalize(torch.randn(6, 64), dim=1))
+    before = crit.lut.clone()
+    x = F.normalize(torch.randn(5, 64), dim=1).to(dev).requires_grad_(True)
+    y = torch.tensor([2, 10 ** 6, -100, 2, 5], device=dev)
+    loss, _ = crit(x, y)
+    loss.backward()
+    ref = F.cross_entropy((x.detach().cpu().mm(before.cpu().t()) * 10)[[0, 3, 4]], torch.tensor([2, 2, 5]))
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert torch.isfinite(x.grad).all() and float(x.grad[1].abs().max()) == 0 and float(x.grad[2].abs().max()) == 0
+    changed = (crit.lut != before).any(1).cpu().tolist()
+    assert changed == [False, False, True, False, False, True]

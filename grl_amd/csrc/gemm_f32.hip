@@ -72,46 +72,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     char* const Ah = reinterpret_cast<char*>(smem);                // [2][PL][BM][64 B]
     char* const Bh = Ah + 2 * PL * BM * 64;                        // [2][PL][BN][64 B]
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch);
-    // give each XCD a contiguous run of tiles so that the W panel / A panel re-reads
-    // of neighbouring tiles hit that XCD's L2.
-    int bid = blockIdx.x;
-    {
-        const int q = num_tiles >> 3, r = num_tiles & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
 
-    // ---- per-thread staging rows --------------------------------------------
+    // Persistent workgroups: the grid holds as many workgroups as the chip keeps resident and
+    // each walks tiles t = blockIdx.x, + gridDim.x, ...  The next tile's first K stage is
+    // requested from HBM BEFORE the current tile's epilogue runs, so a tile no longer starts
+    // with an exposed global-load latency (a quarter of the time of a K = 256 tile).
+    //
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch; gridDim.x is
+    // a multiple of 8 whenever a workgroup has more than one tile); give each XCD a contiguous
+    // run of tiles so that the W panel / A panel re-reads of neighbouring tiles hit that XCD's L2.
     RowInfo ai[A_ITEMS];
-#pragma unroll
-    for (int i = 0; i < A_ITEMS; ++i) {
-        int m = m0 + ld_row + 32 * i;
-        m = m < p.M ? m : p.M - 1;                    // clamp: edge rows are never stored
-        if (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int img = m / hw, rem = m - img * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            ai[i].base = (int64_t)img * p.H * p.W * p.C;
-            ai[i].iy0 = oy * p.stride - p.pad;
-            ai[i].ix0 = ox * p.stride - p.pad;
-        } else {
-            ai[i].base = (int64_t)m * p.lda;
-            ai[i].iy0 = ai[i].ix0 = 0;
-        }
-    }
     int64_t bofs[B_ITEMS];
+    int m0, n0, tile_m;
+    auto setup_tile = [&](int t) {
+        int bid = t;
+        {
+            const int q = num_tiles >> 3, r = num_tiles & 7, xcd = bid & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
+        tile_m = bid / tiles_n;
+        const int tile_n = bid - tile_m * tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        // ---- per-thread staging rows ----------------------------------------
 #pragma unroll
-    for (int i = 0; i < B_ITEMS; ++i) {
-        int n = n0 + ld_row + 32 * i;
-        n = n < p.N ? n : p.N - 1;
-        bofs[i] = (int64_t)n * p.ldw;
-    }
+        for (int i = 0; i < A_ITEMS; ++i) {
+            int m = m0 + ld_row + 32 * i;
+            m = m < p.M ? m : p.M - 1;                    // clamp: edge rows are never stored
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                ai[i].base = (int64_t)img * p.H * p.W * p.C;
+                ai[i].iy0 = oy * p.stride - p.pad;
+                ai[i].ix0 = ox * p.stride - p.pad;
+            } else {
+                ai[i].base = (int64_t)m * p.lda;
+                ai[i].iy0 = ai[i].ix0 = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i) {
+            int n = n0 + ld_row + 32 * i;
+            n = n < p.N ? n : p.N - 1;
+            bofs[i] = (int64_t)n * p.ldw;
+        }
+    };
 
     f32x4 areg[A_ITEMS], breg[B_ITEMS];
     auto load_stage = [&](int ks) {
@@ -177,6 +186,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         }
     };
 
+    const int nk = p.K / KST;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int col_l = lane & 31;
+
+    int t = blockIdx.x;
+    setup_tile(t);
+    load_stage(0);
+    for (;;) {
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -185,10 +202,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / KST;
-    const int frow = lane & 31, fhalf = lane >> 5;
-
-    load_stage(0);
     store_stage(0);
     __syncthreads();
 
@@ -283,10 +296,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         __syncthreads();
     }
 
+    // the K loop ended on a barrier: stage registers and LDS are free.  Request the NEXT tile's
+    // first stage now (its row tables replace this tile's, which the epilogue does not use).
+    const int cur_m0 = m0, cur_n0 = n0, cur_tile_m = tile_m;
+    const int next_t = t + (int)gridDim.x;
+    if (next_t < num_tiles) {
+        setup_tile(next_t);
+        load_stage(0);
+    }
+
     // ---- epilogue --------------------------------------------------------------
     // acc[i][j][r] is Y[row][col] with row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31
-    const int col_l = lane & 31;
-
+    auto epilogue = [&](const int m0, const int n0, const int tile_m) {
     if (vec_epi) {
         // Wide path (N, ldy, ldres multiples of 4, 16-B aligned bases): each wave parks its
         // sub-tile in LDS (the A/B stages are dead: the K loop ended on a barrier) and
@@ -467,6 +488,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             }
         }
     }
+    };
+    epilogue(cur_m0, cur_n0, cur_tile_m);
+    if (next_t >= num_tiles) break;
+    t = next_t;
+    __syncthreads();          // every wave is done with the C staging before the stages are rewritten
+    }
 }
 
 struct TileChoice { int bm, bn; };
@@ -495,6 +522,26 @@ TileChoice choose_tile(const GrlGemm& d) {
     return {64, 64};
 }
 
+// Workgroups the chip keeps resident for one kernel instantiation = the persistent grid
+// (CUs x occupancy, a multiple of 8 so that a workgroup's tiles stay on its XCD's run).
+// GRL_GEMM_GRID overrides it (kernel tuning only; 0 = one workgroup per tile).
+int resident_workgroups(const void* kernel, size_t lds) {
+    if (lds > 65536) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const char* e = getenv("GRL_GEMM_GRID")) {
+        const int g = atoi(e);
+        return g > 0 ? (g + 7) / 8 * 8 : 0x7fffffff;
+    }
+    int dev = 0, cus = 256, occ = 2;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds) != hipSuccess || occ < 1) occ = 2;
+    (void)hipGetLastError();
+    return (cus * occ + 7) / 8 * 8;
+}
+
 template <int BM, int BN, int MATH>
 int launch_math(const GrlGemm& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -511,12 +558,14 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
         return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
     if (d.conv) {
         auto k = gemm_f32_kernel<BM, BN, true, MATH>;
-        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
+        static const int slots = resident_workgroups((const void*)k, lds);
+        hipLaunchKernelGGL(k, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
+                           vec_epi);
     } else {
         auto k = gemm_f32_kernel<BM, BN, false, MATH>;
-        if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles), dim3(256), lds, s, d, tiles_n, num_tiles, vec_epi);
+        static const int slots = resident_workgroups((const void*)k, lds);
+        hipLaunchKernelGGL(k, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
+                           vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
 }

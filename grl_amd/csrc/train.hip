@@ -310,47 +310,75 @@ __global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__
 // max-pool 3x3/s2/p1 backward, gather form (deterministic): an input pixel receives
 // dy of every window in which it is the FIRST maximum in (ky,kx) scan order -- the
 // element torch.nn.MaxPool2d records as argmax.
+// One lane per 2x2 block of input pixels (x 4 channels): the block touches the four windows
+// (a..a+1, b..b+1), whose union is a 5x5 input patch -- every window's first maximum is found
+// once (9 compares) instead of once per input pixel it covers.
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                    float* __restrict__ dx, int H, int W, int C4, int64_t total4) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C = C4 * 4;
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;           // 2x2 input blocks
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         int64_t r = i / C4;
-        const int ix = r % W; r /= W;
-        const int iy = r % H;
-        const int img = r / H;
+        const int b = r % Wb; r /= Wb;
+        const int a = r % Hb;
+        const int img = r / Hb;
         const float* xi = x + (int64_t)img * H * W * C + c;
-        const f32x4 me = *reinterpret_cast<const f32x4*>(xi + ((int64_t)iy * W + ix) * C);
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        // windows (oy, ox) with 2*o-1 <= i <= 2*o+1:  o in [i>>1, (i+1)>>1]
-        for (int oy = iy >> 1; oy <= ((iy + 1) >> 1); ++oy) {
+        f32x4 g[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) g[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // windows (oy, ox) in {a, a+1} x {b, b+1}; window o covers inputs 2o-1 .. 2o+1
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            const int oy = a + wy;
             if (oy >= Ho) continue;
-            for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox) {
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int ox = b + wx;
                 if (ox >= Wo) continue;
-                // is (iy,ix) the first max of window (oy,ox)?
-                bool first[4] = {true, true, true, true};
+                // first maximum of the window in (ky, kx) scan order, per channel
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int by[4] = {-1, -1, -1, -1}, bx[4] = {-1, -1, -1, -1};
+#pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int yy = oy * 2 - 1 + ky;
                     if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        if (yy == iy && xx == ix) continue;
                         const f32x4 o = *reinterpret_cast<const f32x4*>(xi + ((int64_t)yy * W + xx) * C);
-                        const bool before = (yy < iy) || (yy == iy && xx < ix);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (o[e] > me[e] || (before && o[e] == me[e])) first[e] = false;
+                            if (o[e] > best[e] || by[e] < 0) { best[e] = o[e]; by[e] = yy; bx[e] = xx; }
                     }
                 }
                 const f32x4 d = *reinterpret_cast<const f32x4*>(
                     dy + (((int64_t)img * Ho + oy) * Wo + ox) * C + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int uy = by[e] - 2 * a, ux = bx[e] - 2 * b;      // position inside this 2x2 block?
+                    if (uy >= 0 && uy < 2 && ux >= 0 && ux < 2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int v = 0; v < 2; ++v)
+                                if (u == uy && v == ux) g[u][v][e] += d[e];
+                    }
+                }
             }
         }
-        reinterpret_cast<f32x4*>(dx)[i] = g;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int iy = 2 * a + u, ix = 2 * b + v;
+                if (iy < H && ix < W)
+                    *reinterpret_cast<f32x4*>(dx + (((int64_t)img * H + iy) * W + ix) * C + c) = g[u][v];
+            }
     }
 }
 
@@ -636,7 +664,7 @@ extern "C" int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, in
 extern "C" int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
                                     void* stream) {
     GRL_REQUIRE(x && dy && dx && n > 0 && C % 4 == 0, "maxpool_bwd: bad args");
-    const int64_t total4 = (int64_t)n * H * W * (C / 4);
+    const int64_t total4 = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);      // 2x2 input blocks
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W,
                        C / 4, total4);
     return grl_check_launch("grl_maxpool3x3s2_bwd");

@@ -69,7 +69,7 @@ _SIGNATURES = {
     'grl_axpy_strided': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),
     'grl_transpose': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_pack_dgrad_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
-    'grl_dilate2': ([_fp, _fp] + [C.c_int] * 7 + [_fp], C.c_int),
+    'grl_dilate2': ([_fp, _fp] + [C.c_int] * 9 + [_fp], C.c_int),
     'grl_maxpool3x3s2_bwd': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_im2col': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_wgrad_workspace_floats': ([C.POINTER(GrlWgrad)], _i64),

@@ -288,7 +288,7 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
 // zero-stuffing for stride-2 data gradients: up[img][2oy][2ox][:] = dz[img][oy][ox][:], zero
 // elsewhere; accumulate: up[img][2oy][2ox][:] += dz[...], every other element left as it is
 __global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__ up, int Ho, int Wo,
-                               int H, int W, int C4, int64_t total4, int accumulate) {
+                               int H, int W, int C4, int64_t total4, int accumulate, int oy_off, int ox_off) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = i % C4;
@@ -297,11 +297,11 @@ __global__ void dilate2_kernel(const float* __restrict__ dz, float* __restrict__
         const int y = r % H;
         const int img = r / H;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const bool hit = !(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo;
+        const bool hit = (x & 1) == ox_off && (y & 1) == oy_off && (y >> 1) < Ho && (x >> 1) < Wo;
         if (hit) v = reinterpret_cast<const f32x4*>(dz)[(((int64_t)img * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c];
-        if (accumulate) {
+        if (accumulate) {                       // 1: add at the class pixels, 2: write only them
             if (!hit) continue;
-            v += reinterpret_cast<const f32x4*>(up)[i];
+            if (accumulate == 1) v += reinterpret_cast<const f32x4*>(up)[i];
         }
         reinterpret_cast<f32x4*>(up)[i] = v;
     }
@@ -653,11 +653,12 @@ extern "C" int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, i
 }
 
 extern "C" int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
-                           void* stream) {
+                           int oy_off, int ox_off, void* stream) {
     GRL_REQUIRE(dz && up && n > 0 && C % 4 == 0, "dilate2: bad args");
+    GRL_REQUIRE((oy_off == 0 || oy_off == 1) && (ox_off == 0 || ox_off == 1), "dilate2: offsets are 0 or 1");
     const int64_t total4 = (int64_t)n * H * W * (C / 4);
     hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dz, up, Ho, Wo, H, W,
-                       C / 4, total4, accumulate);
+                       C / 4, total4, accumulate, oy_off, ox_off);
     return grl_check_launch("grl_dilate2");
 }
 

@@ -122,6 +122,20 @@ class Tape(object):
             self.wc[key] = out
         return self.wc[key]
 
+    def w_dgrad_s2(self, conv, py, px):
+        """Data-gradient weight of a 3x3 stride-2 conv for the input-pixel parity class (py, px):
+        [cin][dy][dx][N] with the taps that reach that class -- ky = 1 for py = 0; ky = 2 (output row
+        a) then ky = 0 (output row a+1) for py = 1; same in x.  A re-layout of 1/9 .. 4/9 of the
+        weight, done with torch indexing once per step."""
+        w = conv.weight
+        key = ('d2', id(w), py, px)
+        if key not in self.wc:
+            kys = [1] if py == 0 else [2, 0]
+            kxs = [1] if px == 0 else [2, 0]
+            wd = w.detach()[:, :, kys][:, :, :, kxs]              # [N][cin][kh][kw]
+            self.wc[key] = wd.permute(1, 2, 3, 0).contiguous().view(w.shape[1], -1)
+        return self.wc[key]
+
     def backward(self):
         for fn in reversed(self.ops):
             fn()
@@ -260,16 +274,28 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
             # resolution scattered to them (a quarter of the zero-stuffed GEMM's FLOPs)
             small = _new((M, cin), dz)
             gemm(dz, wt, small, M, cin, N)
-            _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin, 1 if cur is not None else 0)
+            _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin, 1 if cur is not None else 0, 0, 0)
         else:
             gemm(dz, wt, dx, Min, cin, N, res=cur)
+    elif stride == 1:
+        gemm(dz, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
+    elif k == 3 and stride == 2 and H == 2 * Ho and W == 2 * Wo:
+        # 3x3 stride-2 pad-1: input pixel (2a+py, 2b+px) only meets the taps ky = 1 (py = 0) or
+        # ky = 2, 0 (py = 1; output rows a, a+1), likewise in x -- four small stride-1 convolutions
+        # over dz at OUTPUT resolution (1, 2, 2 and 4 taps), each scattered to its parity class:
+        # the forward FLOPs instead of the 4x of a zero-stuffed full-resolution convolution.
+        for py in (0, 1):
+            for px in (0, 1):
+                wc = tp.w_dgrad_s2(conv, py, px)                  # [cin][taps][N]
+                kh, kw = 1 + py, 1 + px
+                small = _new((M, cin), dz)
+                gemm(dz, wc, small, M, cin, kh * kw * N, conv=(Ho, Wo, N, Ho, Wo, kh, kw, 1, 0))
+                _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin,
+                      1 if cur is not None else 2, py, px)
     else:
-        wd = tp.w_dgrad(conv)
-        src = dz
-        if stride != 1:
-            src = _new((Min, N), dz)
-            _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N, 0)
-        gemm(src, wd, dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
+        src = _new((Min, N), dz)
+        _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N, 0, 0, 0)
+        gemm(src, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
     if cur is None:
         tp.g[id(x)] = dx
 

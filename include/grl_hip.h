@@ -252,11 +252,12 @@ int grl_axpy_strided(float* dst, int64_t dst_stride, const float* src, int64_t s
 int grl_transpose(const float* x, float* y, int R, int C, int ldx, void* stream);
 /* [N][C][kh][kw] -> [C][flipped tap][N]: data gradient of a kxk conv as a conv over dz */
 int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream);
-/* zero-stuffing of a stride-2 conv's output gradient: up[img][2oy][2ox] = dz[img][oy][ox], zero
- * elsewhere; accumulate != 0: up[img][2oy][2ox] += dz[...] and nothing else is touched (the data
- * gradient of a 1x1 stride-2 conv is computed at OUTPUT resolution and scattered this way) */
+/* zero-stuffing of a stride-2 conv's output gradient: up[img][2oy+oy_off][2ox+ox_off] =
+ * dz[img][oy][ox], zero elsewhere; accumulate == 1: += at those pixels, accumulate == 2: = at those
+ * pixels, and nothing else is touched either way (the data gradient of a stride-2 conv is computed
+ * at OUTPUT resolution, one GEMM per input-pixel parity class, and scattered this way) */
 int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
-                void* stream);
+                int oy_off, int ox_off, void* stream);
 /* nn.MaxPool2d(3,2,1) backward (first-maximum rule, deterministic gather form) */
 int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
                          void* stream);

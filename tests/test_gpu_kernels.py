@@ -369,3 +369,54 @@ def test_bf16_storage_pointwise_twins(dev):
     o16b = torch.empty_like(o16)
     engine._call('grl_stem_conv7x7_bf16', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o16b), n, H, W, 1, None)
     assert torch.equal(o16, o16b)                     # packed image == in-kernel conversion
+
+
+def _im2col(x, k_h, k_w, stride, pad):
+    n, H, W, cin = x.shape
+    Ho, Wo = (H + 2 * pad - k_h) // stride + 1, (W + 2 * pad - k_w) // stride + 1
+    xp = np.zeros((n, H + 2 * pad + k_h, W + 2 * pad + k_w, cin), np.float32)     # slack rows stay zero
+    xp[:, pad:pad + H, pad:pad + W] = x
+    cols = np.empty((n, Ho, Wo, k_h * k_w, cin), np.float32)
+    for ky in range(k_h):
+        for kx in range(k_w):
+            cols[:, :, :, ky * k_w + kx] = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride]
+    return cols.reshape(n * Ho * Wo, k_h * k_w * cin), Ho, Wo
+
+
+def test_gemm_and_conv_fuzz_bit_exact(dev):
+    """Seeded random shapes against the C oracle's fmaf chain, bit for bit: ragged M / N (scalar and
+    float4 epilogues), every tile shape, more tiles than resident workgroups (a persistent
+    workgroup then walks several tiles with the next tile's stage prefetched), rectangular and
+    even-sized conv kernels, pad 0, stride 2, and the forced tile shapes."""
+    import os
+    from grl_amd import engine
+    from oracle.ref_c import chain_gemm
+    rng = np.random.default_rng(2024)
+    dense = [(int(rng.integers(1, 700)), int(rng.integers(1, 300)), 32 * int(rng.integers(1, 9))) for _ in range(10)]
+    dense += [(70000, 192, 64), (33000, 72, 96), (1100 * 128 // 8, 64, 32)]       # > 768 / 1024 tiles
+    for M, N, K in dense:
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        w = rng.standard_normal((N, K)).astype(np.float32)
+        ref = chain_gemm(a, w)
+        for tile in (None, '64x64', '128x64', '128x128'):
+            if tile and M * N > 4e6:
+                continue
+            os.environ.pop('GRL_GEMM_TILE', None)
+            if tile:
+                os.environ['GRL_GEMM_TILE'] = tile
+            y = torch.full((M, N), 7.0, device=dev)
+            engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K)
+            assert np.array_equal(y.cpu().numpy(), ref), (M, N, K, tile)
+    os.environ.pop('GRL_GEMM_TILE', None)
+    convs = [(32, 40, 3, 3, 1, 1, 9, 7, 3), (64, 64, 1, 2, 1, 0, 8, 8, 2), (32, 96, 2, 2, 1, 0, 6, 10, 2),
+             (64, 33, 3, 3, 2, 1, 12, 8, 5), (32, 64, 2, 1, 1, 0, 7, 5, 4), (96, 130, 1, 1, 2, 0, 10, 6, 3),
+             (64, 64, 3, 3, 1, 1, 64, 32, 70)]                                     # 143360 rows: 2240 tiles
+    for cin, cout, kh, kw, stride, pad, H, W, n in convs:
+        x = rng.standard_normal((n, H, W, cin)).astype(np.float32)
+        w = (rng.standard_normal((cout, kh * kw * cin)) / np.sqrt(cin * kh * kw)).astype(np.float32)
+        cols, Ho, Wo = _im2col(x, kh, kw, stride, pad)
+        ref = chain_gemm(cols, w)
+        y = torch.empty(n * Ho * Wo, cout, device=dev)
+        engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), y, n * Ho * Wo, cout, kh * kw * cin,
+                    conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad))
+        assert np.array_equal(y.cpu().numpy(), ref), (cin, cout, kh, kw, stride, pad, H, W, n)

@@ -66,8 +66,8 @@ def main():
     mfma, mcalls = read_pmc(d_mfma)
     fsteps, wsteps, msteps = fcalls[stem], wcalls[stem], mcalls[stem]
     lines = ['# %s: rocprofv3 summary (bench.py, B x T = 32 x 4, fp32), per step' % tag, '',
-             '| kernel | launches/step | ms/step | avg us/launch | HBM read MB/step | HBM write MB/step | MFMA busy % |',
-             '|---|---|---|---|---|---|---|']
+             '| kernel | launches/step | ms/step | avg us/launch | HBM read MB/step | HBM write MB/step | HBM GB/s | MFMA busy % |',
+             '|---|---|---|---|---|---|---|---|']
     tot_ms = 0.0
     gem = dict(ms=0.0, rd=0.0, wr=0.0, launches=0, busy=0.0, active=0.0)
     for k in sorted(dur, key=lambda k: -dur[k]):
@@ -80,13 +80,15 @@ def main():
         active = mfma[k]['GRBM_GUI_ACTIVE']
         # MFMA_BUSY is summed over the 1024 SIMDs, GUI_ACTIVE over the 8 XCDs
         pct = 100.0 * (busy / 1024.0) / (active / 8.0) if active else 0.0
-        lines.append('| %s | %.1f | %.3f | %.1f | %.0f | %.0f | %.1f |' % (
-            k, calls[k] / steps, ms, dur[k] / calls[k] / 1e3, rd, wr, pct))
+        lines.append('| %s | %.1f | %.3f | %.1f | %.0f | %.0f | %.0f | %.1f |' % (
+            k, calls[k] / steps, ms, dur[k] / calls[k] / 1e3, rd, wr, (rd + wr) / max(ms, 1e-9), pct))
         tot_ms += ms
         if k.startswith('gemm_f32_kernel'):
             gem['ms'] += ms; gem['rd'] += rd; gem['wr'] += wr; gem['launches'] += calls[k] / steps
             gem['busy'] += busy; gem['active'] += active
-    lines += ['', 'sum of kernel time: %.3f ms/step over %d profiled steps' % (tot_ms, steps), '',
+    lines += ['', 'HBM GB/s = (FETCH_SIZE x2 + WRITE_SIZE bytes) / kernel time, against ~8000 GB/s HBM3E peak '
+              '(MI355X_MICROARCH.md); MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.',
+              '', 'sum of kernel time: %.3f ms/step over %d profiled steps' % (tot_ms, steps), '',
               'gemm_f32_kernel (all instantiations): %.3f ms/step, %.0f launches/step, HBM read %.0f MB + write %.0f MB '
               'per step (FETCH_SIZE x2 gfx950 correction applied), MFMA busy %.1f %% of kernel-active cycles' % (
                   gem['ms'], gem['launches'], gem['rd'], gem['wr'],

@@ -244,21 +244,32 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
 // ---------------------------------------------------------------------------------
 // y[g][c] (+)= out_scale/rows * sum_r x[g][r][c].  One workgroup per (group, 256-channel
 // slab): 64 lanes x float4 cover the slab, the 4 waves split the rows.
-__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x,
-                                                         float* __restrict__ y, int rows, int C,
-                                                         int ldy, float mul, int accumulate) {
-    __shared__ f32x4 red[4][64];
+// 16 waves per workgroup share the rows of one (group, 256-column) strip: the grid of a GAP over
+// 32 clips is only 256 workgroups, so the loads in flight per CU come from the waves, not the grid.
+constexpr int RED_WAVES = 16;
+__device__ __forceinline__ f32x4 red16(const f32x4 (*red)[64], int l) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < RED_WAVES; w += 4)
+        t += (red[w][l] + red[w + 1][l]) + (red[w + 2][l] + red[w + 3][l]);
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void group_mean_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ y, int rows, int C,
+                                                          int ldy, float mul, int accumulate) {
+    __shared__ f32x4 red[RED_WAVES][64];
     const int g = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int wave = threadIdx.x >> 6;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const float* xp = x + (int64_t)g * rows * C + c;
-        for (int r = wave; r < rows; r += 4) s += *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C);
+        for (int r = wave; r < rows; r += RED_WAVES) s += *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C);
     }
     red[wave][threadIdx.x & 63] = s;
     __syncthreads();
     if (wave == 0 && c < C) {
-        f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        f32x4 t = red16(red, threadIdx.x);
         t *= mul;
         float* yp = y + (int64_t)g * ldy + c;
         if (accumulate) t += *reinterpret_cast<const f32x4*>(yp);
@@ -267,18 +278,18 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 }
 
 // d[b][c] = mean_r (f1[b][r][c] - f2[b*stride + r*C + c])^2
-__global__ __launch_bounds__(256) void sqdiff_mean_kernel(const float* __restrict__ f1,
-                                                          const float* __restrict__ f2,
-                                                          float* __restrict__ d, int rows, int C,
-                                                          int64_t f2_stride) {
-    __shared__ f32x4 red[4][64];
+__global__ __launch_bounds__(1024) void sqdiff_mean_kernel(const float* __restrict__ f1,
+                                                           const float* __restrict__ f2,
+                                                           float* __restrict__ d, int rows, int C,
+                                                           int64_t f2_stride) {
+    __shared__ f32x4 red[RED_WAVES][64];
     const int g = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int wave = threadIdx.x >> 6;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const float* p1 = f1 + (int64_t)g * rows * C + c;
         const float* p2 = f2 + (int64_t)g * f2_stride + c;
-        for (int r = wave; r < rows; r += 4) {
+        for (int r = wave; r < rows; r += RED_WAVES) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p1 + (int64_t)r * C) -
                             *reinterpret_cast<const f32x4*>(p2 + (int64_t)r * C);
             s += t * t;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256) void sqdiff_mean_kernel(const float* __restric
     red[wave][threadIdx.x & 63] = s;
     __syncthreads();
     if (wave == 0 && c < C) {
-        f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        f32x4 t = red16(red, threadIdx.x);
         t *= 1.f / rows;
         *reinterpret_cast<f32x4*>(d + (int64_t)g * C + c) = t;
     }
@@ -689,7 +700,7 @@ extern "C" int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, i
 extern "C" int grl_group_mean(const float* x, float* y, int groups, int rows, int C, int ldy, float out_scale,
                               int accumulate, void* stream) {
     GRL_REQUIRE(x && y && groups > 0 && rows > 0 && C % 4 == 0 && ldy % 4 == 0, "group_mean: bad args");
-    hipLaunchKernelGGL(group_mean_kernel, dim3(grl_ceil_div(C, 256), groups), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(group_mean_kernel, dim3(grl_ceil_div(C, 256), groups), dim3(1024), 0, (hipStream_t)stream,
                        x, y, rows, C, ldy, out_scale / rows, accumulate);
     return grl_check_launch("grl_group_mean");
 }
@@ -715,7 +726,7 @@ extern "C" int grl_temporal_mean(const float* x, float* y, int b, int T, int64_t
 extern "C" int grl_sqdiff_mean(const float* f1, const float* f2, float* d, int b, int rows, int C,
                                int64_t f2_clip_stride, void* stream) {
     GRL_REQUIRE(f1 && f2 && d && b > 0 && rows > 0 && C % 4 == 0 && f2_clip_stride % 4 == 0, "sqdiff_mean: bad args");
-    hipLaunchKernelGGL(sqdiff_mean_kernel, dim3(grl_ceil_div(C, 256), b), dim3(256), 0, (hipStream_t)stream, f1, f2,
+    hipLaunchKernelGGL(sqdiff_mean_kernel, dim3(grl_ceil_div(C, 256), b), dim3(1024), 0, (hipStream_t)stream, f1, f2,
                        d, rows, C, f2_clip_stride);
     return grl_check_launch("grl_sqdiff_mean");
 }

@@ -420,7 +420,7 @@ struct WgradArgs {
     int conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
     constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // float4 per thread per stage (32 rows)
@@ -435,9 +435,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     const int m_begin = blockIdx.y * p.chunk;
     const int m_end = min(p.M, m_begin + p.chunk);
     int tap = 0, c0 = k0, ky = 0, kx = 0;
-    if (p.conv) { tap = k0 / p.C; c0 = k0 - tap * p.C; ky = tap / p.kw; kx = tap - ky * p.kw; }
+    if (CONV) { tap = k0 / p.C; c0 = k0 - tap * p.C; ky = tap / p.kw; kx = tap - ky * p.kw; }
 
     f32x4 areg[A_ITEMS], breg[B_ITEMS];
+    // conv: each staged X row is an output pixel (img, oy, ox); a stage advances every row by 32
+    // pixels, so the decomposition is carried incrementally instead of two divisions per row
+    // and stage (they sat in front of every stage's MFMAs)
+    int pimg[B_ITEMS], poy[B_ITEMS], pox[B_ITEMS];
+    const int adv_y = 32 / p.Wo, adv_x = 32 - adv_y * p.Wo;
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < B_ITEMS; ++i) {
+            const int e = tid + 256 * i, row = e / B_TPR;
+            const int m = m_begin + row, hw = p.Ho * p.Wo;
+            pimg[i] = m / hw;
+            const int rem = m - pimg[i] * hw;
+            poy[i] = rem / p.Wo;
+            pox[i] = rem - poy[i] * p.Wo;
+        }
+    }
     auto load_stage = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < A_ITEMS; ++i) {
@@ -453,18 +469,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
             const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
             const int m = m0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && k0 + col < p.K) {
-                if (p.conv) {
-                    const int hw = p.Ho * p.Wo;
-                    const int img = m / hw, rem = m - img * hw;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                        v = *reinterpret_cast<const f32x4*>(
-                            p.x + (((int64_t)img * p.H + iy) * p.W + ix) * p.C + c0 + col);
-                } else {
-                    v = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + k0 + col);
-                }
+            if (CONV) {
+                const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
+                if (m < m_end && k0 + col < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    v = *reinterpret_cast<const f32x4*>(
+                        p.x + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + c0 + col);
+                // advance this row's pixel by the 32 rows of a stage (stages are loaded in order)
+                pox[i] += adv_x;
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
+                poy[i] += adv_y;
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
+            } else if (m < m_end && k0 + col < p.K) {
+                v = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + k0 + col);
             }
             breg[i] = v;
         }
@@ -748,10 +764,16 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)2 * 32 * (bm + bn) * sizeof(float);
     dim3 grid(tiles_n * tiles_k, real_splits);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), lds, s, a, tiles_k);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), lds, s, a, tiles_k);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), lds, s, a, tiles_k);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), lds, s, a, tiles_k);
+#define GRL_WGRAD_LAUNCH(BM_, BN_)                                                                        \
+    do {                                                                                                  \
+        if (d.conv) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true>), grid, dim3(256), lds, s, a, tiles_k);  \
+        else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, false>), grid, dim3(256), lds, s, a, tiles_k);        \
+    } while (0)
+    if (bm == 128 && bn == 128) GRL_WGRAD_LAUNCH(128, 128);
+    else if (bm == 128 && bn == 64) GRL_WGRAD_LAUNCH(128, 64);
+    else if (bm == 64 && bn == 128) GRL_WGRAD_LAUNCH(64, 128);
+    else GRL_WGRAD_LAUNCH(64, 64);
+#undef GRL_WGRAD_LAUNCH
     const int taps = d.conv ? d.kh * d.kw : 1;
     const int Cc = d.conv ? d.C : d.K;
     const int kout = d.k_out > 0 ? d.k_out : d.K;      // stem: K padded to 160, 147 real

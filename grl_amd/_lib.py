@@ -58,10 +58,10 @@ _SIGNATURES = {
     'grl_mean_T': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_pair_verify': ([_fp] * 7 + [C.c_int] * 4 + [_fp], C.c_int),
     'grl_col_stats_rows': ([C.c_int], C.c_int),
-    'grl_col_stats': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_col_stats': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_slab_sum': ([_fp, C.c_int, _i64, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_bn_stats_finalize': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
-                               _fp, _fp, _fp, _fp, _fp], C.c_int),
+                               _fp, _fp, _fp, _fp, _fp, _fp], C.c_int),
     'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),

@@ -23,18 +23,23 @@ namespace {
 constexpr int CHUNK = 128;     // rows per partial of the column reductions
 
 // ---------------------------------------------------------------------------------
-// column statistics of x[M][C] (row stride ld): slab[chunk][0][c] = sum, [1][c] = sum sq
+// column statistics of x[M][C] (row stride ld): slab[chunk][0][c] = sum, [1][c] = sum sq of
+// (x - pivot[c]).  The pivot (row 0 of x for BatchNorm statistics, none for plain column sums)
+// keeps E[d^2] - E[d]^2 well conditioned when a column's mean dwarfs its spread -- BatchNorm1d
+// over a handful of rows, where fp32 sums of squares would lose the variance.
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x,
                                                         float* __restrict__ slab, int M, int C,
-                                                        int ld) {
+                                                        int ld, const float* __restrict__ pivot) {
     __shared__ f32x4 red[2][4][64];
     const int chunk = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
     if (c < C) {
         const int r1 = min(M, (chunk + 1) * CHUNK);
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (pivot) pv = *reinterpret_cast<const f32x4*>(pivot + c);
         for (int r = chunk * CHUNK + wave; r < r1; r += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c) - pv;
             s += v; q += v * v;
         }
     }
@@ -95,16 +100,18 @@ __device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int 
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
     const float* __restrict__ slab, int rows, int C, double count, const float* gamma,
     const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
+    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+    const float* __restrict__ pivot) {
     __shared__ double sh[2 * 16 * 64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     double s, q;
     slab_totals(slab, rows, C, c, sh, s, q);
     if ((threadIdx.x >> 6) != 0 || c >= C) return;
-    const double mu = s / count;
-    double var = q / count - mu * mu;
+    const double md = s / count;                       // mean of (x - pivot)
+    double var = q / count - md * md;
     var = var > 0.0 ? var : 0.0;
+    const double mu = md + (pivot ? (double)pivot[c] : 0.0);
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)mu;
     invstd[c] = is;
@@ -577,10 +584,10 @@ inline int grid_for(int64_t n, int block = 256) {
 
 extern "C" int grl_col_stats_rows(int M) { return (M + CHUNK - 1) / CHUNK; }
 
-extern "C" int grl_col_stats(const float* x, float* slab, int M, int C, int ld, void* stream) {
+extern "C" int grl_col_stats(const float* x, float* slab, int M, int C, int ld, const float* pivot, void* stream) {
     GRL_REQUIRE(x && slab && M > 0 && C % 4 == 0 && ld % 4 == 0, "col_stats: bad args");
     hipLaunchKernelGGL(col_stats_kernel, dim3(grl_ceil_div(C, 256), grl_col_stats_rows(M)), dim3(256), 0,
-                       (hipStream_t)stream, x, slab, M, C, ld);
+                       (hipStream_t)stream, x, slab, M, C, ld, pivot);
     return grl_check_launch("grl_col_stats");
 }
 
@@ -595,12 +602,13 @@ extern "C" int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, 
 extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var,
                                      int64_t* num_batches_tracked, float momentum, float eps, float* mean,
-                                     float* invstd, float* scale, float* shift, void* stream) {
+                                     float* invstd, float* scale, float* shift, const float* pivot,
+                                     void* stream) {
     GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
     GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, slab,
                        rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
-                       eps, mean, invstd, scale, shift);
+                       eps, mean, invstd, scale, shift, pivot);
     return grl_check_launch("grl_bn_stats_finalize");
 }
 

@@ -164,7 +164,7 @@ def colsum_into(g, M, Ccols, out, ld=None):
     """out[c] += sum_m g[m][c]."""
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Ccols), g)
-    _call('grl_col_stats', ptr(g), ptr(slab), M, Ccols, ld or Ccols)
+    _call('grl_col_stats', ptr(g), ptr(slab), M, Ccols, ld or Ccols, None)
     _call('grl_slab_sum', ptr(slab), rows, 2 * Ccols, Ccols, ptr(out), 1)
 
 
@@ -172,7 +172,7 @@ class _BNState(object):
     __slots__ = ('mean', 'invstd', 'scale', 'shift')
 
 
-def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None):
+def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None, pivot=None):
     st = _BNState()
     buf = torch.empty((4, Cc), dtype=torch.float32, device=dev)
     st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
@@ -183,7 +183,7 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     # num_batches_tracked (torch's int64 counter) is bumped by the same launch
     _call('grl_bn_stats_finalize', ptr(slab), rows, Cc, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
           ptr(bn.num_batches_tracked), C.c_float(bn.momentum), C.c_float(bn.eps), ptr(st.mean), ptr(st.invstd),
-          ptr(st.scale), ptr(st.shift))
+          ptr(st.scale), ptr(st.shift), ptr(pivot))
     return st
 
 
@@ -335,8 +335,8 @@ def linear_bn_relu(tp, x, M, lin, bn):
     gemm(x, w.detach(), z, M, N, K, shift=lin.bias.detach())
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, N), x)
-    _call('grl_col_stats', ptr(z), ptr(slab), M, N, N)
-    st = bn_finalize(slab, rows, N, M, bn, tp.dev)
+    _call('grl_col_stats', ptr(z), ptr(slab), M, N, N, ptr(z))           # pivot = row 0 of z
+    st = bn_finalize(slab, rows, N, M, bn, tp.dev, pivot=z)
     a = _new((M, N), x)
     _call('grl_bn_apply', ptr(z), ptr(st.scale), ptr(st.shift), None, ptr(a), M, N, 1)
 
@@ -378,8 +378,8 @@ def bn1d_l2norm(tp, f, rows, Cc, bn):
     """BatchNorm1d(train) + F.normalize on [rows][C] (grl_model.py:222-226)."""
     nr = _lib.load().grl_col_stats_rows(rows)
     slab = _new((nr, 2, Cc), f)
-    _call('grl_col_stats', ptr(f), ptr(slab), rows, Cc, Cc)
-    st = bn_finalize(slab, nr, Cc, rows, bn, tp.dev)
+    _call('grl_col_stats', ptr(f), ptr(slab), rows, Cc, Cc, ptr(f))
+    st = bn_finalize(slab, nr, Cc, rows, bn, tp.dev, pivot=f)
     y = _new((rows, Cc), f)
     _call('grl_bn_apply', ptr(f), ptr(st.scale), ptr(st.shift), None, ptr(y), rows, Cc, 0)
     out = _new((rows, Cc), f)
@@ -414,8 +414,8 @@ def trunk_train(tp, model, x):
     _call('grl_stem_conv7x7', ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0, None)
     rows = _lib.load().grl_col_stats_rows(M0)
     slab = _new((rows, 2, 64), x)
-    _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64)
-    st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev)
+    _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64, ptr(z0))
+    st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev, pivot=z0)
     a0 = _new((M0, 64), x)
     _call('grl_bn_apply', ptr(z0), ptr(st.scale), ptr(st.shift), None, ptr(a0), M0, 64, 1)
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
@@ -716,8 +716,9 @@ def attn_train(tp, siam, x, b, t):
     scale, shift = _new((2 * D,), x), _new((2 * D,), x)
     for h, bn in enumerate((siam.featQ_bn, siam.featK_bn)):
         slab = _new((rows, 2, D), x)
-        _call('grl_col_stats', ptr(z[:, h * D:]), ptr(slab), M, D, 2 * D)
-        st = bn_finalize(slab, rows, D, M, bn, tp.dev)
+        zh = z[:, h * D:]
+        _call('grl_col_stats', ptr(zh), ptr(slab), M, D, 2 * D, ptr(zh))
+        st = bn_finalize(slab, rows, D, M, bn, tp.dev, pivot=zh)
         scale[h * D:(h + 1) * D] = st.scale
         shift[h * D:(h + 1) * D] = st.shift
         sts.append(st)
@@ -772,8 +773,8 @@ def verify_train(tp, head, probe, gallery):
     _call('grl_pair_sqdiff', ptr(probe), ptr(gallery), ptr(diff), nb, ng, K)
     rows = _lib.load().grl_col_stats_rows(P)
     slab = _new((rows, 2, K), probe)
-    _call('grl_col_stats', ptr(diff), ptr(slab), P, K, K)
-    st = bn_finalize(slab, rows, K, P, bn, tp.dev)
+    _call('grl_col_stats', ptr(diff), ptr(slab), P, K, K, ptr(diff))
+    st = bn_finalize(slab, rows, K, P, bn, tp.dev, pivot=diff)
     dn = _new((P, K), probe)
     _call('grl_bn_apply', ptr(diff), ptr(st.scale), ptr(st.shift), None, ptr(dn), P, K, 0)
     wpad = torch.zeros(32, K, dtype=torch.float32, device=tp.dev)

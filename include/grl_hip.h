@@ -210,9 +210,11 @@ int grl_add_strided_bf16(const void* a, const void* b, void* y, int nb, int64_t 
  * above, driven by reid/train/trainer.py:54 `loss.backward()`).
  * ---------------------------------------------------------------------------------- */
 
-/* column partials of x [M][C] (row stride ld): slab [grl_col_stats_rows(M)][2][C] = sum, sum sq */
+/* column partials of x [M][C] (row stride ld): slab [grl_col_stats_rows(M)][2][C] = sum, sum sq of
+ * (x - pivot[c]); pivot NULL = 0.  For BatchNorm statistics pass a row of x (and the same vector to
+ * grl_bn_stats_finalize): the shifted moments keep the variance when |mean| >> spread. */
 int grl_col_stats_rows(int M);
-int grl_col_stats(const float* x, float* slab, int M, int C, int ld, void* stream);
+int grl_col_stats(const float* x, float* slab, int M, int C, int ld, const float* pivot, void* stream);
 /* out[c] (+)= sum_r slab[r*stride + c]  (bias gradients, partial reductions) */
 int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out, int accumulate,
                  void* stream);
@@ -224,7 +226,8 @@ int grl_slab_sum(const float* slab, int rows, int64_t stride, int C, float* out,
 int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, float momentum, float eps, float* mean,
-                          float* invstd, float* scale, float* shift, void* stream);
+                          float* invstd, float* scale, float* shift,
+                          const float* pivot /* the grl_col_stats pivot, or NULL */, void* stream);
 /* step 2: y = relu?(z*scale + shift + res) */
 int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res,
                  float* y, int64_t M, int C, int relu, void* stream);

@@ -170,19 +170,20 @@ def _fresh_models():
     return cnn.cuda(), siam.cuda(), siamv.cuda()
 
 
-@pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 2.5e-1),
+@pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 5e-2),
                                                    (4, 2, 2, 'grl_train_b4t2.npz', 4e-3)])
 def test_train_forward_backward_matches_reference_golden(golden, B, T, seed, fname, tol_xu):
     """One train-mode forward + backward of the CNN: outputs, BN running statistics and
     parameter gradients against the reference (fp32 autograd on CPU).
 
-    Yardstick for the tolerances: the fp32 reference itself differs from an fp64 run of the
-    same graph by 1.2e-2 (B=2) / 7e-4 (B=4) on x_uncorr and by up to 3e-2 on individual
-    gradient elements (batch-statistics BN over 2-8 samples in front of 50 ReLU layers is
-    that sensitive to rounding); |grad| sums agree to 4e-4..3e-3.  At B = 2 x_uncorr goes
-    through BatchNorm1d over TWO rows ((x0-x1)/sqrt((x0-x1)^2/4 + eps)): a few elements with
-    nearly equal rows flip by O(0.1) under any change of summation order, so that fixture
-    only bounds x_uncorr loosely; the B = 4 fixture is the tight pin."""
+    Yardstick for the tolerances: the fixtures also hold the SAME graph run by the reference
+    model in float64 (f64.* keys).  The fp32 reference itself differs from it by 1.2e-2 (B=2) /
+    7e-4 (B=4) on x_uncorr and by 2e-2..4e-2 on individual gradient elements (batch-statistics
+    BN over 2-8 samples in front of 50 ReLU layers is that sensitive to rounding; at B = 2
+    x_uncorr goes through BatchNorm1d over TWO rows).  The HIP result has to be as close to
+    the float64 run as the reference's own fp32 run is (factor 2), which it is since the
+    BatchNorm1d statistics are accumulated around a pivot row (grl_col_stats): with plain
+    E[x^2] - E[x]^2 in fp32 the B = 2 gradients were 7x further from float64 than torch's."""
     g = golden(fname)
     cnn, _, _ = _fresh_models()
     cnn.train()
@@ -216,8 +217,24 @@ def test_train_forward_backward_matches_reference_golden(golden, B, T, seed, fna
         worst[k] = (err, abs(f.abs().sum().item() - g['grad.' + k + '.abssum']) / g['grad.' + k + '.abssum'])
     for k, v in worst.items():
         print('%-70s sample rel err %.2e  abssum rel err %.2e' % (k, v[0], v[1]))
-    # B = 2: everything upstream of uncorr_bn inherits its 2-row ill-conditioning (see docstring)
-    bad = {k: v for k, v in worst.items() if v[0] > (2.5e-1 if B == 2 else 8e-2) or v[1] > (2.5e-1 if B == 2 else 1e-2)}
+    # The yardstick for this ill-conditioned graph: the reference model run in float64
+    # (f64.* keys).  The HIP gradients must be as close to it as the reference's own float32 run.
+    e_ref, e_hip = {}, {}
+    for k in keys:
+        if k == 'input':
+            continue
+        f = named[k].grad.detach().cpu().reshape(-1).double()
+        t64 = g['f64.grad.' + k + '.val']
+        scale = max(np.abs(t64).max(), 1e-30)
+        e_ref[k] = np.abs(g['grad.' + k + '.val'].astype(np.float64) - t64).max() / scale
+        e_hip[k] = np.abs(f[torch.from_numpy(g['grad.' + k + '.idx'])].numpy() - t64).max() / scale
+    for k in e_ref:
+        print('  %-66s vs f64: ref32 %.2e  hip %.2e' % (k, e_ref[k], e_hip[k]))
+    print('vs float64: reference fp32 worst %.2e, HIP worst %.2e' % (max(e_ref.values()), max(e_hip.values())))
+    assert max(e_hip.values()) <= 2.0 * max(e_ref.values()) + 1e-3, (max(e_hip.values()), max(e_ref.values()))
+    assert _rel(xu.detach().cpu().numpy(), g['f64.x_uncorr']) <= 2.0 * _rel(g['x_uncorr'], g['f64.x_uncorr']) + 1e-4
+    assert _rel(xc.detach().cpu().numpy(), g['f64.x_corr']) <= 2.0 * _rel(g['x_corr'], g['f64.x_corr']) + 1e-4
+    bad = {k: v for k, v in worst.items() if v[0] > 8e-2 or v[1] > 4e-2}
     assert not bad, bad
 
 

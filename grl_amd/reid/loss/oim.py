@@ -2,12 +2,17 @@
 
 forward : logits = scalar * x . LUT^T (the MFMA GEMM kernel, scale in the epilogue), then
           `grl_softmax_ce` = F.cross_entropy(mean) AND its gradient in one launch.
-backward: grad_x = g * scalar * dlogits . LUT (`grl_oim_grad`) with the LUT as it was in the
-          forward, then -- inside backward, as upstream -- the LUT rows of the batch labels are
-          momentum-updated one sample at a time and re-normalised (`grl_oim_update`).
+backward: grad_x = g * scalar * dlogits . LUT (`grl_oim_grad`) with the LUT AS IT IS WHEN THE
+          BACKWARD RUNS (oim.py:23 reads self.lut at backward time), then -- inside backward, as
+          upstream -- the LUT rows of the batch labels are momentum-updated one sample at a time
+          and re-normalised (`grl_oim_update`).  SEQTrainer uses one criterion twice per step
+          (trainer.py:126,138): autograd runs the later (clip-level) node first, so the
+          frame-level backward reads a LUT the clip-level update has already changed and stacks
+          its own update on top.  tests/golden/oim.npz pins exactly that against the reference.
 
-The reference's legacy non-static autograd Function does not run on torch >= 1.5
-(PARITY UNPINNED for OIM); this is a static Function with the same maths.
+The reference's legacy non-static autograd Function cannot be applied on torch >= 1.5; this is
+a static Function with the same maths, pinned to the reference's forward/backward bodies
+(tests/golden/make_golden.py:oim_golden).
 No torch op computes here and nothing syncs with the host; there is no CPU path.
 
 Multi-process data parallel: every rank applies the updates of ALL ranks in rank order

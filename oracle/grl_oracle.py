@@ -9,9 +9,12 @@ Pinning: the reference ships no tests or golden vectors.
 This restatement is pinned against outputs of the reference itself, imported
 in the build container with stub modules by ``tests/golden/make_golden.py``;
 the resulting vectors are committed under ``tests/golden/`` and checked by
-``tests/test_oracle_golden.py``.  Exception: ``oim_*`` below restates
-reid/loss/oim.py, which cannot execute on torch >= 1.5 (legacy autograd
-Function) -- **parity unpinned** for OIM.
+``tests/test_oracle_golden.py``.  ``oim_*`` below restates reid/loss/oim.py, whose
+legacy autograd Function cannot be *applied* on torch >= 1.5; its forward/backward
+bodies still execute as plain functions on a stub ``self`` (make_golden.py:oim_golden),
+so OIM -- logits, loss, input gradient, LUT after the sequential update, and the order
+of the two same-LUT updates of one training step -- is pinned like everything else
+(tests/golden/oim.npz).
 
 All functions take a flat ``state`` dict with the reference's state_dict keys
 (e.g. ``backbone.base.4.0.conv1.weight``).
@@ -288,8 +291,8 @@ def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100):
 # losses (train step)
 # ----------------------------------------------------------------------------
 class _OIMFn(torch.autograd.Function):
-    """reid/loss/oim.py:8-27 as a static Function.  PARITY UNPINNED: the
-    reference's legacy Function cannot run on this torch."""
+    """reid/loss/oim.py:8-27 as a static Function (pinned to the reference's own forward /
+    backward bodies by tests/golden/oim.npz)."""
 
     @staticmethod
     def forward(ctx, inputs, targets, lut, momentum):

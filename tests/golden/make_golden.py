@@ -125,6 +125,107 @@ def train_golden(cnn, sd, clips, B, T, path):
     print('train golden %s: loss' % os.path.basename(path), loss.item())
 
 
+def oim_golden(ref_models, path):
+    """(F) OIM pinned to the reference (reid/loss/oim.py:8-53).  The reference's OIM is a legacy
+    non-static autograd.Function, which torch >= 1.5 refuses to *apply*; its forward/backward
+    BODIES (oim.py:14-27) still execute unmodified as plain functions on a stub ``self`` that carries
+    what a legacy Function instance carried (lut, momentum, needs_input_grad, save_for_backward ->
+    saved_tensors).  A static bridge Function hands them to autograd, ``reid.loss.oim.oim`` is
+    pointed at the bridge and ``OIMLoss.forward`` (oim.py:46-53) runs as shipped -- no math touched,
+    the same standard as the import stubs above."""
+    import importlib
+    ref_oim = importlib.import_module('reid.loss.oim')   # (`reid.loss.oim` the attribute is the function)
+    order = []
+
+    class Bridge(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, inputs, targets, lut, momentum, tag):
+            stub = types.SimpleNamespace(lut=lut, momentum=momentum, needs_input_grad=(True, False))
+            stub.save_for_backward = lambda *t: setattr(stub, 'saved_tensors', t)
+            ctx.stub, ctx.tag = stub, tag
+            return ref_oim.OIM.forward(stub, inputs, targets)          # oim.py:14-17
+
+        @staticmethod
+        def backward(ctx, grad_outputs):
+            order.append(ctx.tag)
+            gi, _ = ref_oim.OIM.backward(ctx.stub, grad_outputs)       # oim.py:19-27
+            return gi, None, None, None, None
+
+    tag = ['?']
+    ref_oim.oim = lambda inputs, targets, lut, momentum=0.5: Bridge.apply(inputs, targets, lut, momentum, tag[0])
+
+    out = {}
+    g = np.random.Generator(np.random.PCG64(17))
+    D, NC = 256, 12          # (a)-(c); the training-step case (d) is 2048 wide (the Siamese input)
+
+    def unit(a):
+        return (a / np.linalg.norm(a, axis=-1, keepdims=True)).astype(np.float32)
+
+    def one(name, x, y, lut0, upstream):
+        crit = ref_oim.OIMLoss(D, NC, scalar=30, momentum=0.5)
+        crit.lut.copy_(torch.from_numpy(lut0))
+        xt = torch.from_numpy(x).clone().requires_grad_(True)
+        tag[0] = name
+        loss, logits = crit(xt, torch.from_numpy(y))
+        (loss * upstream).backward()
+        out[name + '.x'], out[name + '.y'], out[name + '.lut0'] = x, y, lut0
+        out[name + '.upstream'] = np.array(upstream, np.float32)
+        out[name + '.loss'] = np.array(loss.item(), np.float32)
+        out[name + '.logits'] = logits.detach().numpy()
+        out[name + '.grad_x'] = xt.grad.numpy()
+        out[name + '.lut1'] = crit.lut.numpy().copy()
+        print('oim golden %-6s loss %.6f' % (name, loss.item()))
+
+    # (a) zero LUT (the state at step 0: oim.py:43), distinct labels
+    one('zero', unit(g.standard_normal((8, D))), np.array([0, 1, 2, 3, 4, 5, 6, 7], np.int64),
+        np.zeros((NC, D), np.float32), 1.0)
+    # (b) unit-norm LUT, distinct labels, non-unit upstream gradient
+    one('unit', unit(g.standard_normal((8, D))), np.array([3, 1, 4, 11, 5, 9, 2, 6], np.int64),
+        unit(g.standard_normal((NC, D))), 0.7)
+    # (c) duplicate labels: the sequential per-sample update is order dependent (oim.py:24-26),
+    #     a partly zero LUT
+    lut = unit(g.standard_normal((NC, D))); lut[[2, 7]] = 0
+    one('dup', unit(g.standard_normal((24, D))),
+        np.array([5, 5, 5, 5, 9, 9, 9, 9, 5, 5, 2, 2, 7, 7, 7, 7, 9, 9, 0, 0, 5, 2, 7, 0], np.int64), lut, 1.0)
+
+    # (d) the two same-LUT calls of one training step (trainer.py:117-127,137-139): frame-level OIM
+    #     on x_corr [B*T], then clip-level OIM on the reference Siamese's pooled output -- ONE
+    #     criterion, ONE LUT; the update order is the autograd engine's (recorded in `order`).
+    sys.path.insert(0, REPO)
+    from grl_amd.synthetic import synth_state_dict
+    B, T, D = 4, 4, 2048
+    siam = ref_models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'), strict=True)
+    siam.train()
+    xc = unit(g.standard_normal((B, T, D)))
+    ids = np.array([3, 3, 9, 9], np.int64)               # (anchor, positive) pairs, sampler.py:104-123
+    lut0 = unit(g.standard_normal((NC, D))); lut0[9] = 0
+    crit = ref_oim.OIMLoss(D, NC, scalar=30, momentum=0.5)
+    crit.lut.copy_(torch.from_numpy(lut0))
+    xt = torch.from_numpy(xc).clone().requires_grad_(True)
+    targets = torch.from_numpy(ids)
+    frame = xt.view(B * T, -1)
+    targetX = targets.unsqueeze(1).expand(B, T).contiguous().view(B * T, -1).squeeze(1)
+    del order[:]
+    tag[0] = 'frame'
+    l_frame, _ = crit(frame, targetX)                   # trainer.py:126
+    tv = targets.view(B // 2, -1)
+    target = torch.cat((tv[:, 0], tv[:, 1]))            # trainer.py:130-135
+    _, pooled = siam(xt)                                # trainer.py:137
+    tag[0] = 'vid'
+    l_vid, _ = crit(pooled, target)                     # trainer.py:138
+    (l_frame + l_vid).backward()
+    out['step.x_corr'], out['step.ids'], out['step.lut0'] = xc, ids, lut0
+    out['step.loss_frame'] = np.array(l_frame.item(), np.float32)
+    out['step.loss_vid'] = np.array(l_vid.item(), np.float32)
+    out['step.pooled'] = pooled.detach().numpy()
+    out['step.grad_x_corr'] = xt.grad.numpy()
+    out['step.lut1'] = crit.lut.numpy().copy()
+    out['step.backward_order'] = np.array(order)       # ['vid', 'frame']: later node first
+    print('oim golden step: losses %.6f %.6f, backward order %s' % (l_frame.item(), l_vid.item(), order))
+    np.savez_compressed(path, **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -267,6 +368,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'losses.npz'), feat=feat.numpy(), ids=ids.numpy(),
                         triplet=tri.numpy(), score=score.numpy(), tp=tp.numpy(), tg=tg.numpy(),
                         pair_loss=np.array(pl.item()), pair_prec=np.array(float(prec)))
+    oim_golden(ref_models, os.path.join(HERE, 'oim.npz'))
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
@@ -288,5 +390,8 @@ def main_train_only():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         main_train_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'oim':
+        torch.manual_seed(0)
+        oim_golden(import_reference()[0], os.path.join(HERE, 'oim.npz'))
     else:
         main()

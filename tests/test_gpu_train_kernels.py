@@ -133,6 +133,45 @@ def test_wgrad_dense_shapes():
         assert _rel(dw.cpu().numpy(), ref) < 1e-5, (M, N, K)
 
 
+def test_oim_matches_reference_golden(golden, synth_models):
+    """OIMLoss on HIP (logits GEMM + grl_softmax_ce + grl_oim_grad + grl_oim_update) against
+    outputs of the REFERENCE's OIM.forward / OIM.backward bodies and OIMLoss.forward
+    (reid/loss/oim.py:14-27,46-53; tests/golden/oim.npz): zero LUT, unit-norm LUT, duplicate
+    labels, and one training step's two calls on ONE LUT (trainer.py:126,138) in the autograd
+    engine's order -- the clip-level update lands before the frame-level backward reads the LUT."""
+    import copy
+    from grl_amd.reid.loss import OIMLoss
+    dev = torch.device('cuda:0')
+    g = golden('oim.npz')
+    for name in ('zero', 'unit', 'dup'):
+        x0, y, lut0 = g[name + '.x'], g[name + '.y'], g[name + '.lut0']
+        crit = OIMLoss(x0.shape[1], lut0.shape[0], scalar=30, momentum=0.5).to(dev)
+        crit.lut.copy_(torch.from_numpy(lut0))
+        x = torch.from_numpy(x0).to(dev).requires_grad_(True)
+        loss, logits = crit(x, torch.from_numpy(y).to(dev))
+        (loss * float(g[name + '.upstream'])).backward()
+        assert abs(loss.item() - float(g[name + '.loss'])) < 1e-4, name
+        assert _rel(logits.cpu().numpy(), g[name + '.logits']) < 1e-4, name
+        assert _rel(x.grad.cpu().numpy(), g[name + '.grad_x']) < 1e-4, name
+        assert _rel(crit.lut.cpu().numpy(), g[name + '.lut1']) < 1e-4, name
+    siam = copy.deepcopy(synth_models[1]).to(dev).train()
+    xc = torch.from_numpy(g['step.x_corr']).to(dev).requires_grad_(True)
+    ids = torch.from_numpy(g['step.ids']).to(dev)
+    B, T = xc.shape[:2]
+    crit = OIMLoss(2048, g['step.lut0'].shape[0], scalar=30, momentum=0.5).to(dev)
+    crit.lut.copy_(torch.from_numpy(g['step.lut0']))
+    l_frame, _ = crit(xc.view(B * T, -1), ids.repeat_interleave(T))          # trainer.py:126
+    tv = ids.view(B // 2, -1)
+    _, pooled = siam(xc)                                                     # trainer.py:137
+    l_vid, _ = crit(pooled, torch.cat((tv[:, 0], tv[:, 1])))                 # trainer.py:138
+    (l_frame + l_vid).backward()
+    assert abs(l_frame.item() - float(g['step.loss_frame'])) < 1e-4
+    assert abs(l_vid.item() - float(g['step.loss_vid'])) < 1e-4
+    assert _rel(pooled.detach().cpu().numpy(), g['step.pooled']) < 1e-4
+    assert _rel(xc.grad.cpu().numpy(), g['step.grad_x_corr']) < 1e-4
+    assert _rel(crit.lut.cpu().numpy(), g['step.lut1']) < 1e-4
+
+
 def test_oim_update_kernel_matches_sequential_loop():
     """OIMLoss on HIP (logits GEMM + grl_softmax_ce + grl_oim_grad + grl_oim_update) vs the
     oracle's restatement of oim.py:14-27,46-53 with repeated labels (order-dependent updates)."""

@@ -125,3 +125,37 @@ def test_losses_match_reference(golden):
     loss, prec = O.pair_loss(torch.from_numpy(g['score']), torch.from_numpy(g['tp']), torch.from_numpy(g['tg']))
     assert abs(loss.item() - float(g['pair_loss'])) < 1e-6
     assert abs(float(prec) - float(g['pair_prec'])) < 1e-6
+
+
+def test_oim_matches_reference(golden, synth_models):
+    """oracle.oim_loss against the reference's own OIM.forward/backward bodies + OIMLoss.forward
+    (tests/golden/oim.npz, generated by make_golden.py:oim_golden): zero LUT, unit-norm LUT,
+    duplicate labels (order-dependent sequential update), and the two same-LUT calls of one
+    training step in the autograd engine's order (clip-level update first, then frame-level)."""
+    g = golden('oim.npz')
+    for name in ('zero', 'unit', 'dup'):
+        x = torch.from_numpy(g[name + '.x']).requires_grad_(True)
+        lut = torch.from_numpy(g[name + '.lut0']).clone()
+        loss, logits = O.oim_loss(x, torch.from_numpy(g[name + '.y']), lut, 30.0, 0.5)
+        (loss * float(g[name + '.upstream'])).backward()
+        assert abs(loss.item() - float(g[name + '.loss'])) <= 1e-5
+        _close(logits.detach(), g[name + '.logits'])
+        _close(x.grad, g[name + '.grad_x'])
+        _close(lut, g[name + '.lut1'])
+    assert list(g['step.backward_order']) == ['vid', 'frame']
+    _, siam, _ = synth_models
+    ssd = _state(siam)
+    xc = torch.from_numpy(g['step.x_corr']).requires_grad_(True)
+    ids = torch.from_numpy(g['step.ids'])
+    B, T = xc.shape[:2]
+    lut = torch.from_numpy(g['step.lut0']).clone()
+    l_frame, _ = O.oim_loss(xc.view(B * T, -1), ids.repeat_interleave(T), lut, 30.0, 0.5)
+    tv = ids.view(B // 2, -1)
+    _, pooled = O.siamese_forward(ssd, xc, train=True)
+    l_vid, _ = O.oim_loss(pooled, torch.cat((tv[:, 0], tv[:, 1])), lut, 30.0, 0.5)
+    (l_frame + l_vid).backward()
+    assert abs(l_frame.item() - float(g['step.loss_frame'])) <= 1e-5
+    assert abs(l_vid.item() - float(g['step.loss_vid'])) <= 1e-5
+    _close(pooled.detach(), g['step.pooled'])
+    _close(xc.grad, g['step.grad_x_corr'])
+    _close(lut, g['step.lut1'])

@@ -154,8 +154,18 @@ class _Conv(object):
 
 
 def _state_key(module):
-    return tuple((t.data_ptr(), t._version) for t in
-                 list(module.parameters()) + list(module.buffers()))
+    """Identity of a module's state for the packed-plan caches: (pointer, torch version counter)
+    of every parameter / buffer plus the module's train-forward generation.  The train-mode
+    kernels update BatchNorm running statistics through raw device pointers, which torch's
+    version counters never see -- ``touch_state`` (called by every train-mode forward) makes those
+    updates visible here, so eval -> train forward under no_grad -> eval re-folds the BatchNorms."""
+    return (getattr(module, '_grl_generation', 0),) + tuple(
+        (t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def touch_state(module):
+    """Mark ``module``'s buffers as changed behind torch's back (see ``_state_key``)."""
+    module._grl_generation = getattr(module, '_grl_generation', 0) + 1
 
 
 class EvalPlan(object):

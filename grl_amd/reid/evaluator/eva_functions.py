@@ -61,11 +61,13 @@ def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100, indices=
 
 
 def cmc(distmat, query_ids=None, gallery_ids=None, query_cams=None, gallery_cams=None,
-        topk=100, first_match_break=True, **unsupported):
-    """First-match CMC (the `first_match_break` branch of eva_functions.py:18-79).
-    The gallery-resampling variants of the reference are outside the GRL path."""
-    if unsupported.get('separate_camera_set') or unsupported.get('single_gallery_shot'):
-        raise NotImplementedError('only the first-match CMC protocol is provided')
+        topk=100, separate_camera_set=False, single_gallery_shot=False, first_match_break=False):
+    """CMC curve of eva_functions.py:18-79 with the reference's defaults: per valid query either
+    the first match only (``first_match_break=True``) or, by default, every match i (0-based, at
+    filtered rank k_i) adding 1/#matches at rank k_i - i.  The gallery-resampling protocols
+    (``separate_camera_set`` / ``single_gallery_shot``) are outside the GRL path and raise."""
+    if separate_camera_set or single_gallery_shot:
+        raise NotImplementedError('separate_camera_set / single_gallery_shot CMC protocols are not provided')
     d = distmat.cpu().numpy() if torch.is_tensor(distmat) else np.asarray(distmat)
     m, n = d.shape
     query_ids = np.arange(m) if query_ids is None else np.asarray(query_ids)
@@ -73,19 +75,24 @@ def cmc(distmat, query_ids=None, gallery_ids=None, query_cams=None, gallery_cams
     query_cams = np.zeros(m, np.int32) if query_cams is None else np.asarray(query_cams)
     gallery_cams = np.ones(n, np.int32) if gallery_cams is None else np.asarray(gallery_cams)
     indices = np.argsort(d, axis=1)
-    matches = gallery_ids[indices] == query_ids[:, None]
-    ret, valid_q = np.zeros(topk), 0
+    hist, valid_q = np.zeros(topk), 0
     for i in range(m):
-        valid = (gallery_ids[indices[i]] != query_ids[i]) | (gallery_cams[indices[i]] != query_cams[i])
-        if not np.any(matches[i, valid]):
+        order = indices[i]
+        keep = (gallery_ids[order] != query_ids[i]) | (gallery_cams[order] != query_cams[i])
+        ranks = np.flatnonzero(gallery_ids[order][keep] == query_ids[i])   # filtered ranks of the matches
+        if ranks.size == 0:
             continue
-        k = np.nonzero(matches[i, valid])[0][0]
-        if k < topk:
-            ret[k:] += 1          # cumulative form of "first match at rank k"
         valid_q += 1
+        if first_match_break:
+            if ranks[0] < topk:
+                hist[ranks[0]] += 1
+            continue
+        slot = ranks - np.arange(ranks.size)          # non-decreasing: stop at the first slot >= topk
+        slot = slot[:np.searchsorted(slot, topk)]
+        np.add.at(hist, slot, 1.0 / ranks.size)
     if valid_q == 0:
         raise RuntimeError("No valid query")
-    return ret / valid_q
+    return hist.cumsum() / valid_q
 
 
 def mean_ap(distmat, query_ids=None, gallery_ids=None, query_cams=None, gallery_cams=None):

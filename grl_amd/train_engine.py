@@ -17,7 +17,16 @@ import torch
 
 from . import _lib, engine
 from ._lib import GrlWgrad, check, ptr
-from .engine import _call, _new, gemm, EvalPlan, PIX
+from ._lib import MATH_F32
+from .engine import _call, _new, EvalPlan, PIX
+
+
+def gemm(*args, **kw):
+    """engine.gemm pinned to the exact fp32 datapath: the process-wide multiplier mode
+    (engine.set_math / GRL_MATH, an eval-only switch) must not leak into the training forward and
+    data-gradient GEMMs -- every train parity claim is made in fp32."""
+    kw.setdefault('math', MATH_F32)
+    return engine.gemm(*args, **kw)
 
 FRAME_C = 2048
 
@@ -640,6 +649,7 @@ class _GrlTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_box, inputs, *params):
         model = model_box[0]
+        engine.touch_state(model)            # running statistics change below, unseen by torch
         tp = Tape(inputs.device)
         tp.reserve_param_grads(params)
         tp.taps = getattr(model, '_grl_taps', None)
@@ -811,6 +821,7 @@ class _SiameseTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, box, x, *params):
         siam = box[0]
+        engine.touch_state(siam)
         tp = Tape(x.device)
         bsz, t, d = x.shape
         half = bsz // 2
@@ -851,6 +862,7 @@ class _VerifyTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, box, x, *params):
         head = box[0]
+        engine.touch_state(head)
         tp = Tape(x.device)
         bsz = x.shape[0]
         half = bsz // 2

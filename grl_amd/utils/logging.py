@@ -1,39 +1,45 @@
-"""stdout tee (reference: utils/logging.py:8-39)."""
+"""`Logger(path)`: assign it to sys.stdout and every print also lands in a log file
+(the call site is mars_train.py:56-66; upstream counterpart utils/logging.py)."""
 import os
 import sys
 
-from .osutils import mkdir_if_missing
-
 
 class Logger(object):
+    """Tee: forwards write/flush to the stream that was sys.stdout at construction and, when a
+    path is given, to that file (its directory is created).  Usable as a context manager."""
+
     def __init__(self, fpath=None):
         self.console = sys.stdout
         self.file = None
-        if fpath is not None:
-            mkdir_if_missing(os.path.dirname(fpath))
+        if fpath:
+            folder = os.path.dirname(fpath)
+            if folder:
+                os.makedirs(folder, exist_ok=True)
             self.file = open(fpath, 'w')
 
-    def __del__(self):
-        self.close()
+    def _sinks(self):
+        return [s for s in (self.console, self.file) if s is not None]
+
+    def write(self, msg):
+        for s in self._sinks():
+            s.write(msg)
+
+    def flush(self):
+        for s in self._sinks():
+            s.flush()
+        if self.file is not None:
+            os.fsync(self.file.fileno())       # a killed training run keeps its log
+
+    def close(self):
+        f, self.file = self.file, None
+        if f is not None:
+            f.close()
+
+    __del__ = close
 
     def __enter__(self):
         return self
 
-    def __exit__(self, *args):
+    def __exit__(self, *exc):
         self.close()
-
-    def write(self, msg):
-        self.console.write(msg)
-        if self.file is not None:
-            self.file.write(msg)
-
-    def flush(self):
-        self.console.flush()
-        if self.file is not None:
-            self.file.flush()
-            os.fsync(self.file.fileno())
-
-    def close(self):
-        if self.file is not None:
-            self.file.close()
-            self.file = None
+        return False

@@ -226,6 +226,88 @@ def oim_golden(ref_models, path):
     np.savez_compressed(path, **out)
 
 
+def cmc_golden(attev, evaf, path):
+    """(G) eva_functions.cmc / mean_ap (eva_functions.py:18-115) with the reference's defaults and
+    with first_match_break=True, on the same synthetic features as the evaluator fixture."""
+    sys.path.insert(0, REPO)
+    from grl_amd.synthetic import synth_eval_features
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    dist = attev.cosin_dist(qf, gf)
+    np.savez_compressed(path,
+                        cmc_default=evaf.cmc(dist, qp, gp, qc, gc, topk=50),
+                        cmc_first=evaf.cmc(dist, qp, gp, qc, gc, topk=50, first_match_break=True),
+                        cmc_noids=evaf.cmc(dist[:, :40], topk=10),
+                        mean_ap=np.array(evaf.mean_ap(dist, qp, gp, qc, gc)))
+    print('cmc golden written')
+
+
+def sign_pattern(n, salt):
+    """+-1 per flat index from an integer hash (reproducible on any device): the projection
+    <g, sign> is a linear checksum of the WHOLE tensor."""
+    i = torch.arange(n, dtype=torch.int64)
+    h = (i * 2654435761 + salt * 40503) & 0xFFFFFFFF
+    h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+    return (((h >> 13) & 1) * 2 - 1).double()
+
+
+def train_golden_conditioned(ref_models, path, B=8, T=4):
+    """(B') the tight train-parity fixture: 'conditioned' synthetic weights (near-identity residual
+    blocks, ReLU inputs shifted positive -- grl_amd/synthetic.py) on structured clips, B x T = 8 x 4.
+    Two fp32 runs of a ReLU network differ mostly by ReLU-mask flips of pre-activations within
+    rounding of zero (a fraction ~1e-6 of the elements => ~1e-3 relative L2 per layer with the
+    default weights, whatever the arithmetic); this profile keeps that floor at ~2e-4, measured
+    below as the reference's fp32 run against its own float64 run, so that 1e-3 is a real pin.
+    Stored for EVERY parameter gradient: 256 strided samples (fp32 run and float64 run), the full
+    L2 norm and four +-1 projections of the whole tensor."""
+    sys.path.insert(0, REPO)
+    from grl_amd.synthetic import synth_state_dict, synth_clips_structured
+    cnn = ref_models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625)
+    sd = synth_state_dict(cnn, seed=0, profile='conditioned')
+    clips = synth_clips_structured(B, T, seed=3)
+    g = np.random.Generator(np.random.PCG64(7))
+    r1 = torch.from_numpy(g.standard_normal((B, 2048)).astype(np.float32))
+    r2 = torch.from_numpy(g.standard_normal((B, T, 2048)).astype(np.float32))
+    runs = {}
+    for dt in (torch.float32, torch.float64):
+        cnn.load_state_dict(sd, strict=True)
+        cnn.zero_grad(set_to_none=True)
+        cnn.to(dt).train()
+        xu, xc = cnn(clips.to(dt))
+        ((xu * r1.to(dt)).sum() + (xc * r2.to(dt)).sum()).backward()
+        runs[dt] = (xu.detach().double(), xc.detach().double(),
+                    {k: p.grad.detach().double() for k, p in cnn.named_parameters() if p.grad is not None},
+                    {k: v.detach().double().clone() for k, v in cnn.state_dict().items() if 'running' in k or 'tracked' in k})
+    a, b = runs[torch.float32], runs[torch.float64]
+    out = {'meta.B': np.array(B), 'meta.T': np.array(T),
+           'x_uncorr': a[0].float().numpy(), 'x_corr_s4': a[1][..., ::4].float().numpy(),   # every 4th column
+           'f64.x_uncorr': b[0].float().numpy(), 'f64.x_corr_s4': b[1][..., ::4].float().numpy()}
+    keys, worst = [], 0.0
+    for k in a[2]:
+        ga, gb = a[2][k].reshape(-1), b[2][k].reshape(-1)
+        if float(gb.abs().max()) < 1e-9:            # analytically zero (e.g. a bias in front of a train-mode BN)
+            continue
+        idx = torch.linspace(0, ga.numel() - 1, min(256, ga.numel())).long()     # the tests rebuild idx
+        out['g.%s.val' % k] = ga[idx].float().numpy()
+        out['g.%s.f64' % k] = gb[idx].numpy()
+        out['g.%s.norm' % k] = np.array([ga.norm().item(), gb.norm().item()])
+        out['g.%s.proj' % k] = np.array([[float((x * sign_pattern(x.numel(), s)).sum()) for s in range(4)]
+                                         for x in (ga, gb)])
+        e = float((ga - gb).norm() / gb.norm())
+        out['g.%s.ref_l2err' % k] = np.array(e)     # the reference's own fp32 run vs its float64 run
+        worst = max(worst, e)
+        keys.append(k)
+    for k in TRAIN_STAT_KEYS:
+        out['stat.' + k] = a[3][k].numpy()
+    out['meta.keys'] = np.array(keys)
+    np.savez_compressed(path, **out)
+    errs = sorted(float(out['g.%s.ref_l2err' % k]) for k in keys)
+    print('conditioned train golden: %d gradient tensors; reference fp32 vs its float64: outputs %.1e / %.1e, '
+          'gradient L2 median %.1e p90 %.1e max %.1e; %d bytes' % (
+              len(keys), float((a[0] - b[0]).abs().max() / b[0].abs().max()),
+              float((a[1] - b[1]).abs().max() / b[1].abs().max()),
+              errs[len(errs) // 2], errs[int(0.9 * len(errs))], errs[-1], os.path.getsize(path)))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -368,7 +450,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'losses.npz'), feat=feat.numpy(), ids=ids.numpy(),
                         triplet=tri.numpy(), score=score.numpy(), tp=tp.numpy(), tg=tg.numpy(),
                         pair_loss=np.array(pl.item()), pair_prec=np.array(float(prec)))
+    train_golden_conditioned(ref_models, os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
     oim_golden(ref_models, os.path.join(HERE, 'oim.npz'))
+    cmc_golden(attev, evaf, os.path.join(HERE, 'cmc_q40_g400.npz'))
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
@@ -390,6 +474,12 @@ def main_train_only():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         main_train_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cond':
+        torch.manual_seed(0); torch.set_num_threads(8)
+        train_golden_conditioned(import_reference()[0], os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cmc':
+        r = import_reference()
+        cmc_golden(r[1], r[2], os.path.join(HERE, 'cmc_q40_g400.npz'))
     elif len(sys.argv) > 1 and sys.argv[1] == 'oim':
         torch.manual_seed(0)
         oim_golden(import_reference()[0], os.path.join(HERE, 'oim.npz'))

@@ -170,9 +170,41 @@ def _fresh_models():
     return cnn.cuda(), siam.cuda(), siamv.cuda()
 
 
+def _fresh_cnn_conditioned():
+    import contextlib, io
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'))
+    return cnn.cuda()
+
+
+def test_train_forward_backward_matches_reference_golden_1e3(golden):
+    """THE end-to-end backward pin: HIP train-mode forward + backward of the whole CNN against the
+    reference's fp32 autograd run (tests/golden/grl_train_cond_b8t4.npz), B x T = 8 x 4, EVERY
+    parameter gradient at <= 1e-3 relative L2 (north_star's figure), outputs at <= 1e-4, whole
+    tensors covered by norm + projection checksums, BN running statistics at <= 1e-4.  The
+    'conditioned' weights / structured clips keep the ReLU-flip floor (what ANY two fp32 runs
+    differ by) at ~2e-4 -- measured in the fixture as the reference fp32 vs its own float64 -- so
+    a 1 % gradient bug in any layer fails here (tolerance model: tests/train_cond_check.py).
+    The chaotic default-weight fixtures below stay as stress tests."""
+    import train_cond_check as TC
+    from grl_amd.synthetic import synth_clips_structured
+    g = golden('grl_train_cond_b8t4.npz')
+    B, T = int(g['meta.B']), int(g['meta.T'])
+    cnn = _fresh_cnn_conditioned()
+    cnn.train()
+    r1, r2 = TC.upstream(B, T)
+    xu, xc = cnn(synth_clips_structured(B, T, seed=3).cuda())
+    ((xu * r1.cuda()).sum() + (xc * r2.cuda()).sum()).backward()
+    grads = {k: p.grad for k, p in cnn.named_parameters() if p.grad is not None}
+    TC.check(g, xu, xc, grads, cnn.state_dict(), out_tol=1e-4, grad_tol=1e-3, label='HIP')
+
+
 @pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 5e-2),
                                                    (4, 2, 2, 'grl_train_b4t2.npz', 4e-3)])
-def test_train_forward_backward_matches_reference_golden(golden, B, T, seed, fname, tol_xu):
+def test_train_forward_backward_chaotic_weights_stress(golden, B, T, seed, fname, tol_xu):
     """One train-mode forward + backward of the CNN: outputs, BN running statistics and
     parameter gradients against the reference (fp32 autograd on CPU).
 

@@ -159,3 +159,41 @@ def test_oim_matches_reference(golden, synth_models):
     _close(pooled.detach(), g['step.pooled'])
     _close(xc.grad, g['step.grad_x_corr'])
     _close(lut, g['step.lut1'])
+
+
+def test_cmc_and_mean_ap_match_reference(golden):
+    """The drop-in `cmc` (reference default: every match weighted 1/#matches; and the first-match
+    variant) and `mean_ap` of grl_amd.reid.evaluator against the reference's own functions
+    (eva_functions.py:18-115; tests/golden/cmc_q40_g400.npz).  Host numpy code, CPU test."""
+    from grl_amd.reid.evaluator import eva_functions as E
+    g = golden('cmc_q40_g400.npz')
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    dist = O.cosin_dist(qf, gf)
+    _close(E.cmc(dist, qp, gp, qc, gc, topk=50), g['cmc_default'], 1e-12)
+    _close(E.cmc(dist, qp, gp, qc, gc, topk=50, first_match_break=True), g['cmc_first'], 1e-12)
+    _close(E.cmc(dist[:, :40], topk=10), g['cmc_noids'], 1e-12)
+    assert abs(E.mean_ap(dist, qp, gp, qc, gc) - float(g['mean_ap'])) < 1e-9
+    with pytest.raises(NotImplementedError):
+        E.cmc(dist, qp, gp, qc, gc, single_gallery_shot=True)
+
+
+def test_train_conditioned_fixture_pins_oracle(golden):
+    """The tight train fixture (conditioned weights, structured clips, B x T = 8 x 4; every
+    parameter gradient): the oracle's forward + autograd backward against the reference's."""
+    import contextlib, io
+    import train_cond_check as TC
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_state_dict, synth_clips_structured
+    g = golden('grl_train_cond_b8t4.npz')
+    B, T = int(g['meta.B']), int(g['meta.T'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    sd = synth_state_dict(cnn, seed=0, profile='conditioned')
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and 'running' not in k:
+            v.requires_grad_(True)
+    r1, r2 = TC.upstream(B, T)
+    xu, xc = O.grl_forward(sd, synth_clips_structured(B, T, seed=3), train=True)
+    ((xu * r1).sum() + (xc * r2).sum()).backward()
+    TC.check(g, xu, xc, {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None},
+             {k: v.detach() for k, v in sd.items()}, out_tol=1e-5, grad_tol=1e-3, label='oracle')

@@ -24,7 +24,7 @@ class GrlGemm(C.Structure):
                                    'rnorm', 'cnorm', 'stats')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
-                                    'kw', 'stride', 'pad', 'math', 'out_f32')]
+                                    'kw', 'stride', 'pad', 'math', 'out_f32', 'kblock')]
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
@@ -63,6 +63,7 @@ _SIGNATURES = {
     'grl_bn_stats_finalize': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
                                _fp, _fp, _fp, _fp, _fp, _fp], C.c_int),
     'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
     'grl_axpby': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),

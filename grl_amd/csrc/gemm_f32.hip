@@ -12,7 +12,14 @@
 // Accumulation order (documented for the bit-exact oracle): for K-stage j
 // (32 wide), chunk q = 0..3, step s = 0..3 the accumulator receives
 //   acc = fma(a[k0], b[k0], acc);  acc = fma(a[k1], b[k1], acc)
-// with k0 = 32j + 8q + s, k1 = k0 + 4.
+// with k0 = 32j + 8q + s, k1 = k0 + 4.  With GrlGemm.kblock the chain is cut every SEG_STAGES
+// stages (512 k): at a segment boundary that is not the end of K the accumulator is added to a
+// running total and restarts from zero, and the result is last_segment + total.  The rounding
+// error of a sequential fp32 chain grows like sqrt(K); with K up to 4608 on the training path the
+// blocked form is ~3x closer to the exact sum -- the accuracy class of a blocked CPU sgemm -- which
+// keeps train-mode ReLU masks (and with them the parameter gradients) on the reference's side of
+// zero.  It costs ~4 % on K >= 1024 (64 more VGPRs, a flush per segment), so the eval path and the
+// evaluator keep the single chain.
 //
 // Tile: BM x BN x 32 per workgroup of 4 waves (2 x 2), each wave
 // (BM/2) x (BN/2) as MT x NT MFMA tiles of 32 x 32.  LDS holds two stages of
@@ -34,6 +41,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BK = 32;
+constexpr int SEG_STAGES = 16;     // fp32 path: accumulator segment = 16 stages = 512 k
 
 struct RowInfo {          // per staged A row: where it comes from
     int64_t base;         // dense: m*lda ; conv: image base offset (img*H*W*C)
@@ -53,7 +61,9 @@ struct RowInfo {          // per staged A row: where it comes from
 //      swizzle as the fp32 path; one ds_read_b128 (8 consecutive k) feeds one MFMA.
 // In modes 1/3 operands stay fp32 in HBM and are converted in the staging pass; LDS
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
-template <int BM, int BN, bool CONV, int MATH>
+// SEG: cut the fp32 accumulation chain every SEG_STAGES stages (launched when K > 512; K <= 512
+// layers run the instantiation without the second accumulator set).
+template <int BM, int BN, bool CONV, int MATH, bool SEG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
                                                            const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
@@ -194,13 +204,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     setup_tile(t);
     load_stage(0);
     for (;;) {
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT][NT], tot[SEG ? MT : 1][SEG ? NT : 1];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (SEG) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
 
     store_stage(0);
     __syncthreads();
@@ -292,8 +310,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                     }
             }
         }
+        if constexpr (SEG) {
+            if (((ks + 1) & (SEG_STAGES - 1)) == 0 && ks + 1 < nk) {      // segment boundary inside K
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        tot[i][j] += acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    }
+            }
+        }
         if (ks + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (SEG) {
+        if (nk > SEG_STAGES) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] += tot[i][j];
+        }
     }
 
     // the K loop ended on a barrier: stage registers and LDS are free.  Request the NEXT tile's
@@ -542,6 +580,13 @@ int resident_workgroups(const void* kernel, size_t lds) {
     return (cus * occ + 7) / 8 * 8;
 }
 
+template <auto KERNEL>
+void launch_kernel(const GrlGemm& d, hipStream_t s, size_t lds, int tiles_n, int num_tiles, int vec_epi) {
+    static const int slots = resident_workgroups((const void*)KERNEL, lds);      // per instantiation
+    hipLaunchKernelGGL(KERNEL, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
+                       vec_epi);
+}
+
 template <int BM, int BN, int MATH>
 int launch_math(const GrlGemm& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -556,16 +601,14 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (MATH == 2 && !vec_epi)
         return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
+    constexpr bool CAN_SEG = MATH == 0;
+    const bool seg = CAN_SEG && d.kblock && d.K > SEG_STAGES * BK;
     if (d.conv) {
-        auto k = gemm_f32_kernel<BM, BN, true, MATH>;
-        static const int slots = resident_workgroups((const void*)k, lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
-                           vec_epi);
+        if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     } else {
-        auto k = gemm_f32_kernel<BM, BN, false, MATH>;
-        static const int slots = resident_workgroups((const void*)k, lds);
-        hipLaunchKernelGGL(k, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
-                           vec_epi);
+        if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");
 }
@@ -604,6 +647,7 @@ int validate(const GrlGemm& d) {
     if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");
+    if (d.kblock && d.math != GRL_MATH_F32) return grl_fail(GRL_EINVAL, "gemm: kblock needs GRL_MATH_F32");
     return GRL_OK;
 }
 

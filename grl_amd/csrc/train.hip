@@ -143,6 +143,29 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __rest
     }
 }
 
+// y = relu?((z - mean)*scale + beta + res): the train-mode form.  Centering BEFORE the multiply
+// matters for BatchNorm1d over a few similar rows (|z - mean| << |mean|): the folded
+// z*scale + (beta - mean*scale) of the eval path would cancel there and lose ~|mean|/|z - mean| of
+// the fp32 significand; torch's train-mode kernel centres first too.
+__global__ void bn_apply_centered_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                         const float* __restrict__ scale, const float* __restrict__ beta,
+                                         const float* __restrict__ res, float* __restrict__ y, int C4,
+                                         int64_t total4, int relu) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c);
+        v = v * *reinterpret_cast<const f32x4*>(scale + c);
+        if (beta) v += *reinterpret_cast<const f32x4*>(beta + c);
+        if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
 // BN backward, pass 1: g = dy * (act > 0) ; slab[chunk][0][c] = sum g, [1][c] = sum g*xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
@@ -619,6 +642,15 @@ extern "C" int grl_bn_apply(const float* z, const float* scale, const float* shi
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
                        res, y, C / 4, total4, relu);
     return grl_check_launch("grl_bn_apply");
+}
+
+extern "C" int grl_bn_apply_centered(const float* z, const float* mean, const float* scale, const float* beta,
+                                     const float* res, float* y, int64_t M, int C, int relu, void* stream) {
+    GRL_REQUIRE(z && mean && scale && y && M > 0 && C % 4 == 0, "bn_apply_centered: bad args");
+    const int64_t total4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_centered_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, z, mean,
+                       scale, beta, res, y, C / 4, total4, relu);
+    return grl_check_launch("grl_bn_apply_centered");
 }
 
 extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,

@@ -96,7 +96,8 @@ def normalize_u8(x):
 
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
-         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False):
+         epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False,
+         kblock=False):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -119,6 +120,7 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.epilogue = epilogue
     d.math = (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if math is None else math
     d.out_f32 = 1 if out_f32 else 0
+    d.kblock = 1 if kblock else 0
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv

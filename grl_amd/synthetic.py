@@ -39,7 +39,7 @@ def _rng(name, seed):
 # is meaningful.  The default profile (wide gains) stays as the ill-conditioned stress case.
 _COND_BN3_GAMMA = (0.1, 0.2)
 _COND_GAMMA = (0.9, 1.1)
-_COND_BETA = (1.0, 2.0)
+_COND_BETA = (1.5, 2.5)
 
 
 def synth_tensor(name, shape, seed=0, is_bn=False, profile='default'):

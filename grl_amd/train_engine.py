@@ -26,6 +26,7 @@ def gemm(*args, **kw):
     (engine.set_math / GRL_MATH, an eval-only switch) must not leak into the training forward and
     data-gradient GEMMs -- every train parity claim is made in fp32."""
     kw.setdefault('math', MATH_F32)
+    kw.setdefault('kblock', True)        # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock)
     return engine.gemm(*args, **kw)
 
 FRAME_C = 2048
@@ -178,7 +179,13 @@ def colsum_into(g, M, Ccols, out, ld=None):
 
 
 class _BNState(object):
-    __slots__ = ('mean', 'invstd', 'scale', 'shift')
+    __slots__ = ('mean', 'invstd', 'scale', 'shift', 'beta')
+
+
+def bn_apply(z, st, res, y, M, Cc, relu):
+    """y = relu?((z - mean) * gamma*invstd + beta + res) -- centred first, as torch's train kernel."""
+    _call('grl_bn_apply_centered', ptr(z), ptr(st.mean), ptr(st.scale), ptr(st.beta), ptr(res), ptr(y), M, Cc,
+          1 if relu else 0)
 
 
 def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None, pivot=None):
@@ -189,6 +196,7 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     beta = bn.bias if beta is None else beta
     rm = bn.running_mean if rm is None else rm
     rv = bn.running_var if rv is None else rv
+    st.beta = beta
     # num_batches_tracked (torch's int64 counter) is bumped by the same launch
     _call('grl_bn_stats_finalize', ptr(slab), rows, Cc, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
           ptr(bn.num_batches_tracked), C.c_float(bn.momentum), C.c_float(bn.eps), ptr(st.mean), ptr(st.invstd),
@@ -233,7 +241,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
                    stats=True, conv=geom)
     st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
     a = _new((M, N), x)
-    _call('grl_bn_apply', ptr(z), ptr(st.scale), ptr(st.shift), ptr(res), ptr(a), M, N, 1 if relu else 0)
+    bn_apply(z, st, res, a, M, N, relu)
 
     def bwd():
         da = tp.take(a)
@@ -347,7 +355,7 @@ def linear_bn_relu(tp, x, M, lin, bn):
     _call('grl_col_stats', ptr(z), ptr(slab), M, N, N, ptr(z))           # pivot = row 0 of z
     st = bn_finalize(slab, rows, N, M, bn, tp.dev, pivot=z)
     a = _new((M, N), x)
-    _call('grl_bn_apply', ptr(z), ptr(st.scale), ptr(st.shift), None, ptr(a), M, N, 1)
+    bn_apply(z, st, None, a, M, N, True)
 
     def bwd():
         da = tp.take(a)
@@ -390,7 +398,7 @@ def bn1d_l2norm(tp, f, rows, Cc, bn):
     _call('grl_col_stats', ptr(f), ptr(slab), rows, Cc, Cc, ptr(f))
     st = bn_finalize(slab, nr, Cc, rows, bn, tp.dev, pivot=f)
     y = _new((rows, Cc), f)
-    _call('grl_bn_apply', ptr(f), ptr(st.scale), ptr(st.shift), None, ptr(y), rows, Cc, 0)
+    bn_apply(f, st, None, y, rows, Cc, False)
     out = _new((rows, Cc), f)
     _call('grl_affine_l2norm', ptr(y), None, None, ptr(out), rows, Cc, Cc)
 
@@ -426,7 +434,7 @@ def trunk_train(tp, model, x):
     _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64, ptr(z0))
     st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev, pivot=z0)
     a0 = _new((M0, 64), x)
-    _call('grl_bn_apply', ptr(z0), ptr(st.scale), ptr(st.shift), None, ptr(a0), M0, 64, 1)
+    bn_apply(z0, st, None, a0, M0, 64, True)
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     p0 = _new((n * Hp * Wp, 64), x)
     _call('grl_maxpool3x3s2', ptr(a0), ptr(p0), n, Hs, Ws, 64)
@@ -510,7 +518,7 @@ def gce_train(tp, model, x4, b, t):
     bn6.running_mean.copy_(rm32[:1])
     bn6.running_var.copy_(rv32[:1])
     y3 = _new((M, 32), x4)
-    _call('grl_bn_apply', ptr(z3), ptr(st.scale), ptr(st.shift), None, ptr(y3), M, 32, 0)
+    bn_apply(z3, st, None, y3, M, 32, False)
     cmap = _new((M,), x4)
     xc, xu = _new((M, 2048), x4), _new((M, 2048), x4)
     _call('grl_gate_apply', ptr(y3), 32, ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 2048)
@@ -723,17 +731,19 @@ def attn_train(tp, siam, x, b, t):
     gemm(x, wqk, z, M, 2 * D, Cc, shift=bqk)
     rows = _lib.load().grl_col_stats_rows(M)
     sts = []
-    scale, shift = _new((2 * D,), x), _new((2 * D,), x)
+    both = _BNState()
+    both.mean, both.scale, both.beta = _new((2 * D,), x), _new((2 * D,), x), _new((2 * D,), x)
     for h, bn in enumerate((siam.featQ_bn, siam.featK_bn)):
         slab = _new((rows, 2, D), x)
         zh = z[:, h * D:]
         _call('grl_col_stats', ptr(zh), ptr(slab), M, D, 2 * D, ptr(zh))
         st = bn_finalize(slab, rows, D, M, bn, tp.dev, pivot=zh)
-        scale[h * D:(h + 1) * D] = st.scale
-        shift[h * D:(h + 1) * D] = st.shift
+        both.mean[h * D:(h + 1) * D] = st.mean
+        both.scale[h * D:(h + 1) * D] = st.scale
+        both.beta[h * D:(h + 1) * D] = bn.bias.detach()
         sts.append(st)
     qk = _new((M, 2 * D), x)
-    _call('grl_bn_apply', ptr(z), ptr(scale), ptr(shift), None, ptr(qk), M, 2 * D, 0)
+    bn_apply(z, both, None, qk, M, 2 * D, False)
     out = _new((b, Cc), x)
     _call('grl_siamese_attn', ptr(qk), ptr(x), ptr(out), b, t, D, Cc, Cc)
 
@@ -786,7 +796,7 @@ def verify_train(tp, head, probe, gallery):
     _call('grl_col_stats', ptr(diff), ptr(slab), P, K, K, ptr(diff))
     st = bn_finalize(slab, rows, K, P, bn, tp.dev, pivot=diff)
     dn = _new((P, K), probe)
-    _call('grl_bn_apply', ptr(diff), ptr(st.scale), ptr(st.shift), None, ptr(dn), P, K, 0)
+    bn_apply(diff, st, None, dn, P, K, False)
     wpad = torch.zeros(32, K, dtype=torch.float32, device=tp.dev)
     wpad[:ncls] = lin.weight.detach()
     bpad = _pad32(lin.bias)

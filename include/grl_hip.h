@@ -83,6 +83,11 @@ typedef struct GrlGemm {
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
     int32_t math;          /* GRL_MATH_*: multiplier datapath (accumulation is always fp32)   */
     int32_t out_f32;       /* GRL_MATH_BF16S only: write y as fp32                            */
+    int32_t kblock;        /* GRL_MATH_F32 only: 1 = cut the accumulation chain every 512 k and sum the
+                              segments (K-blocked accumulation: the accuracy class of a blocked CPU
+                              sgemm; ~4 % slower on K >= 1024).  The train-mode forward sets it -- ReLU
+                              masks, hence parameter gradients, agree with the reference's only as well
+                              as the forward does; 0 = ONE k-ordered fmaf chain (eval path, evaluator). */
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
@@ -231,6 +236,11 @@ int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, con
 /* step 2: y = relu?(z*scale + shift + res) */
 int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res,
                  float* y, int64_t M, int C, int relu, void* stream);
+/* step 2, train-mode form: y = relu?((z - mean)*scale + beta + res), centred before the multiply as
+ * torch's training kernel does (F.batch_norm(training=True); resnets1.py:76-91, grl_model.py:222-226):
+ * exact where the folded form cancels (BatchNorm1d over a few similar rows).  beta may be NULL. */
+int grl_bn_apply_centered(const float* z, const float* mean, const float* scale, const float* beta,
+                          const float* res, float* y, int64_t M, int C, int relu, void* stream);
 
 /* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask);
  * dgamma += sum g*xhat; dbeta += sum g; dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).

@@ -240,7 +240,7 @@ def pairwise_distance(x, y):
     return d.clamp(min=1e-12).sqrt()
 
 
-def fma_chain_dot(q, g, order=None):
+def fma_chain_dot(q, g, order=None, kblock=False):
     """Bit-exact model of the HIP GEMM's accumulation ('GEMM
     numerics'): every output element is ONE fp32 accumulator updated by a
     k-ordered chain of fused multiply-adds, acc = fma(q[k], g[k], acc), which
@@ -256,10 +256,14 @@ def fma_chain_dot(q, g, order=None):
     k = q.shape[1]
     order = np.arange(k) if order is None else np.asarray(order)
     acc = np.zeros((q.shape[0], g.shape[0]), np.float32)
-    for kk in order:
+    tot = np.zeros_like(acc)
+    for n, kk in enumerate(order):
         acc = (q[:, kk:kk + 1].astype(np.float64) * g[None, :, kk].astype(np.float64)
                + acc.astype(np.float64)).astype(np.float32)
-    return acc
+        if kblock and (n + 1) % 512 == 0 and n + 1 < k:   # segment boundary (gemm_f32.hip SEG_STAGES)
+            tot = tot + acc
+            acc = np.zeros_like(acc)
+    return acc + tot if (kblock and k > 512) else acc
 
 
 def evaluate(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=100):

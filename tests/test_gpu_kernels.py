@@ -40,6 +40,43 @@ def test_gemm_bit_exact_vs_fma_chain(dev, M, N, K):
     assert np.array_equal(got, ref), 'max diff %g' % np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize('M,N,K,conv', [(300, 200, 2048, None), (64, 130, 4608, None), (4096, 512, 1024, None),
+                                        (2 * 16 * 8, 96, 9 * 128, (16, 8, 128, 16, 8, 3, 3, 1, 1)),
+                                        (128, 64, 512, None)])
+def test_gemm_kblock_bit_exact_and_more_accurate(dev, M, N, K, conv):
+    """GrlGemm.kblock (the train-mode forward's K-blocked accumulation: the chain cut every 512 k,
+    segments summed in order) equals the C oracle's blocked chain bit for bit on every tile shape,
+    dense and implicit-GEMM, and is closer to the exact product than the single chain on
+    positive-mean operands (where a long fp32 chain drifts)."""
+    from grl_amd import engine
+    from oracle.ref_c import chain_gemm
+    rng = np.random.default_rng(M + N + K)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    if conv is None:
+        a = (rng.standard_normal((M, K)) + 1.5).astype(np.float32)
+        cols = a
+        xa = torch.from_numpy(a).to(dev)
+    else:
+        H, W, Cc = conv[0], conv[1], conv[2]
+        n = M // (H * W)
+        x = (rng.standard_normal((n, H, W, Cc)) + 1.5).astype(np.float32)
+        xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+        cols = np.stack([xp[:, ky:ky + H, kx:kx + W] for ky in range(3) for kx in range(3)], 3).reshape(M, K)
+        xa = torch.from_numpy(x).to(dev)
+    wd = torch.from_numpy(w).to(dev)
+    y1, y0 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    engine.gemm(xa, wd, y1, M, N, K, conv=conv, kblock=True)
+    engine.gemm(xa, wd, y0, M, N, K, conv=conv)
+    assert np.array_equal(y1.cpu().numpy(), chain_gemm(cols, w, kblock=True))
+    assert np.array_equal(y0.cpu().numpy(), chain_gemm(cols, w))
+    if K > 512:
+        exact = cols.astype(np.float64) @ w.astype(np.float64).T
+        e1 = np.linalg.norm(y1.cpu().numpy() - exact); e0 = np.linalg.norm(y0.cpu().numpy() - exact)
+        assert e1 < e0, (e1, e0)
+    else:
+        assert torch.equal(y0, y1)
+
+
 def test_gemm_epilogue_affine_residual_relu_gbias(dev):
     from grl_amd import engine
     rng = np.random.default_rng(3)

@@ -726,3 +726,32 @@ def test_train_forward_backward_realistic_batch_vs_float64_oracle():
         print('   %-60s hip %.2e  fp32 oracle %.2e' % (k, e_hip[k], e_ref[k]))
     assert qh[0] <= 2.0 * qr[0] + 1e-4 and qh[1] <= 2.0 * qr[1] + 1e-4 and qh[2] <= 3.0 * qr[2] + 1e-3
     assert ratio < 8.0
+
+
+def test_eval_plan_follows_running_stats_changed_by_train_forward():
+    """the train-mode kernels update BatchNorm running statistics through raw device
+    pointers, which torch's version counters never see.  eval -> train-mode forwards under no_grad
+    (no optimizer step) -> eval must fold the NEW statistics: equal to a freshly built model that
+    loads the state_dict, and different from the stale first result."""
+    import copy
+    from grl_amd import engine
+    cnn, siam, _ = _fresh_models()
+    clips = synth_clips(2, 2, seed=9).cuda()
+    cnn.eval(); siam.eval()
+    before = engine.extract_features(cnn, siam, clips).clone()
+    graphed = engine.GraphedExtractor(cnn, siam)
+    assert torch.equal(graphed(clips), before)
+    cnn.train(); siam.train()
+    with torch.no_grad():
+        for s in (3, 4):
+            xu, xc = cnn(synth_clips(2, 2, seed=s).cuda())
+            siam(xc)
+    cnn.eval(); siam.eval()
+    after = engine.extract_features(cnn, siam, clips)
+    cnn2, siam2, _ = _fresh_models()
+    cnn2.load_state_dict(copy.deepcopy(cnn.state_dict())); siam2.load_state_dict(copy.deepcopy(siam.state_dict()))
+    cnn2.eval(); siam2.eval()
+    fresh = engine.extract_features(cnn2, siam2, clips)
+    assert torch.equal(after, fresh)
+    assert not torch.equal(after, before)
+    assert torch.equal(graphed(clips), fresh)            # the captured graphs were dropped too

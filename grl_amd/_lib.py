@@ -40,6 +40,7 @@ _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
+    'grl_gemm_bf16_tile_mode': ([C.c_int], C.c_int),
     'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),
     'grl_stem_conv7x7': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),

@@ -27,3 +27,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
+
+// gemm_bf16.hip: 256 x 256 bf16-storage tile.  1 = launched, 0 = shape not covered (use the
+// 128 x 128 family), < 0 = error.
+struct GrlGemm;
+int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s);

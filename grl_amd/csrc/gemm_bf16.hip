@@ -1,0 +1,300 @@
+// bf16-storage GEMM / implicit-GEMM convolution for gfx950 (MI355X), large-tile form.
+//
+//   Y[M][N] = epilogue( A[M][K] . W[N][K]^T ),  A, W, residual, Y bf16 in HBM, fp32 accumulate
+//
+// This is the GRL_MATH_BF16S datapath of grl_conv_gemm_f32 for the shapes that can fill the chip
+// with 256 x 256 output tiles (BASELINE configs[2]: every N >= 256 layer from layer 3 on, the GCE
+// convs and the TRL 2048-wide 1x1s).  Round 1's 128 x 128 x 64 tile moved 32 KB out of L2 per
+// 2*128*128*64 FLOP = 64 FLOP/B and saturated the L2 -> CU path at ~0.7 PFLOP/s; this tile halves
+// the bytes per FLOP, and its staging costs no VGPRs and no ds_write:
+//
+//   * workgroup = 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
+//     (v_mfma_f32_32x32x16_bf16, 128 accumulator registers), one workgroup per CU;
+//   * K stage = 64 bf16 = 128-byte rows, two stages of (256 + 256) rows = 128 KiB of LDS;
+//   * staging is LDS-DMA (`global_load_lds_dwordx4`): a wave-instruction writes 8 rows x 128 B
+//     linearly, the XOR swizzle of the 16-byte chunks ((row >> 1) & 7, conflict-free
+//     ds_read_b128) is applied to the per-lane SOURCE address and again on the fragment read;
+//   * implicit GEMM: a lane's source is row (image, oy, ox) at the stage's tap -- out-of-image
+//     taps read a zero page -- so 1x1 / 3x3, stride 1 / 2 convolutions need no im2col;
+//   * the loads of stage t+1 are issued before the MFMAs of stage t and retire at the one
+//     barrier per stage (the compiler's vmcnt(0) in front of it);
+//   * epilogue: each wave parks 32 x 64 accumulator blocks in its own LDS slab and reads them
+//     back row-major: 8 channels = 16 bytes per lane for scale / shift / per-clip bias /
+//     residual / ReLU / bf16 store.
+//
+// Reference call sites of the convolutions it runs: reid/models/resnets1.py:62-68,73-93,
+// basebranch.py:42-50, grl_model.py:56-64,95-121.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TB = 256;                       // tile rows = tile cols
+constexpr int ROWB = 128;                     // bytes of one staged row (64 bf16)
+constexpr int STAGE = 2 * TB * ROWB;          // A + B tile of one stage: 64 KiB
+
+__device__ uint4 g_zero_row[8];               // 128 zero bytes: source of out-of-image taps
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// one LDS-DMA wave-instruction: lane l's 16 bytes at `g` land at lds + 16*l
+__device__ __forceinline__ void glds16(const char* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds, 16, 0, 0);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
+                                                               const int num_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- staging rows: wave w fills the 8-row blocks w, w+8, w+16, w+24 of both operands ----
+    const int srow = lane >> 3, schunk = lane & 7;
+    const int sw = (schunk ^ (((srow >> 1) + 4 * (wave & 1)) & 7)) << 4;   // swizzled source chunk (bytes)
+    const char* abase[4];
+    const char* bsrc[4];
+    int iy0[4], ix0[4];
+    const char* const a8 = reinterpret_cast<const char*>(p.a);
+    const char* const w8 = reinterpret_cast<const char*>(p.w);
+    const char* const zrow = reinterpret_cast<const char*>(g_zero_row) + sw;
+    int m0, n0;
+
+    // Persistent workgroups (one per CU) walk tiles t = blockIdx.x, + gridDim.x, ...  XCD-aware
+    // order: blocks b, b+8, ... share an XCD (gridDim.x is a multiple of 8 whenever a workgroup
+    // has more than one tile); each XCD gets a contiguous run of tiles, column tile fastest, so
+    // its 32 CUs share A row panels and sweep W together.
+    auto setup_tile = [&](int t) {
+        int bid = t;
+        {
+            const int q = num_tiles >> 3, r = num_tiles & 7, xcd = bid & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
+        const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+        m0 = tile_m * TB;
+        n0 = tile_n * TB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave + 8 * i) * 8 + srow;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;                           // edge rows are loaded, never stored
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                abase[i] = a8 + ((int64_t)img * p.H * p.W * p.C) * 2 + sw;
+                iy0[i] = oy * p.stride - p.pad;
+                ix0[i] = ox * p.stride - p.pad;
+            } else {
+                abase[i] = a8 + (int64_t)m * p.lda * 2 + sw;
+                iy0[i] = ix0[i] = 0;
+            }
+            int n = n0 + r;
+            n = n < p.N ? n : p.N - 1;
+            bsrc[i] = w8 + (int64_t)n * p.ldw * 2 + sw;
+        }
+    };
+
+    // One stage = 8 LDS-DMA wave-instructions per wave (4 A blocks, 4 W blocks), issued back to back
+    // at the top of the previous stage's MFMAs.  (Measured alternatives, all slower on MI355X:
+    // pieces spread between the MFMA groups, register double-buffered fragments with the emitted
+    // order pinned by sched_group_barrier, the last k-step rotated behind the barrier: -7 %.)
+    auto stage = [&](int s, int kt) {
+        char* const As = smem + s * STAGE;
+        char* const Bs = As + TB * ROWB;
+        int tap_ky = 0, tap_kx = 0, c0 = kt * 64;
+        if (CONV) {
+            const int tap = c0 / p.C;                        // wave-uniform: a stage lies inside one tap
+            c0 -= tap * p.C;
+            tap_ky = tap / p.kw;
+            tap_kx = tap - tap_ky * p.kw;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* src;
+            if (CONV) {
+                const int iy = iy0[i] + tap_ky, ix = ix0[i] + tap_kx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                src = ok ? abase[i] + ((int64_t)(iy * p.W + ix) * p.C + c0) * 2 : zrow;
+            } else {
+                src = abase[i] + (int64_t)kt * ROWB;
+            }
+            glds16(src, As + (wave + 8 * i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(bsrc[i] + (int64_t)kt * ROWB, Bs + (wave + 8 * i) * 1024);
+    };
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    const int nk = p.K / 64;
+    // epilogue slab of this wave: 32 x 64 fp32 in the SECOND stage buffer (the next tile's first
+    // stage is already landing in the first one); 16-byte chunks XOR-swizzled by (row >> 1) & 1
+    float* const Cs = reinterpret_cast<float*>(smem + STAGE) + wave * (32 * 64);
+    const int lrow = lane >> 3, lcol = (lane & 7) * 8;                        // 8 lanes per 64-wide row
+    __bf16* const y16 = reinterpret_cast<__bf16*>(p.y);
+    const __bf16* const r16 = reinterpret_cast<const __bf16*>(p.res);
+
+    int t = blockIdx.x;
+    setup_tile(t);
+    stage(0, 0);
+    for (;;) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        __syncthreads();          // stage 0 of this tile has landed; every wave is out of the previous epilogue
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);        // in flight under this stage's MFMAs
+            const char* const Ab = smem + cur * STAGE + (wr * 128 + frow) * ROWB;
+            const char* const Bb = smem + cur * STAGE + TB * ROWB + (wc * 64 + frow) * ROWB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                   // four k-steps of 16
+                const int ch = ((2 * q + fhalf) ^ fsw) << 4;
+                bf16x8 af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROWB + ch);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROWB + ch);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                // (vmcnt(0): stage kt+1 has landed)
+        }
+
+        // the K loop ended on a barrier: both stage buffers are free.  Request the NEXT tile's first
+        // stage now, so that it lands under this tile's epilogue.
+        const int cm0 = m0 + wr * 128, cn = n0 + wc * 64 + lcol;
+        const int next_t = t + (int)gridDim.x;
+        if (next_t < num_tiles) {
+            setup_tile(next_t);
+            stage(0, 0);
+        }
+
+        // ---- epilogue: acc[i][j][r] is Y[row][col], row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31 ----
+        const bool n_ok = cn < p.N;
+        f32x4 sc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (n_ok) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (p.scale) sc[u] = *reinterpret_cast<const f32x4*>(p.scale + cn + 4 * u);
+                if (p.shift) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // the four residual rows of this 32-row block are requested before the slab round trip
+            // (one dependent load per row would serialise the HBM-bound epilogue of a short-K layer)
+            bf16x8 res8[4];
+            if (r16) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = cm0 + i * 32 + it * 8 + lrow;
+                    if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + cn);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    Cs[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
+                }
+            // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + lrow;
+                const int m = cm0 + i * 32 + row;
+                if (m < p.M && n_ok) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
+                        if (p.gbias)
+                            v += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
+                        v = v * sc[u] + sh[u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float tt = v[e] + (r16 ? (float)res8[it][4 * u + e] : 0.f);
+                            if (p.relu) tt = tt > 0.f ? tt : 0.f;
+                            o[4 * u + e] = (__bf16)tt;
+                        }
+                    }
+                    *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                }
+            }
+        }
+        if (next_t >= num_tiles) break;
+        t = next_t;
+    }
+}
+
+bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+// -1 auto (default; GRL_GEMM_BF16_256 overrides it at load time), 0 never, 1 whenever legal
+int g_mode = [] {
+    const char* e = getenv("GRL_GEMM_BF16_256");
+    return e ? atoi(e) : -1;
+}();
+
+}  // namespace
+
+extern "C" int grl_gemm_bf16_tile_mode(int mode) {
+    const int old = g_mode;
+    if (mode >= -1 && mode <= 1) g_mode = mode;
+    return old;
+}
+
+// Returns 1 when the 256 x 256 kernel took the launch, 0 when the caller should use the
+// 128 x 128 family (shape / feature not covered), < 0 on error.
+int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
+    const int mode = g_mode;
+    if (mode == 0) return 0;
+    if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.stats || d.rowscale || d.out_f32) return 0;
+    if (d.K % 64 || d.N % 8 || d.ldy % 8 || (d.res && d.ldres % 8) || d.lda % 8 || d.ldw % 8) return 0;
+    if (d.conv && d.C % 64) return 0;
+    if (!al16(d.a) || !al16(d.w) || !al16(d.y) || !al16(d.res) || !al16(d.scale) || !al16(d.shift) || !al16(d.gbias))
+        return 0;
+    const int tiles_m = (d.M + TB - 1) / TB, tiles_n = (d.N + TB - 1) / TB;
+    const int64_t num_tiles = (int64_t)tiles_m * tiles_n;
+    // one workgroup per CU: fewer than ~3/4 of a wave of tiles leaves the chip idle and the
+    // 128 x 128 family (two workgroups per CU, 4x the tiles) does better
+    if (mode < 0 && (num_tiles < 192 || d.N < 256 || d.K < 128)) return 0;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        return true;
+    }();
+    (void)attr;
+    static const int cus = [] {                  // persistent grid: one 8-wave workgroup per CU, a multiple of 8
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        return n / 8 * 8 > 0 ? n / 8 * 8 : 8;
+    }();
+    const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
+    if (d.conv)
+        hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+    else
+        hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+    const int e = grl_check_launch("grl_conv_gemm_f32 (bf16 256x256)");
+    return e ? e : 1;
+}

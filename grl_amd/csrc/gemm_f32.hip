@@ -664,6 +664,10 @@ extern "C" int grl_conv_gemm_f32(const GrlGemm* desc, void* stream) {
     const GrlGemm& d = *desc;
     if (int e = validate(d)) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (d.math == GRL_MATH_BF16S) {
+        const int r = grl_gemm_bf16_256(d, s);       // large-tile LDS-DMA kernel where it can fill the chip
+        if (r != 0) return r < 0 ? r : GRL_OK;
+    }
     const TileChoice t = choose_tile(d);
     if (t.bm == 128 && t.bn == 128) return launch<128, 128>(d, s);
     if (t.bm == 128 && t.bn == 64) return launch<128, 64>(d, s);

@@ -91,6 +91,11 @@ typedef struct GrlGemm {
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
+/* Kernel-tuning / test hook of the GRL_MATH_BF16S datapath: which launches take the 256 x 256
+ * LDS-DMA tile (gemm_bf16.hip): -1 = automatic (enough tiles to fill the chip; the default),
+ * 0 = never, 1 = whenever the shape is legal.  Returns the previous mode; results do not depend
+ * on it (same MFMA, same k order).  Not thread-safe. */
+int grl_gemm_bf16_tile_mode(int mode);
 /* rows of the stats slab the call above writes (= number of M tiles it will use) */
 int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc);
 

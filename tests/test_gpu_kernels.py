@@ -341,6 +341,47 @@ def test_gemm_bf16_storage(dev, M, N, K, conv):
     assert torch.equal(y, y32.bfloat16())                               # one rounding on the store
 
 
+@pytest.mark.parametrize('M,N,K,conv,gb', [
+    (700, 520, 256, None, False),                                     # ragged M and N (N % 8 == 0), 3 x 3 tiles
+    (2 * 128 * 3, 256, 2048, None, True),                             # per-clip bias (GCE corr0), rows_per_group = 256
+    (3 * 16 * 8, 264, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1), False),   # 3x3 stride 1, zero-page taps
+    (2 * 8 * 8, 256, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1), False),  # 3x3 stride 2
+    (2 * 8 * 4, 512, 256, (16, 8, 256, 8, 4, 1, 1, 2, 0), False),       # 1x1 stride 2 (downsample)
+    (256, 256, 128, None, False)])
+def test_gemm_bf16_256_tile_equals_128_family(dev, M, N, K, conv, gb):
+    """The 256 x 256 LDS-DMA kernel (gemm_bf16.hip) against the 128 x 128 register-staged family on
+    the same GRL_MATH_BF16S call: same MFMA, same k order => bit-identical bf16 outputs, with
+    residual, ReLU, scale/shift, per-clip bias, ragged edges and every implicit-GEMM geometry."""
+    from grl_amd import engine, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N + K)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+    a = torch.from_numpy(rng.standard_normal((rows_in, cin)).astype(np.float32)).bfloat16().to(dev)
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).bfloat16().to(dev)
+    res = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).bfloat16().to(dev)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(dev)
+    sh = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    kw = dict(scale=sc, shift=sh, res=res, relu=True, conv=conv, math=2)
+    if gb:
+        kw.update(gbias=torch.from_numpy(rng.standard_normal((M // 256, N)).astype(np.float32)).to(dev), rows_per_group=256)
+    ys = []
+    try:
+        for mode in (0, 1):
+            lib.grl_gemm_bf16_tile_mode(mode)
+            y = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev)      # guard row: no write past M
+            engine.gemm(a, w, y, M, N, K, **kw)
+            ys.append(y)
+    finally:
+        lib.grl_gemm_bf16_tile_mode(-1)
+    assert torch.equal(ys[0], ys[1])
+    assert bool((ys[1][M] == 7.0).all())
+    ref = torch.empty(M, N, device=dev)
+    kw32 = dict(kw, res=res.float(), math=0)
+    engine.gemm(a.float(), w.float(), ref, M, N, K, **kw32)
+    assert torch.equal(ys[1][:M], ref.bfloat16()) or _rel(ys[1][:M].float().cpu().numpy(), ref.cpu().numpy()) < 8e-3
+
+
 def test_bf16_storage_pointwise_twins(dev):
     """bf16-storage twins of the bandwidth-bound kernels against their fp32 twins on
     bf16-representable data: identical fp32 results for the reductions, one rounding on bf16

@@ -126,14 +126,16 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
     cnn.train(); siam.train(); siamv.train()
     clips = synth_clips(B, T, seed=rank).to(dev)
     pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
-    bucket = grl_dist.GradBucket(params) if world > 1 else None
+    sync = grl_dist.GradSync(params) if world > 1 else None      # bucketed all-reduce under the backward
 
     def step():
         loss, _, _, _ = trainer._forward([clips], pids, 0, 0)
         opt.zero_grad()
+        if sync is not None:
+            sync.begin()
         loss.backward()
-        if bucket is not None:
-            bucket.allreduce_mean()
+        if sync is not None:
+            sync.finish()
         opt.step()
         return loss
 

@@ -1,13 +1,31 @@
-"""Data-parallel plumbing for training: one process per GPU, torch.distributed with
-the `nccl` backend (= RCCL over xGMI on ROCm) on the GPU node, `gloo` in the CPU tests.
+"""Data-parallel plumbing for training and evaluation: one process per GPU, torch.distributed
+with the `nccl` backend (= RCCL over xGMI on ROCm) on the GPU node, `gloo` in the CPU tests.
 
 The reference has no distributed code: it wraps the CNN in a single-process
-``nn.DataParallel`` (mars_train.py:80).  Here the global batch is split at PAIR
-granularity (Siamese.forward needs interleaved (anchor, positive) rows,
-Siamese.py:116), every rank keeps its own BatchNorm statistics (= DataParallel's
-per-replica BN) and the only exchange is ONE all-reduce per step of a flat fp32 bucket
-holding every parameter gradient (54.76 M values = 219 MB): on a fully connected xGMI
-node RCCL runs it as reduce-scatter + all-gather over all 7 links.
+``nn.DataParallel`` (mars_train.py:80).  Here
+
+* the global batch is split at PAIR granularity (``shard_pairs`` / ``ShardedPairSampler`` /
+  ``PairShardedBatches``: Siamese.forward needs interleaved (anchor, positive) rows,
+  Siamese.py:116, sampler.py:104-123);
+* every rank keeps its own BatchNorm statistics (= DataParallel's per-replica BN);
+* the only exchange of a step is the gradient average, ``GradSync``: the parameter gradients
+  of a step live in ONE flat fp32 buffer per tape (train_engine.Tape.reserve_param_grads; 54.76 M
+  values = 219 MB in all), cut into four contiguous buckets that are all-reduced
+  ASYNCHRONOUSLY as the backward finishes them -- TRL + tail (92 MB) first, then layer 4 + GCE,
+  layer 3, and layers 2/1 + stem -- so that on an 8-GPU xGMI node all but the last few MB ride
+  under the remaining backward kernels (RCCL runs a 219 MB all-reduce as reduce-scatter +
+  all-gather over all 7 links in ~0.4 ms; a ring would take ~2.5 ms);
+* the OIM look-up tables stay identical across ranks by replaying every rank's (feature, label)
+  block in rank order (``gather_rank_order``);
+* evaluation: clips are independent (no collective); the query x gallery matrix shards by
+  gallery rows (``sharded_distmat``, used by ATTEvaluator.evaluate when distributed).
+
+Documented difference from the reference's single-process DataParallel run: upstream only the
+CNN is replicated -- Siamese, the pair-verification matrix (n^2 BCE terms), the batch-hard
+triplet mining and classifierBN see the GLOBAL batch on device 0 (mars_train.py:80-82,
+trainer.py:137-162).  Here every rank builds them from its LOCAL pairs and the gradients are
+averaged: cross-rank negatives are not mined.  That is what north_star prescribes ("all-reduce
+on the gradient step only"); it is not bit-equivalent to a 2-GPU DataParallel run.
 """
 import torch
 import torch.distributed as dist
@@ -17,6 +35,9 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+# ----------------------------------------------------------------------------
+# batch sharding
+# ----------------------------------------------------------------------------
 def shard_pairs(batch_size, rank, world):
     """Index range [lo, hi) of this rank's rows of a global batch of interleaved pairs."""
     if batch_size % 2:
@@ -28,6 +49,58 @@ def shard_pairs(batch_size, rank, world):
     return 2 * per * rank, 2 * per * (rank + 1)
 
 
+def _rank_world(rank, world):
+    if rank is None or world is None:
+        if is_distributed():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+    return rank, world
+
+
+class ShardedPairSampler(torch.utils.data.Sampler):
+    """Wraps a sampler that emits consecutive (index, cross-camera positive) pairs -- the
+    reference's RandomPairSamplerForMars (sampler.py:83-125) -- and keeps, of every run of
+    ``global_batch`` indices, this rank's pair shard.  All ranks must iterate the base sampler
+    with the same seed; the DataLoader on top uses batch_size = global_batch // world, so a rank
+    decodes only its own clips and every local batch is whole pairs."""
+
+    def __init__(self, sampler, global_batch, rank=None, world=None):
+        self.sampler, self.global_batch = sampler, global_batch
+        self.rank, self.world = _rank_world(rank, world)
+        self.lo, self.hi = shard_pairs(global_batch, self.rank, self.world)
+
+    def __iter__(self):
+        run = []
+        for idx in self.sampler:
+            run.append(idx)
+            if len(run) == self.global_batch:
+                for j in run[self.lo:self.hi]:
+                    yield j
+                run = []
+        # a trailing partial global batch is dropped (the reference loader uses drop_last=True)
+
+    def __len__(self):
+        return len(self.sampler) // self.global_batch * (self.hi - self.lo)
+
+
+class PairShardedBatches(object):
+    """For a loader that already yields GLOBAL batches (imgs, pids, camids) on every rank: keep
+    this rank's pair shard of each batch (simple, but every rank decodes the whole batch --
+    prefer ShardedPairSampler)."""
+
+    def __init__(self, loader, rank=None, world=None):
+        self.loader = loader
+        self.rank, self.world = _rank_world(rank, world)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for imgs, pids, cams in self.loader:
+            lo, hi = shard_pairs(len(pids), self.rank, self.world)
+            yield imgs[lo:hi], pids[lo:hi], cams[lo:hi]
+
+
 def gather_rank_order(x, y, group=None):
     """(features, labels) of every rank concatenated in rank order -- the OIM look-up tables
     replay all ranks' updates in that order so they stay identical without a broadcast
@@ -37,8 +110,8 @@ def gather_rank_order(x, y, group=None):
     world = dist.get_world_size(group)
     xl = [torch.empty_like(x) for _ in range(world)]
     yl = [torch.empty_like(y) for _ in range(world)]
-    dist.all_gather(xl, x.contiguous(), group=group)
-    dist.all_gather(yl, y.contiguous(), group=group)
+    _all_gather(xl, x.contiguous(), group)
+    _all_gather(yl, y.contiguous(), group)
     return torch.cat(xl), torch.cat(yl)
 
 
@@ -64,15 +137,163 @@ def sharded_distmat(qf, gf, fn, group=None):
     if hi > lo:
         block[:, :hi - lo] = fn(qf, gf[lo:hi].contiguous())
     blocks = [torch.empty_like(block) for _ in range(world)]
-    dist.all_gather(blocks, block, group=group)
+    _all_gather(blocks, block, group)
     cols = [blocks[r][:, :shard_rows(ng, r, world)[1] - shard_rows(ng, r, world)[0]] for r in range(world)]
     return torch.cat(cols, 1)
 
 
+def gather_feature_batches(mine, n_batches, group=None):
+    """Evaluation feature extraction sharded by batch (batch i belongs to rank i % world; clips are
+    independent): ``mine`` = [(batch index, features [r_i, D], pids, camids)] of this
+    rank -> the full, batch-ordered (features, pids, camids) on every rank.  One padded all_gather
+    of the feature rows (RCCL) and one all_gather_object of the small id lists."""
+    if not is_distributed():
+        mine = sorted(mine, key=lambda e: e[0])
+        return torch.cat([e[1] for e in mine], 0), [x for e in mine for x in e[2]], [x for e in mine for x in e[3]]
+    world = dist.get_world_size(group)
+    meta = [None] * world
+    dist.all_gather_object(meta, [(i, f.size(0), list(p), list(c)) for i, f, p, c in mine], group=group)
+    rows = [sum(m[1] for m in r) for r in meta]
+    ref = mine[0][1] if mine else None
+    dims = [None] * world
+    dist.all_gather_object(dims, None if ref is None else (ref.size(1), str(ref.device)), group=group)
+    D = next(d[0] for d in dims if d is not None)
+    dev = ref.device if ref is not None else torch.device(next(d[1] for d in dims if d is not None))
+    width = max(rows)
+    block = torch.zeros((width, D), dtype=torch.float32, device=dev)
+    if mine:
+        block[:rows[dist.get_rank(group)]] = torch.cat([e[1] for e in mine], 0)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    _all_gather(blocks, block, group)
+    pieces = {}
+    for r in range(world):
+        off = 0
+        for i, nrow, pids, cams in meta[r]:
+            pieces[i] = (blocks[r][off:off + nrow], pids, cams)
+            off += nrow
+    order = sorted(pieces)
+    assert order == list(range(n_batches)), 'gather_feature_batches: missing batches'
+    return (torch.cat([pieces[i][0] for i in order], 0), [x for i in order for x in pieces[i][1]],
+            [x for i in order for x in pieces[i][2]])
+
+
+# ----------------------------------------------------------------------------
+# collectives (gloo cannot take device tensors on every build: stage through the host there)
+# ----------------------------------------------------------------------------
+def _host_staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _all_gather(outs, t, group=None):
+    if _host_staged(t, group):
+        houts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(houts, t.cpu(), group=group)
+        for o, h in zip(outs, houts):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+class _HostWork(object):
+    """all-reduce of a device tensor through the host (gloo test backend): completes at wait()."""
+
+    def __init__(self, t, group):
+        self.t, self.group = t, group
+
+    def wait(self):
+        h = self.t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        self.t.copy_(h)
+
+
+# ----------------------------------------------------------------------------
+# gradient averaging
+# ----------------------------------------------------------------------------
+class GradSync(object):
+    """Bucketed, backward-overlapped gradient averaging.
+
+    ``begin()`` (before ``loss.backward()``) registers the object with train_engine; while the
+    backward runs, every tape hands over contiguous slices of its flat gradient buffer as soon as
+    all gradients inside are final (``reduce``): an asynchronous all-reduce is launched on each --
+    torch's NCCL/RCCL work stream first waits for the kernels already queued on the compute stream,
+    i.e. the producers of that slice, and the backward kernels that follow overlap the transfer.
+    ``finish()`` (before ``optimizer.step()``) waits for the collectives, divides by the world size
+    and makes sure every ``p.grad`` holds the averaged values (autograd normally adopts the tape's
+    views as ``p.grad``, in which case nothing is copied).
+
+    Parameters that never receive a gradient (Siamese.featV*, the unused uncorr verification
+    head) sit in the flat buffers as zeros on every rank; their ``p.grad`` stays None everywhere --
+    ``finish`` asserts once that the None-pattern is identical across ranks."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if is_distributed() else 1
+        self._works = []          # (work, flat slice)
+        self._owned = []          # (param, flat, offset) of every tape-owned gradient of this step
+        self._checked = False
+        self.launched = []        # (label, numel) per collective of the last step (tests / logging)
+
+    # -- protocol with train_engine.Tape -------------------------------------------------------
+    def begin(self):
+        from . import train_engine
+        train_engine.set_grad_sync(self)
+        self._works, self._owned, self.launched = [], [], []
+
+    def own(self, param, flat, offset):
+        self._owned.append((param, flat, offset))
+
+    def reduce(self, piece, label=''):
+        """Average ``piece`` (a contiguous slice of a flat gradient buffer) over the ranks; returns
+        at once, the result is valid after ``finish()``."""
+        self.launched.append((label, piece.numel()))
+        if self.world == 1 or piece.numel() == 0:
+            return
+        if _host_staged(piece, self.group):
+            self._works.append((_HostWork(piece, self.group), piece))
+        else:
+            self._works.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True), piece))
+
+    def finish(self):
+        from . import train_engine
+        train_engine.set_grad_sync(None)
+        inv = 1.0 / self.world
+        for work, piece in self._works:
+            work.wait()
+            piece.mul_(inv)
+        self._works = []
+        stray = []
+        for p, flat, off in self._owned:
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() != flat.data_ptr() + 4 * off:      # autograd copied instead of adopting the view
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+        owned = set(id(p) for p, _, _ in self._owned)
+        for p in self.params:                                       # gradients no tape owns (none on this path)
+            if id(p) not in owned and p.grad is not None:
+                stray.append(p)
+        if stray and self.world > 1:
+            for p in stray:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+                p.grad.mul_(inv)
+        if not self._checked and self.world > 1:
+            mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32)
+            if dist.get_backend(self.group) != 'gloo':              # RCCL reduces device tensors only
+                mask = mask.to(self.params[0].device)
+            lo, hi = mask.clone(), mask.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError('GradSync: the set of parameters that receive gradients differs across ranks')
+            self._checked = True
+        self._owned = []
+
+
 class GradBucket(object):
-    """Flat gradient bucket.  Parameters that never receive a gradient on any rank
-    (Siamese.featV*, the unused uncorr verification head) contribute zeros so the
-    bucket layout is identical on every rank."""
+    """Non-overlapped fallback: copies every ``p.grad`` into one flat buffer, ONE blocking
+    all-reduce, copies back.  Kept for optimisers / modules whose gradients are not produced by
+    the GRL tapes; the trainer uses ``GradSync``.  Parameters whose ``p.grad`` is None contribute
+    zeros (the layout is rank-invariant) and stay None."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -90,7 +311,10 @@ class GradBucket(object):
                 self.flat[off:off + n].zero_()
             off += n
         if is_distributed():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if _host_staged(self.flat, group):
+                _HostWork(self.flat, group).wait()
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
         off = 0
         for p in self.params:

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from grl_amd import engine
+from grl_amd import dist as grl_dist
 from .eva_functions import evaluate
 from .rerank import re_ranking
 
@@ -53,9 +54,14 @@ class ATTEvaluator(object):
         self.cnn_model.eval()
         self.siamese_model.eval()
         dev = self._device()
-        feats, pids_all, cams_all = [], [], []
+        rank, world = grl_dist._rank_world(None, None)
+        # data parallel (one process per GPU): batch i is extracted by rank i % world -- clips are
+        # independent, there is no collective on the data path -- and the rows are all-gathered once
+        own = [i for i in range(len(data_loader)) if i % world == rank]
+        batches = (b for i, b in enumerate(data_loader) if i % world == rank)
+        mine = []
         # the next batch's host->device copy overlaps this batch's kernels (side HIP stream)
-        for imgs, pids, camids in engine.DevicePrefetcher(data_loader, dev):
+        for i, (imgs, pids, camids) in zip(own, engine.DevicePrefetcher(batches, dev)):
             if self.only_eval:
                 # dense mode: one tracklet per item, all its clips; features are averaged
                 # over clips (attevaluator.py:68-98)
@@ -64,12 +70,12 @@ class ATTEvaluator(object):
                 parts = [engine.extract_features(self.cnn_model, self.siamese_model,
                                                  clips[y * self.chunk:(y + 1) * self.chunk])
                          for y in range(int(math.ceil(b * n / float(self.chunk))))]
-                feats.append(engine.rows_mean(torch.cat(parts, 0)))
+                feat = engine.rows_mean(torch.cat(parts, 0))
             else:
-                feats.append(engine.extract_features(self.cnn_model, self.siamese_model, imgs))
-            pids_all.extend(pids)
-            cams_all.extend(camids)
-        return torch.cat(feats, 0), np.asarray(pids_all), np.asarray(cams_all)
+                feat = engine.extract_features(self.cnn_model, self.siamese_model, imgs)
+            mine.append((i, feat, [int(x) for x in pids], [int(x) for x in camids]))
+        feat, pids_all, cams_all = grl_dist.gather_feature_batches(mine, len(data_loader))
+        return feat, np.asarray(pids_all), np.asarray(cams_all)
 
     def evaluate(self, query, gallery, query_loader, gallery_loader, path, visual, rerank):
         if visual:
@@ -82,7 +88,7 @@ class ATTEvaluator(object):
         g_camids = np.append(q_camids, g_camids)
         print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
         print("Computing distance matrix")
-        dist_dev = cosin_dist(qf, gf)
+        dist_dev = grl_dist.sharded_distmat(qf, gf, cosin_dist)     # gallery rows sharded over the ranks
         # ranking AND the per-query CMC / AP work on the device when the gallery fits one LDS sort
         # network (MARS: 11310 columns): neither the distance nor the index matrix leaves HBM
         if not rerank and dist_dev.shape[1] <= 16384:

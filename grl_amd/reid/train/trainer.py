@@ -46,8 +46,12 @@ class BaseTrainer(object):
         end = time.time()
         from grl_amd import engine
         batches = data_loader
+        if grl_dist.is_distributed() and not getattr(data_loader, 'grl_rank_sharded', False):
+            # a loader that yields GLOBAL batches on every rank: keep this rank's pair shard
+            # (loaders built on dist.ShardedPairSampler set .grl_rank_sharded = True)
+            batches = grl_dist.PairShardedBatches(data_loader)
         if torch.device(self.device).type == 'cuda':     # next batch's H2D copy under this step's kernels
-            batches = engine.DevicePrefetcher(data_loader, self.device)
+            batches = engine.DevicePrefetcher(batches, self.device)
         for i, inputs in enumerate(batches):
             data_time.update(time.time() - end)
             inputs, targets = self._parse_data(inputs)
@@ -59,11 +63,19 @@ class BaseTrainer(object):
             precisions2.update(corr_prec_id_frame, targets.size(0))
 
             optimizer1.zero_grad()
-            loss.backward()
-            if grl_dist.is_distributed():       # one RCCL all-reduce of the flat grad bucket
+            # data parallel: the gradient buckets are all-reduced (RCCL) while the backward still
+            # runs -- TRL + tail first, layers 2/1 + stem last -- and averaged before the step
+            sync = None
+            if grl_dist.is_distributed():
                 if self._bucket is None:
-                    self._bucket = grl_dist.GradBucket(self._all_params())
-                self._bucket.allreduce_mean()
+                    self._bucket = grl_dist.GradSync(self._all_params())
+                sync = self._bucket
+                sync.begin()
+            try:
+                loss.backward()
+            finally:
+                if sync is not None:
+                    sync.finish()
             optimizer1.step()
 
             batch_time.update(time.time() - end)

@@ -35,10 +35,20 @@ FRAME_C = 2048
 # ----------------------------------------------------------------------------
 # tape
 # ----------------------------------------------------------------------------
+_grad_sync = [None]      # grl_amd.dist.GradSync of the running step (data-parallel training), or None
+
+
+def set_grad_sync(sync):
+    _grad_sync[0] = sync
+
+
 class Tape(object):
     def __init__(self, dev):
         self.dev = dev
         self.ops = []
+        self.flat = None     # flat buffer of every parameter gradient of this tape
+        self.cuts = {}       # section name -> (lo, hi) of `flat`: gradients final once the section's backward is done
+        self._sent = 0       # elements of `flat` from the END already handed to the gradient sync
         self.g = {}          # id(forward tensor) -> gradient tensor
         self.pg = {}         # id(param) -> (param, grad)
         self.wc = {}         # packed weights for this step
@@ -75,16 +85,43 @@ class Tape(object):
         return self.g.pop(id(t), None)
 
     # gradients of parameters --------------------------------------------------
-    def reserve_param_grads(self, params):
+    def reserve_param_grads(self, params, cuts=None):
         """One zero-filled flat buffer for every parameter gradient of the step (one memset
-        instead of one fill per parameter); ``pgrad`` hands out views."""
+        instead of one fill per parameter); ``pgrad`` hands out views, which autograd adopts as
+        ``p.grad``.  ``cuts``: {section: index of its first parameter} -- in data-parallel training
+        the slice from that parameter to the previously sent one is all-reduced as soon as the
+        section's backward has run (``mark``)."""
         total = sum((p.numel() + 3) // 4 * 4 for p in params)
         flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-        off = 0
+        sync = _grad_sync[0]
+        off, offs = 0, []
         for p in params:
             n = p.numel()
             self._pview[id(p)] = flat[off:off + n].view_as(p)
+            if sync is not None:
+                sync.own(p, flat, off)
+            offs.append(off)
             off += (n + 3) // 4 * 4
+        self.flat = flat
+        self.cuts = {name: offs[i] for name, i in (cuts or {}).items()}
+
+    def mark(self, name):
+        """Forward: called where section ``name`` BEGINS.  Backward (reverse replay): runs once
+        everything recorded after it has run, i.e. when the gradients of the section's parameters
+        -- and of every later section's -- are final: hand that tail of the flat buffer to the
+        gradient sync, so its all-reduce overlaps the rest of the backward."""
+        def done():
+            self.flush(self.cuts.get(name), name)
+        self.ops.append(done)
+
+    def flush(self, lo=0, label='rest'):
+        sync = _grad_sync[0]
+        if sync is None or self.flat is None or lo is None:
+            return
+        hi = self.flat.numel() - self._sent
+        if lo < hi:
+            sync.reduce(self.flat[lo:hi], label)
+            self._sent = self.flat.numel() - lo
 
     def pgrad(self, p):
         e = self.pg.get(id(p))
@@ -422,6 +459,7 @@ def trunk_train(tp, model, x):
     n, _, H0, W0 = x.shape
     H, W = H0, W0
     tp.no_grad.add(id(x))
+    tp.mark('stem')
     Hs, Ws = H // 2, W // 2
     M0 = n * Hs * Ws
     conv1, bn1 = base[0], base[1]
@@ -456,6 +494,7 @@ def trunk_train(tp, model, x):
         tp.taps['pool'] = engine._to_nchw(p0, n, Hp, Wp)
     cur, H, W = p0, Hp, Wp
     for li in (4, 5, 6, 7):
+        tp.mark('layer%d' % (li - 3))
         for blk in base[li]:
             o1, _, _, _ = conv_bn(tp, cur, n, H, W, blk.conv1, blk.bn1, True)
             o2, Ho, Wo, _ = conv_bn(tp, o1, n, H, W, blk.conv2, blk.bn2, True)
@@ -565,6 +604,7 @@ def trl_train(tp, model, xu, xc, b, t):
     Cc, frame, Mb = FRAME_C, PIX * FRAME_C, b * PIX
     dirs = ((trl.forward_f1, trl.forward_f2, trl.channel_atte_foreward_corr, trl.uncorr_memo_forward),
             (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward))
+    tp.mark('trl')
     memo0 = _new((Mb, Cc), xu)
     _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
 
@@ -659,7 +699,7 @@ class _GrlTrainFn(torch.autograd.Function):
         model = model_box[0]
         engine.touch_state(model)            # running statistics change below, unseen by torch
         tp = Tape(inputs.device)
-        tp.reserve_param_grads(params)
+        tp.reserve_param_grads(params, cuts=_grl_cuts(model))
         tp.taps = getattr(model, '_grl_taps', None)
         b, t = inputs.shape[:2]
         x = inputs.contiguous().view(b * t, 3, 256, 128)
@@ -687,12 +727,28 @@ class _GrlTrainFn(torch.autograd.Function):
         if d_corr is not None:
             tp.g[id(xc_out)] = d_corr.contiguous().view(xc_out.shape)
         tp.backward()
+        tp.flush()                                   # (whatever no section mark has sent)
         grads = []
         for p in ctx.params:
             e = tp.pg.get(id(p))
             grads.append(e[1] if e is not None else None)
         ctx.tape = None
-        return (None, None) + tuple(grads)
+        tp.pg, tp._pview = {}, {}                    # the returned views must be the only references:
+        return (None, None) + tuple(grads)           # autograd then adopts them as p.grad (no copy)
+
+
+def _grl_cuts(model):
+    """Index (in model.parameters() order) of the first parameter of the sections whose completion
+    releases a gradient bucket: [0, layer3) -> 'stem', [layer3, layer4) -> 'layer3',
+    [layer4, TRL) (layer 4 + GCE) -> 'layer4', [TRL, end) (TRL + the two tail BatchNorms) -> 'trl'."""
+    cuts = getattr(model, '_grl_cut_cache', None)
+    if cuts is None:
+        names = [n for n, _ in model.named_parameters()]
+        first = lambda prefix: next(i for i, n in enumerate(names) if n.startswith(prefix))
+        cuts = {'stem': 0, 'layer3': first('backbone.base.6.'), 'layer4': first('backbone.base.7.'),
+                'trl': first('temporal_learning_block.')}
+        model._grl_cut_cache = cuts
+    return cuts
 
 
 def grl_forward_train(model, inputs):
@@ -833,6 +889,7 @@ class _SiameseTrainFn(torch.autograd.Function):
         siam = box[0]
         engine.touch_state(siam)
         tp = Tape(x.device)
+        tp.reserve_param_grads(params)
         bsz, t, d = x.shape
         half = bsz // 2
         xv = x.contiguous().view(half, 2, t, d)
@@ -863,8 +920,10 @@ class _SiameseTrainFn(torch.autograd.Function):
             dx[:, 0] = gp.view(half, t, d)
         if gg is not None:
             dx[:, 1] = gg.view(half, t, d)
+        tp.flush()
         grads = [tp.pg[id(p)][1] if id(p) in tp.pg else None for p in ctx.params]
         ctx.tape = None
+        tp.pg, tp._pview = {}, {}
         return (None, dx.view(bsz, t, d)) + tuple(grads)
 
 
@@ -874,6 +933,7 @@ class _VerifyTrainFn(torch.autograd.Function):
         head = box[0]
         engine.touch_state(head)
         tp = Tape(x.device)
+        tp.reserve_param_grads(params)
         bsz = x.shape[0]
         half = bsz // 2
         xv = x.contiguous().view(half, 2, -1)
@@ -899,8 +959,10 @@ class _VerifyTrainFn(torch.autograd.Function):
         if dout is not None:
             dx[:, 0] += dout[:half]
             dx[:, 1] += dout[half:]
+        tp.flush()
         grads = [tp.pg[id(p)][1] if id(p) in tp.pg else None for p in ctx.params]
         ctx.tape = None
+        tp.pg, tp._pview = {}, {}
         return (None, dx.view(ctx.bsz, -1)) + tuple(grads)
 
 

@@ -1,0 +1,180 @@
+"""Data-parallel training on ONE MI355X: two processes share cuda:0 and talk over gloo (device
+tensors are staged through the host by grl_amd.dist) -- the same GradSync / tape code path the
+8-GPU RCCL run takes, minus the transport.  RCCL itself cannot be exercised on a 1-GPU box."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, T = 8, 2                       # global batch: 4 pairs -> 2 pairs per rank
+
+
+def _models(dev):
+    import contextlib, io
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'))
+    siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'))
+    siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
+    return cnn.to(dev), siam.to(dev), siamv.to(dev)
+
+
+def _trainer(dev):
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    cnn, siam, siamv = _models(dev)
+    crit_c, crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    tr = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+    params = [p for m in (cnn, siam, siamv) for p in m.parameters()]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    return tr, opt, (cnn, siam, siamv), (crit_c, crit_u)
+
+
+def _batches():
+    from grl_amd.synthetic import synth_clips_structured
+    out = []
+    for step in range(2):
+        clips = synth_clips_structured(B, T, seed=40 + step)
+        pids = torch.tensor([5, 5, 9, 9, 300, 300, 77, 77]) + step
+        out.append((clips, pids, torch.zeros(B, dtype=torch.long)))
+    return out
+
+
+def _snapshot(mods, crits):
+    sd = {}
+    for i, m in enumerate(mods):
+        for k, v in m.state_dict().items():
+            sd['m%d.%s' % (i, k)] = v.detach().cpu().clone()
+    for i, c in enumerate(crits):
+        sd['lut%d' % i] = c.lut.detach().cpu().clone()
+    return sd
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    tr, opt, mods, crits = _trainer(dev)
+    assert tr.device.type == 'cuda'
+    launched = []
+    snaps = []
+    g0 = {}
+
+    def grab(optimizer, args, kwargs):                 # averaged gradients as the optimizer sees them, step 0
+        if not g0:
+            g0.update({'m%d.%s' % (i, k): p.grad.detach().cpu().clone() for i, m in enumerate(mods)
+                       for k, p in m.named_parameters() if p.grad is not None})
+    opt.register_step_pre_hook(grab)
+    for step, batch in enumerate(_batches()):
+        tr.train(step, [batch], opt)              # the trainer keeps this rank's pair shard of the global batch
+        launched.append(list(tr._bucket.launched))
+        snaps.append(_snapshot(mods, crits))
+    out[rank] = (snaps, launched, g0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_on_one_device_matches_averaged_gradients():
+    world, port = 2, 29700 + os.getpid() % 1500
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    (s0, l0, dp_grads), (s1, l1, _) = out[0], out[1]
+    # (1) both ranks hold identical parameters, BN-free buffers aside, and identical OIM tables after each step
+    for step in range(2):
+        for k in s0[step]:
+            if 'running_' in k or 'num_batches' in k:
+                continue                                   # per-rank BatchNorm statistics (= DataParallel replicas)
+            assert torch.equal(s0[step][k], s1[step][k]), (step, k)
+    # (2) the buckets went out in backward order: TRL + tail, layer 4 + GCE, layer 3, layers 2/1 + stem, then the
+    #     two Siamese tapes -- 54.76 M values in all
+    labels = [lab for lab, _ in l0[0]]
+    assert labels[-4:] == ['trl', 'layer4', 'layer3', 'stem'] or set(['trl', 'layer4', 'layer3', 'stem']) <= set(labels)
+    order = [lab for lab in labels if lab in ('trl', 'layer4', 'layer3', 'stem')]
+    assert order == ['trl', 'layer4', 'layer3', 'stem']
+    assert sum(n for _, n in l0[0]) >= 54758726
+    # (3) step 1 equals a single process that runs the two shards one after the other from the same
+    #     initial weights, averages the gradients and takes the same SGD step.  The OIM backward reads
+    #     its look-up table AFTER the clip-level update of the same step (oim.py:23-26), and in data
+    #     parallel that update replays every rank's (feature, label) block in rank order -- the
+    #     emulation feeds gather_rank_order the other shard's block, exactly what the peer would send.
+    from grl_amd import dist as grl_dist
+    import importlib
+    oim_mod = importlib.import_module('grl_amd.reid.loss.oim')
+    dev = torch.device('cuda:0')
+    tr, opt, mods, crits = _trainer(dev)
+    params = [p for m in mods for p in m.parameters()]
+    init = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+    clips, pids, _ = _batches()[0]
+    calls = [[], []]                                   # per shard: (x, y) of every OIM call, forward order
+    cur = [0]
+    real_fwd = oim_mod.OIMLoss.forward
+
+    def rec_fwd(self, inputs, targets):
+        calls[cur[0]].append((inputs.contiguous().detach(), targets.detach().clone()))
+        return real_fwd(self, inputs, targets)
+    oim_mod.OIMLoss.forward = rec_fwd
+    losses = []
+    try:
+        for r in range(world):
+            for m, sd in zip(mods, init):
+                m.load_state_dict(sd, strict=True)
+                m.train()
+            cur[0] = r
+            lo, hi = r * B // world, (r + 1) * B // world
+            losses.append(tr._forward([clips[lo:hi].to(dev)], pids[lo:hi].to(dev), 0, 0)[0])
+    finally:
+        oim_mod.OIMLoss.forward = real_fwd
+    where = {x.data_ptr(): k for r in range(world) for k, (x, y) in enumerate(calls[r])}
+
+    def fake_gather(x, y, group=None):
+        k = where[x.data_ptr()]
+        return (torch.cat([calls[r][k][0] for r in range(world)]),
+                torch.cat([calls[r][k][1].to(y.dtype) for r in range(world)]))
+    real_gather = grl_dist.gather_rank_order
+    grl_dist.gather_rank_order = fake_gather
+    grads = []
+    try:
+        for r in range(world):
+            for c in crits:
+                c.lut.zero_()
+            opt.zero_grad()
+            losses[r].backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in params])
+    finally:
+        grl_dist.gather_rank_order = real_gather
+    names = ['m%d.%s' % (i, k) for i, m in enumerate(mods) for k, _ in m.named_parameters()]
+    gerr = {}
+    for nme, g0, g1 in zip(names, grads[0], grads[1]):
+        if g0 is not None:
+            avg = ((g0 + g1) * 0.5).cpu()
+            gerr[nme] = float((dp_grads[nme] - avg).abs().max() / avg.abs().max().clamp_min(1e-30))
+    assert len(gerr) >= 190 and max(gerr.values()) < 1e-6, sorted(gerr.items(), key=lambda e: -e[1])[:5]
+    for m, sd in zip(mods, init):
+        m.load_state_dict(sd, strict=True)
+    opt.zero_grad()
+    for p, g0, g1 in zip(params, grads[0], grads[1]):
+        if g0 is not None:
+            p.grad = (g0 + g1) * 0.5
+    opt.step()
+    worst = 0.0
+    for mi, m in enumerate(mods):
+        for k, v in m.named_parameters():
+            ref = v.detach().cpu()
+            got = s0[0]['m%d.%s' % (mi, k)]
+            worst = max(worst, float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+    print('two-rank step vs averaged single-process gradients: worst relative parameter difference %.2e' % worst)
+    assert worst < 1e-6

@@ -315,3 +315,25 @@ def test_oim_out_of_range_labels_do_not_touch_memory():
     assert torch.isfinite(x.grad).all() and float(x.grad[1].abs().max()) == 0 and float(x.grad[2].abs().max()) == 0
     changed = (crit.lut != before).any(1).cpu().tolist()
     assert changed == [False, False, True, False, False, True]
+
+
+@pytest.mark.parametrize('M,N,K', [(4, 2048, 128), (4, 128, 2048), (2, 32, 2048), (7, 64, 64), (33, 96, 160), (4, 1024, 512)])
+def test_wgrad_tiny_M_ignores_memory_past_the_operands(M, N, K):
+    """dW = dz^T X with a handful of rows (TRL channel MLP: M = clips; verification head: M = pairs):
+    the operands sit inside poisoned allocations, so a read past row M-1 (stage padding) shows."""
+    from grl_amd import train_engine as TE
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(M * 131 + N + K)
+    dz = rng.standard_normal((M, N)).astype(np.float32)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    ref = dz.astype(np.float64).T @ x.astype(np.float64)
+    outs = []
+    for poison in (1e30, float('nan'), 0.0):
+        bz = torch.full((M + 64, N), poison, device=dev); bx = torch.full((M + 64, K), poison, device=dev)
+        bz[:M] = torch.from_numpy(dz).to(dev); bx[:M] = torch.from_numpy(x).to(dev)
+        dw = torch.zeros(N, K, device=dev)
+        TE.wgrad(bz[:M], bx[:M], dw, M, N, K, accumulate=0)
+        outs.append(dw.cpu().numpy())
+        assert np.isfinite(outs[-1]).all(), poison
+        assert _rel(outs[-1], ref) < 1e-5, poison
+    assert np.array_equal(outs[0], outs[2])

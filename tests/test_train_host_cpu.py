@@ -71,7 +71,29 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(3)
     qf, gf = torch.randn(5, 16, generator=g), torch.randn(11, 16, generator=g)
     dm = sharded_distmat(qf, gf, lambda q, gg: -q.mm(gg.t()))
-    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone())
+    # GradSync: a tape's flat gradient buffer, released in two pieces while "the backward runs";
+    # p (adopted view), q (autograd made a copy) and r (never gets a gradient)
+    from grl_amd.dist import GradSync, gather_feature_batches
+    p_, q_, r_ = (torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(2, 3)),
+                  torch.nn.Parameter(torch.zeros(3)))
+    sync = GradSync([p_, q_, r_])
+    sync.begin()
+    flat = torch.zeros(16)
+    for prm, off in ((p_, 0), (q_, 4), (r_, 12)):
+        sync.own(prm, flat, off)
+    flat[4:10] = float(10 * (rank + 1))            # "TRL" gradients are final first ...
+    sync.reduce(flat[4:16], 'late layers')
+    flat[0:4] = float(rank + 1)                    # ... the rest of the backward runs meanwhile
+    sync.reduce(flat[0:4], 'early layers')
+    p_.grad = flat[0:4].view_as(p_)                # autograd adopted the view
+    q_.grad = flat[4:10].view_as(q_).clone()       # autograd copied (pre-reduction values)
+    sync.finish()
+    sync_out = (p_.grad.clone(), q_.grad.clone(), r_.grad, list(sync.launched))
+    # evaluation features sharded by batch: rank r owns batches r, r + world, ...
+    feats = [(i, torch.full((2 + i, 3), float(i)), [i] * (2 + i), [7] * (2 + i)) for i in range(5) if i % world == rank]
+    gf, gp, gc = gather_feature_batches(feats, 5)
+    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone(), sync_out,
+                 (gf.clone(), gp, gc))
     dist.destroy_process_group()
 
 
@@ -81,7 +103,7 @@ def test_gradient_allreduce_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
-        ga, gb, gc, _, dm = out[r]
+        ga, gb, gc, _, dm = out[r][:5]
         g = torch.Generator().manual_seed(3)
         qf, gf = torch.randn(5, 16, generator=g), torch.randn(11, 16, generator=g)
         assert torch.equal(dm, -qf.mm(gf.t()))
@@ -92,3 +114,28 @@ def test_gradient_allreduce_gloo_world2():
         xs, ys = out[r][3]
         assert torch.equal(xs, torch.cat((torch.zeros(3, 8), torch.ones(3, 8))))
         assert ys.tolist() == [0, 2, 3, 1, 2, 3]
+        pg, qg, rg, launched = out[r][5]
+        assert torch.equal(pg, torch.full((4,), 1.5)) and torch.equal(qg, torch.full((2, 3), 15.0)) and rg is None
+        assert launched == [('late layers', 12), ('early layers', 4)]
+        gf, gp, gc = out[r][6]
+        assert gf.shape == (2 + 3 + 4 + 5 + 6, 3) and gp == [i for i in range(5) for _ in range(2 + i)]
+        assert torch.equal(gf[:, 0], torch.tensor([float(i) for i in range(5) for _ in range(2 + i)])) and set(gc) == {7}
+
+
+def test_sharded_pair_sampler_and_batches():
+    """Every rank iterates the same pair stream and keeps whole pairs of each global batch."""
+    from grl_amd.dist import ShardedPairSampler, PairShardedBatches
+    stream = [v for pair in range(20) for v in (100 + pair, 200 + pair)]      # (index, positive), 20 pairs
+    got = [list(ShardedPairSampler(stream, 8, rank=r, world=2)) for r in range(2)]
+    assert len(got[0]) == len(got[1]) == len(ShardedPairSampler(stream, 8, rank=0, world=2)) == 20
+    for r in range(2):
+        assert all(b - a == 100 for a, b in zip(got[r][0::2], got[r][1::2]))        # pairs stay together
+    merged = []                                        # local batches of 4 re-interleave to the global batches
+    for k in range(5):
+        merged += got[0][4 * k:4 * k + 4] + got[1][4 * k:4 * k + 4]
+    assert merged == stream
+    with pytest.raises(ValueError):
+        ShardedPairSampler(stream, 12, rank=0, world=4)
+    loader = [(torch.arange(8).view(8, 1), torch.arange(8), torch.zeros(8))]
+    parts = [list(PairShardedBatches(loader, rank=r, world=2))[0] for r in range(2)]
+    assert parts[0][1].tolist() == [0, 1, 2, 3] and parts[1][1].tolist() == [4, 5, 6, 7]

@@ -178,3 +178,47 @@ def test_two_rank_training_on_one_device_matches_averaged_gradients():
             worst = max(worst, float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
     print('two-rank step vs averaged single-process gradients: worst relative parameter difference %.2e' % worst)
     assert worst < 1e-6
+
+
+def _eval_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out[rank] = _run_eval()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_eval():
+    import contextlib, io
+    from torch.utils.data import DataLoader
+    from grl_amd.reid.evaluator import ATTEvaluator
+    from grl_amd.reid.data import SyntheticPairs
+    dev = torch.device('cuda:0')
+    cnn, siam, _ = _models(dev)
+    ev = ATTEvaluator(cnn, siam, only_eval=False)
+    q = DataLoader(SyntheticPairs(5, T, seed=11), batch_size=4)           # 10 clips: batches of 4, 4, 2
+    g = DataLoader(SyntheticPairs(13, T, seed=12), batch_size=4)          # 26 clips: 7 batches, ragged tail
+    qf, qp, qc = ev.extract_feature(q)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        r1 = ev.evaluate(None, None, q, g, None, False, False)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith(('Mean AP', 'Rank-'))]
+    return qf.cpu(), list(qp), list(qc), float(r1), lines
+
+
+def test_two_rank_evaluation_equals_single_process():
+    """ATTEvaluator under world_size 2 (batches dealt round-robin to the ranks, feature rows and the
+    gallery-sharded distance matrix all-gathered) prints the same metrics and returns bit-identical
+    features as a single process."""
+    world, port = 2, 31300 + os.getpid() % 1500
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    mp.spawn(_eval_worker, args=(world, port, out), nprocs=world, join=True)
+    ref = _run_eval()
+    for r in range(world):
+        assert torch.equal(out[r][0], ref[0]) and out[r][1] == ref[1] and out[r][2] == ref[2]
+        assert out[r][3] == ref[3] and out[r][4] == ref[4] and len(ref[4]) == 5

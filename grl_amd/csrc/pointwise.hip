@@ -614,9 +614,57 @@ __global__ void normalize_u8_kernel(const uint8_t* __restrict__ x, const float* 
         y[t] = ((float)x[t] / 255.f - norm[c]) / norm[3 + c];
     }
 }
+
+// Training augmentation + ToTensor + Normalize in one pass over raw uint8 clips [n][T][3][H][W]:
+//   RandomHorizontalFlip (whole clip), RandomSizedEarser (per frame, a constant-colour patch
+//   pasted AFTER the flip, seqtransforms.py:92-151), then ((float)u / 255 - mean) / std.
+// params[clip] = {flip, T x {erase, left, top, w, h, R, G, B}} drawn on the host
+// (grl_amd/reid/data/augment.py).  One thread per 4 output pixels of a row.
+__global__ void augment_normalize_u8_kernel(const uint8_t* __restrict__ x, const int* __restrict__ params,
+                                            const float* __restrict__ norm, float* __restrict__ y, int T,
+                                            int H, int W, int64_t total4) {
+    const int W4 = W >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % W4);
+        int64_t r = i / W4;
+        const int yy = (int)(r % H); r /= H;
+        const int c = (int)(r % 3); r /= 3;
+        const int t = (int)(r % T);
+        const int64_t clip = r / T;
+        const int* pc = params + clip * (1 + 8 * T);
+        const int flip = pc[0];
+        const int* pf = pc + 1 + 8 * t;
+        const int erase = pf[0], ex0 = pf[1], ey0 = pf[2], ex1 = pf[1] + pf[3], ey1 = pf[2] + pf[4];
+        const uint8_t colour = (uint8_t)pf[5 + c];
+        const uint8_t* row = x + (((clip * T + t) * 3 + c) * H + yy) * (int64_t)W;
+        const bool in_y = erase && yy >= ey0 && yy < ey1;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xx = xq * 4 + e;
+            uint8_t u = row[flip ? W - 1 - xx : xx];
+            if (in_y && xx >= ex0 && xx < ex1) u = colour;
+            o[e] = ((float)u / 255.f - norm[c]) / norm[3 + c];
+        }
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
 }  // namespace
 
 #define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_augment_normalize_u8(const uint8_t* x, const int* params, const float* mean_std, float* y,
+                                        int n_clips, int T, int H, int W, void* stream) {
+    GRL_REQUIRE(x && params && mean_std && y && n_clips > 0 && T > 0 && H > 0 && W > 0 && W % 4 == 0,
+                "augment_normalize_u8: bad args (W must be a multiple of 4)");
+    const int64_t total4 = (int64_t)n_clips * T * 3 * H * (W / 4);
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(augment_normalize_u8_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, params,
+                       mean_std, y, T, H, W, total4);
+    return grl_check_launch("grl_augment_normalize_u8");
+}
 
 extern "C" int grl_normalize_u8(const uint8_t* x, const float* mean_std, float* y, int n, int64_t plane,
                                 void* stream) {

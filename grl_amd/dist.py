@@ -96,9 +96,9 @@ class PairShardedBatches(object):
         return len(self.loader)
 
     def __iter__(self):
-        for imgs, pids, cams in self.loader:
+        for imgs, pids, cams, *extra in self.loader:
             lo, hi = shard_pairs(len(pids), self.rank, self.world)
-            yield imgs[lo:hi], pids[lo:hi], cams[lo:hi]
+            yield (imgs[lo:hi], pids[lo:hi], cams[lo:hi]) + tuple(e[lo:hi] for e in extra)
 
 
 def gather_rank_order(x, y, group=None):

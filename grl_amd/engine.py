@@ -94,6 +94,23 @@ def normalize_u8(x):
     return y
 
 
+def augment_normalize_u8(clips, params):
+    """Training augmentation on the device: uint8 clips [B,T,3,H,W] + the host-drawn decisions
+    (int32 [B, 1 + 8T], grl_amd.reid.data.augment) -> float32 clips, flipped / erased / normalised
+    exactly as the reference's PIL transforms would (seqtransforms.py:92-190, dataloader.py:51-57)."""
+    require_device(clips, 'clips', allow_u8=True)
+    if clips.dtype != torch.uint8 or clips.dim() != 5 or clips.shape[2] != 3:
+        raise ValueError('augment_normalize_u8 expects uint8 clips [B,T,3,H,W]')
+    b, t, _, h, w = clips.shape
+    params = params.to(device=clips.device, dtype=torch.int32).contiguous()
+    if tuple(params.shape) != (b, 1 + 8 * t):
+        raise ValueError('augmentation parameters must be [B, 1 + 8*T] (got %s)' % (tuple(params.shape),))
+    clips = clips.contiguous()
+    y = _new(clips.shape, clips)
+    _call('grl_augment_normalize_u8', ptr(clips), ptr(params), ptr(input_mean_std(clips.device)), ptr(y), b, t, h, w)
+    return y
+
+
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False,
@@ -663,14 +680,14 @@ class DevicePrefetcher(object):
 
     def _load(self):
         try:
-            imgs, pids, cams = next(self.it)
+            imgs, pids, cams, *extra = next(self.it)   # extra: e.g. the augmentation parameter block
         except StopIteration:
             self._next = None
             return
         if imgs.dtype not in (torch.uint8, torch.float32):
             imgs = imgs.float()
         if imgs.is_cuda:
-            self._next = (imgs, pids, cams, None, None)
+            self._next = (imgs, pids, cams, None, None, extra)
             return
         host = imgs.contiguous()
         host = host if host.is_pinned() else host.pin_memory()
@@ -678,7 +695,7 @@ class DevicePrefetcher(object):
             d = host.to(self.dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(self.stream)
-        self._next = (d, pids, cams, ev, host)         # `host` kept alive until the copy is consumed
+        self._next = (d, pids, cams, ev, host, extra)  # `host` kept alive until the copy is consumed
 
     def __iter__(self):
         return self
@@ -686,13 +703,13 @@ class DevicePrefetcher(object):
     def __next__(self):
         if self._next is None:
             raise StopIteration
-        d, pids, cams, ev, _host = self._next
+        d, pids, cams, ev, _host, extra = self._next
         if ev is not None:
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_event(ev)
             d.record_stream(cur)
         self._load()
-        return d, pids, cams
+        return (d, pids, cams) + tuple(extra)
 
 
 class GraphedExtractor(object):

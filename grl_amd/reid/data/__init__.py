@@ -11,16 +11,21 @@ from grl_amd.synthetic import synth_clips
 class SyntheticPairs(Dataset):
     """`n_pairs` x 2 clips; both clips of a pair share the pid, cameras differ."""
 
-    def __init__(self, n_pairs, seq_len, num_classes=625, seed=0, raw=False):
+    def __init__(self, n_pairs, seq_len, num_classes=625, seed=0, raw=False, augment=False):
         self.n, self.t, self.k, self.seed = 2 * n_pairs, seq_len, num_classes, seed
-        self.raw = raw          # uint8 pixels (normalised on the device) instead of float32
+        self.raw = raw or augment   # uint8 pixels (normalised on the device) instead of float32
+        self.augment = augment      # also yield the flip / erase decisions: the device applies them
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
         clip = synth_clips(1, self.t, seed=self.seed * 100003 + i, raw=self.raw)[0]
-        return clip, (i // 2 * 7919 + self.seed) % self.k, i % 2
+        item = (clip, (i // 2 * 7919 + self.seed) % self.k, i % 2)
+        if self.augment:
+            from .augment import draw_clip_params
+            item += (torch.tensor(draw_clip_params(self.t, clip.shape[-2], clip.shape[-1]), dtype=torch.int32),)
+        return item
 
 
 def get_data(dataset_name, split_id, data_dir, batch_size, seq_len, seq_srd, workers, only_eval=False):

@@ -116,8 +116,14 @@ class SEQTrainer(BaseTrainer):
         return [p for m in mods for p in m.parameters()]
 
     def _parse_data(self, inputs):
-        imgs, pids, _ = inputs
-        return [imgs.to(self.device)], pids.to(self.device)
+        """(imgs, pids, camids) as upstream (trainer.py:99-105); a 4th element -- the augmentation
+        parameter block of grl_amd.reid.data.augment for raw uint8 clips -- makes flip / erase /
+        ToTensor / Normalize run on the device instead of in the loader's PIL transforms."""
+        imgs, pids = inputs[0].to(self.device), inputs[1]
+        if len(inputs) > 3:
+            from grl_amd import engine
+            imgs = engine.augment_normalize_u8(imgs, inputs[3])
+        return [imgs], pids.to(self.device)
 
     @staticmethod
     def _pair_prob(encode_scores):

@@ -127,6 +127,14 @@ int grl_stem_conv7x7_u8(const uint8_t* x, const float* mean_std, const float* w,
 /* the normalisation alone (train mode keeps a float clip for the stem's weight gradient):
  * y[n][3][plane] = (x/255 - mean[c]) / std[c] */
 int grl_normalize_u8(const uint8_t* x, const float* mean_std, float* y, int n, int64_t plane, void* stream);
+/* Training input pipeline on the device (replaces the per-frame PIL transforms of
+ * reid/data/seqtransforms.py:92-190 as composed in reid/data/dataloader.py:51-57): RandomHorizontalFlip
+ * (per clip) + RandomSizedEarser (per frame: a constant-colour w x h patch pasted at (left, top) of the
+ * flipped frame) + ToTensor + Normalize, raw uint8 clips [n_clips][T][3][H][W] -> float32.
+ * params: int32 [n_clips][1 + 8*T] = {flip, T x {erase, left, top, w, h, R, G, B}}, the reference's
+ * random draws made on the host (grl_amd/reid/data/augment.py).  W % 4 == 0. */
+int grl_augment_normalize_u8(const uint8_t* x, const int32_t* params, const float* mean_std, float* y,
+                             int n_clips, int T, int H, int W, void* stream);
 /* the stem's LDS weight image (K padded 147 -> 160, rows padded to 164 floats), made once per
  * weight version so that every workgroup copies it with 16-byte loads */
 int grl_stem_pack_weight(const float* w, float* wp /* 64*164 floats */, void* stream);

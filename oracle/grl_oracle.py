@@ -343,3 +343,28 @@ def pair_loss(score, tar_probe, tar_gallery):
     pred = (s.detach() > 0.5).float()      # argmax over (1-s, s); ties -> class 0
     prec = (pred == labels).float().mean()
     return loss, prec
+
+
+# ----------------------------------------------------------------------------
+# training input transforms (flip / erase / ToTensor / Normalize)
+# ----------------------------------------------------------------------------
+def augment_apply(u8, params, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """numpy restatement of RandomHorizontalFlip + RandomSizedEarser + ToTensor + Normalize
+    (seqtransforms.py:92-216) for GIVEN random decisions: u8 [n,T,3,H,W] uint8, params [n, 1+8T]
+    int (flip, then per frame erase, left, top, w, h, R, G, B -- the patch is pasted at (left, top)
+    of the flipped frame and clipped by it, as PIL's paste does)."""
+    u8 = np.asarray(u8)
+    n, T, _, H, W = u8.shape
+    out = np.empty(u8.shape, np.float32)
+    for i in range(n):
+        p = [int(v) for v in params[i]]
+        for t in range(T):
+            fr = u8[i, t, :, :, ::-1].copy() if p[0] else u8[i, t].copy()
+            e, x0, y0, w, h, r, g, b = p[1 + 8 * t:9 + 8 * t]
+            if e:
+                for c, col in enumerate((r, g, b)):
+                    fr[c, y0:min(y0 + h, H), x0:min(x0 + w, W)] = col
+            f = fr.astype(np.float32) / np.float32(255)
+            for c in range(3):
+                out[i, t, c] = (f[c] - np.float32(mean[c])) / np.float32(std[c])
+    return out

@@ -308,6 +308,61 @@ def train_golden_conditioned(ref_models, path, B=8, T=4):
               errs[len(errs) // 2], errs[int(0.9 * len(errs))], errs[-1], os.path.getsize(path)))
 
 
+def augment_golden(path):
+    """(H) the training input transforms as the reference composes them (dataloader.py:51-57:
+    RectScale(256,128) -> RandomHorizontalFlip -> RandomSizedEarser -> ToTensor -> Normalize,
+    seqtransforms.py:30-216) on synthetic PIL frames, `random` seeded; plus the frame indices of
+    VideoDataset's three sampling modes (video_loader.py:30-141).  Frames are 64 x 32 here to keep
+    the fixture small (RectScale(64, 32) is then the identity, as RectScale(256,128) is on MARS's
+    own 256 x 128 crops); the transforms are size-agnostic."""
+    import random
+    from PIL import Image
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, REF)
+    from reid.data import seqtransforms as ST
+    from grl_amd.synthetic import synth_clips
+    H, W, T, N = 64, 32, 2, 8
+    u8 = synth_clips(N, T, seed=21, h=H, w=W, raw=True).numpy()                 # [N,T,3,H,W]
+    tf = ST.Compose([ST.RectScale(H, W), ST.RandomHorizontalFlip(), ST.RandomSizedEarser(), ST.ToTensor(),
+                     ST.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+    random.seed(20251003)
+    outs = []
+    for n in range(N):
+        frames = [Image.fromarray(np.ascontiguousarray(u8[n, t].transpose(1, 2, 0)), 'RGB') for t in range(T)]
+        outs.append(torch.stack(tf([frames])[0], 0).numpy())
+    out = {'seed': np.array(20251003), 'shape': np.array([N, T, H, W]), 'clips_seed': np.array(21),
+           'out': np.stack(outs).astype(np.float32)}
+    # frame sampling: VideoDataset.__get_single_item__ on fake tracklets (paths = indices), no images
+    from reid.data import video_loader as VL
+    np.random.seed(7)
+    samp = {}
+    for num in (1, 3, 8, 9, 26, 27, 40):
+        for S in (4, 8):
+            for mode in ('rrs_train', 'rrs_test', 'dense'):
+                ds = VL.VideoDataset.__new__(VL.VideoDataset)
+                ds.dataset, ds.seq_len, ds.sample, ds.transform = [(tuple(range(num)), 0, 0)], S, mode, None
+                opened = []
+
+                class FakeImage(object):
+                    @staticmethod
+                    def open(p):
+                        opened.append(int(p))
+
+                        class Im(object):
+                            def convert(self, m):
+                                return torch.zeros(1)
+                        return Im()
+                VL.Image = FakeImage
+                try:
+                    ds.__get_single_item__(0)
+                except Exception:
+                    pass                                   # torch.stack on the fake frames may complain; indices are recorded
+                samp['idx.%d.%d.%s' % (num, S, mode)] = np.array(opened, np.int32)
+    out.update(samp)
+    np.savez_compressed(path, **out)
+    print('augment golden: flips/erases exercised, %d sampling cases, %d bytes' % (len(samp), os.path.getsize(path)))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -453,6 +508,7 @@ def main():
     train_golden_conditioned(ref_models, os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
     oim_golden(ref_models, os.path.join(HERE, 'oim.npz'))
     cmc_golden(attev, evaf, os.path.join(HERE, 'cmc_q40_g400.npz'))
+    augment_golden(os.path.join(HERE, 'augment.npz'))
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
@@ -477,6 +533,9 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'cond':
         torch.manual_seed(0); torch.set_num_threads(8)
         train_golden_conditioned(import_reference()[0], os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'augment':
+        import_reference()
+        augment_golden(os.path.join(HERE, 'augment.npz'))
     elif len(sys.argv) > 1 and sys.argv[1] == 'cmc':
         r = import_reference()
         cmc_golden(r[1], r[2], os.path.join(HERE, 'cmc_q40_g400.npz'))

@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from grl_amd.synthetic import synth_clips
+
 pytestmark = pytest.mark.gpu
 
 
@@ -498,3 +500,52 @@ def test_gemm_and_conv_fuzz_bit_exact(dev):
         engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), y, n * Ho * Wo, cout, kh * kw * cin,
                     conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad))
         assert np.array_equal(y.cpu().numpy(), ref), (cin, cout, kh, kw, stride, pad, H, W, n)
+
+
+def test_device_augmentation_matches_reference_transforms(dev, golden):
+    """grl_augment_normalize_u8 (flip + erase + ToTensor + Normalize in one pass over raw uint8
+    clips) against the output of the reference's own PIL pipeline (tests/golden/augment.npz,
+    seqtransforms.py:92-216 as composed in dataloader.py:51-57), bit for bit; then at the real
+    256 x 128 size against the oracle restatement with every branch forced."""
+    import random
+    from grl_amd import engine
+    from grl_amd.reid.data.augment import draw_clip_params, pack_params
+    from oracle import grl_oracle as O
+    g = golden('augment.npz')
+    N, T, H, W = [int(v) for v in g['shape']]
+    u8 = synth_clips(N, T, seed=int(g['clips_seed']), h=H, w=W, raw=True)
+    random.seed(int(g['seed']))
+    params = pack_params([draw_clip_params(T, H, W) for _ in range(N)])
+    out = engine.augment_normalize_u8(u8.to(dev), params)
+    assert np.array_equal(out.cpu().numpy(), g['out'])
+    # full-size frames, T = 4: patches clipped by the right / bottom border, flips, untouched frames
+    B, T = 6, 4
+    u8 = synth_clips(B, T, seed=3, raw=True)
+    rnd = random.Random(11)
+    plist = [draw_clip_params(T, 256, 128, rnd) for _ in range(B)]
+    plist[0][0] = 1; plist[0][1:9] = [1, 100, 200, 100, 200, 7, 8, 9]        # clipped on both borders
+    plist[1] = [0] * (1 + 8 * T)                                             # nothing happens
+    params = pack_params(plist)
+    out = engine.augment_normalize_u8(u8.to(dev), params.to(dev))
+    assert np.array_equal(out.cpu().numpy(), O.augment_apply(u8.numpy(), params.numpy()))
+    assert torch.equal(out[1], engine.normalize_u8(u8[1:2].to(dev))[0])      # = plain ToTensor + Normalize
+    with pytest.raises(ValueError):
+        engine.augment_normalize_u8(u8.to(dev), params[:, :-1])
+
+
+def test_trainer_consumes_raw_clips_with_device_augmentation(dev):
+    """A loader that yields (uint8 clips, pids, camids, augmentation block): the trainer's
+    _parse_data hands the model the flipped / erased / normalised float clips."""
+    from torch.utils.data import DataLoader
+    from grl_amd import engine
+    from grl_amd.reid.data import SyntheticPairs
+    from grl_amd.reid.train.trainer import SEQTrainer
+    from oracle import grl_oracle as O
+    loader = DataLoader(SyntheticPairs(2, 2, seed=4, augment=True), batch_size=4)
+    batch = next(iter(engine.DevicePrefetcher(loader, dev)))
+    assert len(batch) == 4 and batch[0].dtype == torch.uint8 and batch[3].shape == (4, 1 + 8 * 2)
+    tr = SEQTrainer.__new__(SEQTrainer)
+    tr.device = dev
+    (imgs,), pids = tr._parse_data(batch)
+    assert imgs.dtype == torch.float32 and pids.is_cuda
+    assert np.array_equal(imgs.cpu().numpy(), O.augment_apply(batch[0].cpu().numpy(), batch[3].cpu().numpy()))

@@ -197,3 +197,34 @@ def test_train_conditioned_fixture_pins_oracle(golden):
     ((xu * r1).sum() + (xc * r2).sum()).backward()
     TC.check(g, xu, xc, {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None},
              {k: v.detach() for k, v in sd.items()}, out_tol=1e-5, grad_tol=1e-3, label='oracle')
+
+
+def test_augmentation_params_and_oracle_match_reference_transforms(golden):
+    """grl_amd.reid.data.augment.draw_clip_params consumes `random` exactly as the reference's
+    RandomHorizontalFlip + RandomSizedEarser do, and oracle.augment_apply reproduces the reference's
+    Compose output bit for bit from those decisions (tests/golden/augment.npz, generated by running
+    the reference's seqtransforms on PIL frames)."""
+    import random
+    from grl_amd.reid.data.augment import draw_clip_params, pack_params
+    g = golden('augment.npz')
+    N, T, H, W = [int(v) for v in g['shape']]
+    u8 = synth_clips(N, T, seed=int(g['clips_seed']), h=H, w=W, raw=True).numpy()
+    random.seed(int(g['seed']))
+    params = [draw_clip_params(T, H, W) for _ in range(N)]
+    flips = sum(p[0] for p in params); erases = sum(p[1 + 8 * t] for p in params for t in range(T))
+    assert 0 < flips < N and 0 < erases < N * T                    # the fixture exercises both branches
+    out = O.augment_apply(u8, pack_params(params).numpy())
+    assert np.array_equal(out, g['out'])
+
+
+def test_frame_sampling_matches_reference(golden):
+    """sample_frame_indices against VideoDataset.__get_single_item__'s index lists
+    (video_loader.py:30-141) for tracklets shorter / longer than the clip, all three modes."""
+    from grl_amd.reid.data.augment import sample_frame_indices
+    g = golden('augment.npz')
+    np.random.seed(7)
+    for num in (1, 3, 8, 9, 26, 27, 40):
+        for S in (4, 8):
+            for mode in ('rrs_train', 'rrs_test', 'dense'):
+                got = np.asarray(sample_frame_indices(num, S, mode)).reshape(-1)
+                assert np.array_equal(got, g['idx.%d.%d.%s' % (num, S, mode)]), (num, S, mode)

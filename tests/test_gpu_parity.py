@@ -755,3 +755,42 @@ def test_eval_plan_follows_running_stats_changed_by_train_forward():
     assert torch.equal(after, fresh)
     assert not torch.equal(after, before)
     assert torch.equal(graphed(clips), fresh)            # the captured graphs were dropped too
+
+
+def test_train_step_full_size_32x4_properties():
+    """BASELINE configs[1] at full size (B x T = 32 x 4) in train mode, through size-independent
+    properties: finite outputs and gradients for every parameter that gets one; unit-norm output
+    rows; BatchNorm bookkeeping (num_batches_tracked advances by 1 in the trunk / GCE / tail and by T
+    in the TRL memo blocks, grl_model.py:153,167); the backward is linear in the upstream gradient
+    (2g -> exactly 2x); and a clip's train-mode OUTPUT does not depend on its position in the batch
+    (BatchNorm statistics are permutation invariant up to summation order: 1e-5)."""
+    B, T = 32, 4
+    cnn = _fresh_cnn_conditioned()
+    cnn.train()
+    from grl_amd.synthetic import synth_clips_structured
+    clips = synth_clips_structured(B, T, seed=8).cuda()
+    rg = torch.Generator().manual_seed(2)
+    r1, r2 = torch.randn(B, 2048, generator=rg).cuda(), torch.randn(B, T, 2048, generator=rg).cuda()
+    grads = []
+    for scale in (1.0, 2.0):
+        cnn.zero_grad(set_to_none=True)
+        xu, xc = cnn(clips)
+        (((xu * r1).sum() + (xc * r2).sum()) * scale).backward()
+        grads.append({k: p.grad.clone() for k, p in cnn.named_parameters() if p.grad is not None})
+    assert bool(torch.isfinite(xu).all()) and bool(torch.isfinite(xc).all())
+    assert float((xu.norm(dim=1) - 1).abs().max()) < 1e-5 and float((xc.norm(dim=2) - 1).abs().max()) < 1e-5
+    assert len(grads[0]) >= 190
+    for k in grads[0]:
+        assert bool(torch.isfinite(grads[0][k]).all()), k
+        # exact doubling, except where a value sits in the fp32 DENORMAL range (a saturated channel
+        # attention gives d*g*a*(1-a) ~ 1e-40: a denormal has fewer significand bits than its double)
+        assert float((grads[1][k] - grads[0][k] * 2).abs().max()) <= 1e-36, k
+    sd = cnn.state_dict()
+    assert int(sd['backbone.base.1.num_batches_tracked']) == 2 and int(sd['corr_bn.num_batches_tracked']) == 2
+    assert int(sd['backbone.corr_atte.6.num_batches_tracked']) == 2
+    assert int(sd['temporal_learning_block.uncorr_memo_forward.bn1.num_batches_tracked']) == 2 * T
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        xu_p, xc_p = cnn(clips[perm])
+    assert float((xu_p - xu.detach()[perm]).abs().max()) < 1e-5
+    assert float((xc_p - xc.detach()[perm]).abs().max()) < 1e-5

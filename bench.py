@@ -124,6 +124,11 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
     params = trainer._all_params()
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
     cnn.train(); siam.train(); siamv.train()
+    from grl_amd import train_engine
+    if args.math in ('bf16x3', 'bf16'):              # opt-in training datapaths (fp32 is the parity mode)
+        train_engine.set_math(args.math)
+    elif args.math != 'f32':
+        raise SystemExit('--mode train supports --math f32 | bf16x3 | bf16')
     clips = synth_clips(B, T, seed=rank).to(dev)
     pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
     sync = grl_dist.GradSync(params) if world > 1 else None      # bucketed all-reduce under the backward
@@ -158,10 +163,13 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
         print(json.dumps({
             "metric": "train clips/sec", "value": round(value, 2), "unit": "clips/sec", "n_gpus": n,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = 32 x 4 per GPU",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
+                      "bf16": "bf16 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad"}[args.math],
+            "data": "synthetic",
+            "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = %d x %d per GPU" % (B, T),
                        "clips_per_gpu": B, "seq_len": T, "math": args.math,
-                       "parallelism": "dp%d (one RCCL all-reduce of the flat grad bucket per step)" % n},
+                       "parallelism": "dp%d (4 gradient buckets all-reduced over RCCL under the backward)" % n},
             "end_to_end_tflops": round(value / n * 173.8 / 1e3, 2)}))
     if dist is not None:
         dist.barrier()

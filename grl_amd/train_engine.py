@@ -21,12 +21,32 @@ from ._lib import MATH_F32
 from .engine import _call, _new, EvalPlan, PIX
 
 
+# Multiplier datapath of the TRAINING forward and data-gradient GEMMs (operands stay fp32 in HBM,
+# accumulation is fp32; the weight-gradient GEMMs, BatchNorm and the loss block are always fp32):
+#   'f32'    exact fp32 MFMA with K-blocked accumulation -- the default and the mode every train
+#            parity claim is made in (the eval-side engine.set_math / GRL_MATH never leaks in here);
+#   'bf16x3' split-bf16 products (hi*hi + hi*lo + lo*hi): fp32-class gradients at ~3x the GEMM rate;
+#   'bf16'   operands rounded to bf16 while staging (BASELINE configs[2]'s "bf16 MFMA" datapath for
+#            training): gradients to ~1e-2, forward + data-gradient GEMMs ~5x faster.
+_TRAIN_MATH = {'f32': MATH_F32, 'bf16x3': engine.MATH_BF16X3, 'bf16': engine.MATH_BF16}
+_train_math = [_TRAIN_MATH[__import__('os').environ.get('GRL_TRAIN_MATH', 'f32')]]
+
+
+def set_math(name):
+    """Select the training GEMM datapath ('f32' | 'bf16x3' | 'bf16'); returns the previous name."""
+    old = get_math()
+    _train_math[0] = _TRAIN_MATH[name]
+    return old
+
+
+def get_math():
+    return {v: k for k, v in _TRAIN_MATH.items()}[_train_math[0]]
+
+
 def gemm(*args, **kw):
-    """engine.gemm pinned to the exact fp32 datapath: the process-wide multiplier mode
-    (engine.set_math / GRL_MATH, an eval-only switch) must not leak into the training forward and
-    data-gradient GEMMs -- every train parity claim is made in fp32."""
-    kw.setdefault('math', MATH_F32)
-    kw.setdefault('kblock', True)        # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock)
+    kw.setdefault('math', _train_math[0])
+    if kw['math'] == MATH_F32:
+        kw.setdefault('kblock', True)    # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock)
     return engine.gemm(*args, **kw)
 
 FRAME_C = 2048

@@ -106,6 +106,8 @@ _SIGNATURES = {
     'grl_rerank_expand': ([_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp], C.c_int),
     'grl_rerank_jaccard': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp], C.c_int),
     'grl_row_argsort': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_row_argsort_workspace_bytes': ([C.c_int, C.c_int], _i64),
+    'grl_row_argsort_wide': ([_fp, _i64, C.c_int, C.c_int, _fp, _fp, _fp], C.c_int),
     'grl_cast_bf16': ([_fp, _fp, _i64, _fp], C.c_int),
     'grl_stem_conv7x7_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_maxpool3x3s2_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),

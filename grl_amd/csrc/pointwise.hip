@@ -598,6 +598,73 @@ __global__ __launch_bounds__(1024) void row_argsort_kernel(const float* __restri
     for (int i = tid; i < n; i += 1024) out[(int64_t)row * n + i] = idx[i];
 }
 
+// ---- rows wider than one LDS network (n > 16384): the same bitonic network, cut at the LDS size.
+// Keys / indices of the padded row (P = 2^ceil(log2 n) entries) live in a caller workspace; chunks of
+// CH = 16384 entries are sorted in LDS (`k_lo`..`k_hi` stages; the direction bit of stage k comes from
+// the GLOBAL position, so neighbouring chunks come out ascending / descending as the network needs),
+// compare-exchange steps at distance j >= CH run as plain global passes.  Same total order as the
+// one-workgroup kernel: (key, index), ties to the smaller index = numpy's stable argsort.
+constexpr int SORT_CH = 16384;
+
+// stages k = k_lo .. k_hi (each with j = min(k/2, CH/2) .. 1) of the network inside every chunk
+__global__ __launch_bounds__(1024) void sort_chunk_kernel(const float* __restrict__ d, int64_t ld, int n, int P,
+                                                          unsigned* __restrict__ gkey, int* __restrict__ gidx,
+                                                          int k_lo, int k_hi, int load_from_d,
+                                                          int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm_sort[];
+    unsigned* key = sm_sort;
+    int* idx = reinterpret_cast<int*>(sm_sort + SORT_CH);
+    const int row = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int g0 = chunk * SORT_CH;
+    unsigned* rk = gkey + (int64_t)row * P + g0;
+    int* ri = gidx + (int64_t)row * P + g0;
+    if (load_from_d) {
+        const float* dr = d + (int64_t)row * ld;
+        for (int i = tid; i < SORT_CH; i += 1024) {
+            const int gi = g0 + i;
+            key[i] = gi < n ? sort_key(dr[gi]) : 0xffffffffu;
+            idx[i] = gi < n ? gi : 0x7fffffff;
+        }
+    } else {
+        for (int i = tid; i < SORT_CH; i += 1024) { key[i] = rk[i]; idx[i] = ri[i]; }
+    }
+    __syncthreads();
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+        for (int j = min(k >> 1, SORT_CH >> 1); j > 0; j >>= 1) {
+            for (int t = tid; t < (SORT_CH >> 1); t += 1024) {
+                const int i = 2 * j * (t / j) + (t % j), l = i + j;
+                const bool asc = ((g0 + i) & k) == 0;
+                const unsigned ki = key[i], kl = key[l];
+                const int ii = idx[i], il = idx[l];
+                const bool gt = ki > kl || (ki == kl && ii > il);
+                if (gt == asc) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+    if (out) {                                             // last pass: the row is sorted
+        for (int i = tid; i < SORT_CH; i += 1024)
+            if (g0 + i < n) out[(int64_t)row * n + g0 + i] = idx[i];
+    } else {
+        for (int i = tid; i < SORT_CH; i += 1024) { rk[i] = key[i]; ri[i] = idx[i]; }
+    }
+}
+
+// one compare-exchange step of stage k at distance j >= CH, in global memory
+__global__ void sort_global_step_kernel(unsigned* __restrict__ gkey, int* __restrict__ gidx, int P, int k, int j) {
+    const int row = blockIdx.y;
+    unsigned* rk = gkey + (int64_t)row * P;
+    int* ri = gidx + (int64_t)row * P;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (P >> 1); t += gridDim.x * blockDim.x) {
+        const int i = 2 * j * (t / j) + (t % j), l = i + j;
+        const bool asc = (i & k) == 0;
+        const unsigned ki = rk[i], kl = rk[l];
+        const int ii = ri[i], il = ri[l];
+        const bool gt = ki > kl || (ki == kl && ii > il);
+        if (gt == asc) { rk[i] = kl; rk[l] = ki; ri[i] = il; ri[l] = ii; }
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -840,9 +907,45 @@ extern "C" int grl_pair_verify(const float* p, const float* g, const float* scal
     return grl_check_launch("grl_pair_verify");
 }
 
+extern "C" int64_t grl_row_argsort_workspace_bytes(int rows, int n) {
+    if (rows <= 0 || n <= SORT_MAX) return 0;
+    int64_t P = 2;
+    while (P < n) P <<= 1;
+    return (int64_t)rows * P * 8;
+}
+
+extern "C" int grl_row_argsort_wide(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* workspace,
+                                    void* stream) {
+    GRL_REQUIRE(d && idx && workspace && rows > 0 && n > SORT_MAX && ld >= n, "row_argsort_wide: bad args");
+    GRL_REQUIRE(n <= (1 << 24) && rows <= 65535, "row_argsort_wide: at most 2^24 columns, 65535 rows per call");
+    int P = 2;
+    while (P < n) P <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* gkey = reinterpret_cast<unsigned*>(workspace);
+    int* gidx = reinterpret_cast<int*>(gkey + (int64_t)rows * P);
+    const size_t lds = (size_t)SORT_CH * 8;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)sort_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_CH * 8);
+        return true;
+    }();
+    (void)attr;
+    const dim3 cgrid(P / SORT_CH, rows);
+    // stages 2 .. CH entirely inside the chunks
+    hipLaunchKernelGGL(sort_chunk_kernel, cgrid, dim3(1024), lds, s, d, ld, n, P, gkey, gidx, 2, SORT_CH, 1,
+                       (int*)nullptr);
+    for (int k = 2 * SORT_CH; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= SORT_CH; j >>= 1)
+            hipLaunchKernelGGL(sort_global_step_kernel, dim3(grid_for(P / 2), rows), dim3(256), 0, s, gkey, gidx, P, k, j);
+        // the remaining steps of stage k (j = CH/2 .. 1) stay inside a chunk
+        hipLaunchKernelGGL(sort_chunk_kernel, cgrid, dim3(1024), lds, s, d, ld, n, P, gkey, gidx, k, k, 0,
+                           k == P ? idx : (int*)nullptr);
+    }
+    return grl_check_launch("grl_row_argsort_wide");
+}
+
 extern "C" int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* stream) {
     GRL_REQUIRE(d && idx && rows > 0 && n > 0 && ld >= n, "row_argsort: bad args");
-    GRL_REQUIRE(n <= SORT_MAX, "row_argsort: at most 16384 columns (one LDS bitonic network per row)");
+    GRL_REQUIRE(n <= SORT_MAX, "row_argsort: at most 16384 columns per LDS network (wider rows: grl_row_argsort_wide)");
     int P = 2;
     while (P < n) P <<= 1;
     const size_t lds = (size_t)P * 8;

@@ -779,13 +779,23 @@ def pairwise_distance_tensor(x, y):
 
 def rank_rows(distmat):
     """Row-wise ascending argsort on the GPU (int32 [rows][n]); ties to the smaller index.
-    Replaces the host `np.argsort(distmat, axis=1)` of eva_functions.py:139 for matrices of up
-    to 16384 columns (MARS: 11310)."""
+    Replaces the host `np.argsort(distmat, axis=1)` of eva_functions.py:139: one LDS bitonic
+    network per row up to 16384 columns (MARS: 11310), the chunked network beyond (galleries of
+    up to 2^24 entries; rows are processed in slabs so the workspace stays below ~1 GB)."""
     require_device(distmat, 'distmat')
     distmat = distmat.contiguous()
     rows, n = distmat.shape
     idx = torch.empty((rows, n), dtype=torch.int32, device=distmat.device)
-    _call('grl_row_argsort', ptr(distmat), n, rows, n, ptr(idx))
+    if n <= 16384:
+        _call('grl_row_argsort', ptr(distmat), n, rows, n, ptr(idx))
+        return idx
+    lib = _lib.load()
+    per_row = lib.grl_row_argsort_workspace_bytes(1, n)
+    slab = max(1, min(rows, 65535, (1 << 30) // per_row))
+    ws = torch.empty(lib.grl_row_argsort_workspace_bytes(slab, n), dtype=torch.uint8, device=distmat.device)
+    for r0 in range(0, rows, slab):
+        r = min(slab, rows - r0)
+        _call('grl_row_argsort_wide', ptr(distmat[r0:]), n, r, n, ptr(idx[r0:]), ptr(ws))
     return idx
 
 

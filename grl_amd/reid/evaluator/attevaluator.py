@@ -89,9 +89,10 @@ class ATTEvaluator(object):
         print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
         print("Computing distance matrix")
         dist_dev = grl_dist.sharded_distmat(qf, gf, cosin_dist)     # gallery rows sharded over the ranks
-        # ranking AND the per-query CMC / AP work on the device when the gallery fits one LDS sort
-        # network (MARS: 11310 columns): neither the distance nor the index matrix leaves HBM
-        if not rerank and dist_dev.shape[1] <= 16384:
+        # ranking AND the per-query CMC / AP work on the device (one LDS sort network per row up to
+        # 16384 gallery entries -- MARS: 11310 -- the chunked network beyond): neither the distance nor
+        # the index matrix leaves HBM
+        if not rerank:
             return evaluate_seq(None, q_pids, q_camids, g_pids, g_camids, path,
                                 indices=engine.rank_rows(dist_dev))
         if rerank and qf.size(0) + gf.size(0) <= 16384:

@@ -194,6 +194,13 @@ int grl_pair_verify(const float* p, const float* g, const float* scale, const fl
  * indices out [rows][n]; ties go to the smaller index.  Replaces np.argsort(distmat, axis=1)
  * in reid/evaluator/eva_functions.py:139.  n <= 16384. */
 int grl_row_argsort(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* stream);
+/* the same ranking for rows wider than one LDS network (16384 < n <= 2^24): the bitonic network cut at
+ * the LDS size -- 16384-entry chunks sorted in LDS, the long-distance steps as global passes over
+ * (key, index) pairs kept in `workspace` (grl_row_argsort_workspace_bytes(rows, n) bytes).  Same total
+ * order (distance, then index) = np.argsort(kind='stable') of eva_functions.py:139. */
+int64_t grl_row_argsort_workspace_bytes(int rows, int n);
+int grl_row_argsort_wide(const float* d, int64_t ld, int rows, int n, int32_t* idx, void* workspace,
+                         void* stream);
 
 /* |x_row|^2 for the Euclidean epilogue (attevaluator.py:37-38). */
 int grl_row_sqnorm(const float* x, float* out, int rows, int K, int ld, void* stream);

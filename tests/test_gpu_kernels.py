@@ -284,9 +284,29 @@ def test_row_argsort_matches_numpy(dev):
         d[:, ::5] = np.round(d[:, ::5], 1)                  # plenty of exact ties
         got = engine.rank_rows(torch.from_numpy(d).to(dev)).cpu().numpy()
         assert np.array_equal(got, np.argsort(d, axis=1, kind='stable')), (rows, n)
-    from grl_amd._lib import GrlHipError
-    with pytest.raises(GrlHipError):
-        engine.rank_rows(torch.zeros(2, 16385, device=dev))
+    # beyond one LDS network (galleries > 16384): the chunked bitonic network, same stable order;
+    # widths just past a chunk, a non-power-of-two, three chunk levels, NaN / +-0 / inf rows
+    for rows, n in ((3, 16385), (4, 20000), (2, 32768), (2, 70001)):
+        d = rng.standard_normal((rows, n)).astype(np.float32)
+        d[:, ::7] = np.round(d[:, ::7], 1)
+        d[0, :5] = [np.inf, -np.inf, 0.0, -0.0, np.inf]
+        got = engine.rank_rows(torch.from_numpy(d).to(dev)).cpu().numpy()
+        assert np.array_equal(got, np.argsort(d, axis=1, kind='stable')), (rows, n)
+
+
+def test_evaluator_ranks_a_gallery_wider_than_one_lds_network(dev):
+    """17000-entry gallery through ATTEvaluator's device path (rank_rows + rank_metrics): same CMC /
+    mAP as the host evaluate() over numpy's stable argsort of the same distance matrix."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    from grl_amd.synthetic import synth_eval_features
+    qf, gf, qp, qc, gp, gc = synth_eval_features(24, 17000, seed=3, n_ids=200, noise=4.0)
+    dist = engine.cosin_dist(qf.to(dev), gf.to(dev))
+    idx = engine.rank_rows(dist)
+    cmc_d, map_d = engine.rank_metrics(idx, qp, gp, qc, gc)
+    cmc_h, map_h = evaluate(dist.cpu().numpy(), qp, gp, qc, gc)
+    assert np.array_equal(idx.cpu().numpy(), np.argsort(dist.cpu().numpy(), axis=1, kind='stable'))
+    assert np.allclose(cmc_d, cmc_h, atol=1e-7) and abs(map_d - map_h) < 1e-9
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,H,W,n', [(64, 64, 3, 1, 16, 8, 2), (128, 96, 3, 2, 16, 16, 1),

@@ -94,6 +94,7 @@ _SIGNATURES = {
     'grl_softmax2': ([_fp, _fp, _fp, _i64, _fp], C.c_int),
     'grl_softmax2_bwd': ([_fp, _fp, _fp, _fp, _i64, _fp], C.c_int),
     'grl_normalize_u8': ([_fp, _fp, _fp, C.c_int, _i64, _fp], C.c_int),
+    'grl_resize_bilinear_u8': ([_fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_augment_normalize_u8': ([_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_conv7x7_u8': ([_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_stem_conv7x7_u8_bf16': ([_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],

@@ -717,9 +717,51 @@ __global__ void augment_normalize_u8_kernel(const uint8_t* __restrict__ x, const
         reinterpret_cast<f32x4*>(y)[i] = o;
     }
 }
+
+// RectScale (seqtransforms.py:30-47) = PIL's `resize(size, BILINEAR)` on 8-bit frames, bit for bit:
+// Pillow resamples horizontally, rounds to uint8, then vertically, with 22-bit fixed-point taps
+// (libImaging/Resample.c).  The host builds the per-axis tap tables with Pillow's own arithmetic
+// (grl_amd/reid/data/augment.py:pil_bilinear_coeffs); one thread per output pixel recomputes the
+// (at most kv) horizontally resampled, rounded pixels its vertical taps need.
+__global__ void resize_bilinear_u8_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y,
+                                          const int* __restrict__ bh, const int* __restrict__ ch, int kh,
+                                          const int* __restrict__ bv, const int* __restrict__ cv, int kv,
+                                          int Hin, int Win, int Hout, int Wout, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wout);
+        const int yo = (int)((i / Wout) % Hout);
+        const int64_t plane = i / ((int64_t)Wout * Hout);
+        const uint8_t* src = x + plane * (int64_t)Hin * Win;
+        const int x0 = bh[2 * xo], nx = bh[2 * xo + 1], y0 = bv[2 * yo], ny = bv[2 * yo + 1];
+        int acc_v = 1 << 21;
+        for (int r = 0; r < ny; ++r) {
+            const uint8_t* row = src + (int64_t)(y0 + r) * Win + x0;
+            int acc = 1 << 21;
+            for (int t = 0; t < nx; ++t) acc += (int)row[t] * ch[xo * kh + t];
+            int h8 = acc >> 22;
+            h8 = h8 < 0 ? 0 : (h8 > 255 ? 255 : h8);
+            acc_v += h8 * cv[yo * kv + r];
+        }
+        int o = acc_v >> 22;
+        y[i] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+}
 }  // namespace
 
 #define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_resize_bilinear_u8(const uint8_t* x, uint8_t* y, const int* bounds_h, const int* coefs_h, int kh,
+                                      const int* bounds_v, const int* coefs_v, int kv, int64_t planes, int Hin,
+                                      int Win, int Hout, int Wout, void* stream) {
+    GRL_REQUIRE(x && y && bounds_h && coefs_h && bounds_v && coefs_v && planes > 0, "resize_bilinear_u8: null");
+    GRL_REQUIRE(kh > 0 && kv > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "resize_bilinear_u8: bad shape");
+    const int64_t total = planes * Hout * Wout;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, y, bounds_h,
+                       coefs_h, kh, bounds_v, coefs_v, kv, Hin, Win, Hout, Wout, total);
+    return grl_check_launch("grl_resize_bilinear_u8");
+}
 
 extern "C" int grl_augment_normalize_u8(const uint8_t* x, const int* params, const float* mean_std, float* y,
                                         int n_clips, int T, int H, int W, void* stream) {

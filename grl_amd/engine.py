@@ -94,6 +94,34 @@ def normalize_u8(x):
     return y
 
 
+_resize_tables = {}
+
+
+def rect_scale_u8(x, height=256, width=128):
+    """RectScale(height, width) of the reference's loaders (seqtransforms.py:30-47, dataloader.py:53,68)
+    on the device: uint8 frames [..., 3, Hin, Win] -> [..., 3, height, width], bit-identical to PIL's
+    BILINEAR resize (frames that already have the size are returned as they are, as upstream)."""
+    require_device(x, 'frames', allow_u8=True)
+    if x.dtype != torch.uint8:
+        raise ValueError('rect_scale_u8 expects raw uint8 frames')
+    hin, win = x.shape[-2:]
+    if (hin, win) == (height, width):
+        return x
+    key = (hin, win, height, width, x.device)
+    tabs = _resize_tables.get(key)
+    if tabs is None:
+        from .reid.data.augment import pil_bilinear_coeffs
+        bh, ch = pil_bilinear_coeffs(win, width)
+        bv, cv = pil_bilinear_coeffs(hin, height)
+        tabs = _resize_tables[key] = tuple(torch.from_numpy(t).contiguous().to(x.device) for t in (bh, ch, bv, cv))
+    bh, ch, bv, cv = tabs
+    x = x.contiguous()
+    y = torch.empty(x.shape[:-2] + (height, width), dtype=torch.uint8, device=x.device)
+    _call('grl_resize_bilinear_u8', ptr(x), ptr(y), ptr(bh), ptr(ch), ch.shape[1], ptr(bv), ptr(cv), cv.shape[1],
+          x.numel() // (hin * win), hin, win, height, width)
+    return y
+
+
 def augment_normalize_u8(clips, params):
     """Training augmentation on the device: uint8 clips [B,T,3,H,W] + the host-drawn decisions
     (int32 [B, 1 + 8T], grl_amd.reid.data.augment) -> float32 clips, flipped / erased / normalised
@@ -595,6 +623,8 @@ def grl_forward(model, inputs, taps=None):
     require_device(inputs, 'inputs', allow_u8=True)
     if inputs.dim() != 5:
         raise ValueError('inputs must be [B,T,3,256,128]')
+    if inputs.dtype == torch.uint8:
+        inputs = rect_scale_u8(inputs)           # raw frames of another size: RectScale(256, 128) first
     if model.training:
         from . import train_engine
         return train_engine.grl_forward_train(model, normalize_u8(inputs))
@@ -645,6 +675,8 @@ def extract_features(cnn, siam, clips):
     if cnn.training or siam.training:
         raise RuntimeError('extract_features needs cnn.eval() and siamese.eval()')
     with torch.no_grad():
+        if clips.dtype == torch.uint8:
+            clips = rect_scale_u8(clips)
         b, t = clips.shape[:2]
         feat = _new((b, 6144), clips)
         _, x_corr = _grl_eval(cnn, clips, out_uncorr=feat, ld_uncorr=6144)

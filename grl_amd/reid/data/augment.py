@@ -84,3 +84,47 @@ def sample_frame_indices(num, seq_len, mode, np_random=np.random):
         out.append(last)
         return np.array(out)
     raise KeyError("Unknown sample method: {}".format(mode))
+
+
+# ----------------------------------------------------------------------------
+# RectScale on the device: PIL's BILINEAR resize, bit for bit
+# ----------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2          # Pillow's fixed-point coefficient scale for 8-bit images
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's resampling table for one axis (libImaging/Resample.c: precompute_coeffs +
+    normalize_coeffs_8bpc with the bilinear filter, support 1): for every output index the first
+    input index, the tap count and the taps as 22-bit fixed-point integers.  Computed in float64
+    with Pillow's own expression order, so the device kernel's integer arithmetic reproduces
+    `frame.resize(size, Image.BILINEAR)` (RectScale, seqtransforms.py:30-47) exactly.
+    Returns (bounds int32 [out, 2], coefs int32 [out, ksize])."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    coefs = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        ww = 0.0
+        for x in range(xmax):
+            v = (x + xmin - center + 0.5) * ss
+            v = -v if v < 0 else v
+            w = 1.0 - v if v < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            kv = k[x] / ww if ww != 0.0 else k[x]
+            coefs[xx, x] = int(-0.5 + kv * (1 << _PRECISION_BITS)) if kv < 0 else int(0.5 + kv * (1 << _PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coefs

@@ -122,7 +122,7 @@ class SEQTrainer(BaseTrainer):
         imgs, pids = inputs[0].to(self.device), inputs[1]
         if len(inputs) > 3:
             from grl_amd import engine
-            imgs = engine.augment_normalize_u8(imgs, inputs[3])
+            imgs = engine.augment_normalize_u8(engine.rect_scale_u8(imgs), inputs[3])   # RectScale comes first
         return [imgs], pids.to(self.device)
 
     @staticmethod

@@ -135,6 +135,13 @@ int grl_normalize_u8(const uint8_t* x, const float* mean_std, float* y, int n, i
  * random draws made on the host (grl_amd/reid/data/augment.py).  W % 4 == 0. */
 int grl_augment_normalize_u8(const uint8_t* x, const int32_t* params, const float* mean_std, float* y,
                              int n_clips, int T, int H, int W, void* stream);
+/* RectScale (reid/data/seqtransforms.py:30-47: `frame.resize((W, H), Image.BILINEAR)`) on uint8 planes
+ * [planes][Hin][Win] -> [planes][Hout][Wout], bit-identical to Pillow: horizontal pass, rounding to
+ * uint8, vertical pass, 22-bit fixed-point taps.  bounds_*: int32 [out][2] = (first input index, taps);
+ * coefs_*: int32 [out][k*]; both from grl_amd/reid/data/augment.py:pil_bilinear_coeffs. */
+int grl_resize_bilinear_u8(const uint8_t* x, uint8_t* y, const int32_t* bounds_h, const int32_t* coefs_h, int kh,
+                           const int32_t* bounds_v, const int32_t* coefs_v, int kv, int64_t planes, int Hin,
+                           int Win, int Hout, int Wout, void* stream);
 /* the stem's LDS weight image (K padded 147 -> 160, rows padded to 164 floats), made once per
  * weight version so that every workgroup copies it with 16-byte loads */
 int grl_stem_pack_weight(const float* w, float* wp /* 64*164 floats */, void* stream);

@@ -358,6 +358,14 @@ def augment_golden(path):
                 except Exception:
                     pass                                   # torch.stack on the fake frames may complain; indices are recorded
                 samp['idx.%d.%d.%s' % (num, S, mode)] = np.array(opened, np.int32)
+    # RectScale itself (seqtransforms.py:30-47) to a 64 x 32 target from six input sizes: up, down,
+    # identity, odd, one axis only
+    rs = ST.RectScale(64, 32)
+    for k, (hh, ww) in enumerate(((32, 16), (100, 50), (64, 32), (75, 29), (64, 40), (90, 32))):
+        src = np.random.Generator(np.random.PCG64(100 + k)).integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+        res = rs([[Image.fromarray(src, 'RGB')]])[0][0]
+        out['rect.%d.shape' % k] = np.array([hh, ww])
+        out['rect.%d.out' % k] = np.asarray(res).copy()
     out.update(samp)
     np.savez_compressed(path, **out)
     print('augment golden: flips/erases exercised, %d sampling cases, %d bytes' % (len(samp), os.path.getsize(path)))

@@ -569,3 +569,26 @@ def test_trainer_consumes_raw_clips_with_device_augmentation(dev):
     (imgs,), pids = tr._parse_data(batch)
     assert imgs.dtype == torch.float32 and pids.is_cuda
     assert np.array_equal(imgs.cpu().numpy(), O.augment_apply(batch[0].cpu().numpy(), batch[3].cpu().numpy()))
+
+
+def test_device_rect_scale_matches_reference_and_pil(dev, golden):
+    """grl_resize_bilinear_u8 against the reference's RectScale output (tests/golden/augment.npz:
+    six input sizes -> 64 x 32) and, at the real 256 x 128 target, against Pillow itself."""
+    from grl_amd import engine
+    g = golden('augment.npz')
+    for k in range(6):
+        hh, ww = [int(v) for v in g['rect.%d.shape' % k]]
+        src = np.random.Generator(np.random.PCG64(100 + k)).integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+        x = torch.from_numpy(np.ascontiguousarray(src.transpose(2, 0, 1))).to(dev)
+        y = engine.rect_scale_u8(x, 64, 32)
+        assert np.array_equal(y.cpu().numpy().transpose(1, 2, 0), g['rect.%d.out' % k]), (hh, ww)
+    Image = pytest.importorskip('PIL.Image')
+    rng = np.random.default_rng(9)
+    for hh, ww in ((128, 64), (300, 150), (277, 131)):
+        frames = rng.integers(0, 256, (2, 3, hh, ww), dtype=np.uint8)                 # [B*T, 3, H, W]
+        y = engine.rect_scale_u8(torch.from_numpy(frames).to(dev)).cpu().numpy()
+        for n in range(2):
+            ref = np.asarray(Image.fromarray(np.ascontiguousarray(frames[n].transpose(1, 2, 0)), 'RGB').resize((128, 256), Image.BILINEAR))
+            assert np.array_equal(y[n].transpose(1, 2, 0), ref), (hh, ww)
+    x = torch.from_numpy(rng.integers(0, 256, (1, 2, 3, 256, 128), dtype=np.uint8)).to(dev)
+    assert engine.rect_scale_u8(x) is x

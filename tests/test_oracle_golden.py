@@ -228,3 +228,21 @@ def test_frame_sampling_matches_reference(golden):
             for mode in ('rrs_train', 'rrs_test', 'dense'):
                 got = np.asarray(sample_frame_indices(num, S, mode)).reshape(-1)
                 assert np.array_equal(got, g['idx.%d.%d.%s' % (num, S, mode)]), (num, S, mode)
+
+
+def test_pil_bilinear_tables_reproduce_reference_rect_scale(golden):
+    """The host-built tap tables (pil_bilinear_coeffs) + Pillow's two integer passes, emulated in
+    numpy, give the reference's RectScale output bit for bit (tests/golden/augment.npz)."""
+    from grl_amd.reid.data.augment import pil_bilinear_coeffs
+    g = golden('augment.npz')
+
+    def one_axis(img, axis, out_size):
+        b, c = pil_bilinear_coeffs(img.shape[axis], out_size)
+        img = np.moveaxis(img, axis, 0).astype(np.int64)
+        out = np.stack([np.clip(((img[b[i, 0]:b[i, 0] + b[i, 1]] * c[i, :b[i, 1]].reshape(-1, 1, 1)).sum(0) + (1 << 21)) >> 22,
+                                0, 255) for i in range(out_size)])
+        return np.moveaxis(out.astype(np.uint8), 0, axis)
+    for k in range(6):
+        hh, ww = [int(v) for v in g['rect.%d.shape' % k]]
+        src = np.random.Generator(np.random.PCG64(100 + k)).integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+        assert np.array_equal(one_axis(one_axis(src, 1, 32), 0, 64), g['rect.%d.out' % k]), (hh, ww)

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/grl_hip.h"
 #include "common.h"
 
@@ -61,9 +62,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
     // ---- staging rows: wave w fills the 8-row blocks w, w+8, w+16, w+24 of both operands ----
     const int srow = lane >> 3, schunk = lane & 7;
     const int sw = (schunk ^ (((srow >> 1) + 4 * (wave & 1)) & 7)) << 4;   // swizzled source chunk (bytes)
-    const char* abase[4];
-    const char* bsrc[4];
-    int iy0[4], ix0[4];
+    // 32-bit byte offsets from the (wave-uniform) operand bases: half the address registers of 64-bit
+    // pointers (the dispatcher guarantees both operands are < 4 GiB); conv rows also carry their
+    // window origin (iy0 + 1, ix0 + 1), 16 bits each
+    unsigned aoff[4], boff[4], yx0[4];
     const char* const a8 = reinterpret_cast<const char*>(p.a);
     const char* const w8 = reinterpret_cast<const char*>(p.w);
     const char* const zrow = reinterpret_cast<const char*>(g_zero_row) + sw;
@@ -91,51 +93,53 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                 const int hw = p.Ho * p.Wo;
                 const int img = m / hw, rem = m - img * hw;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                abase[i] = a8 + ((int64_t)img * p.H * p.W * p.C) * 2 + sw;
-                iy0[i] = oy * p.stride - p.pad;
-                ix0[i] = ox * p.stride - p.pad;
+                aoff[i] = (unsigned)(((int64_t)img * p.H * p.W * p.C) * 2 + sw);
+                yx0[i] = ((unsigned)(oy * p.stride - p.pad + 1) << 16) | (unsigned)(ox * p.stride - p.pad + 1);
             } else {
-                abase[i] = a8 + (int64_t)m * p.lda * 2 + sw;
-                iy0[i] = ix0[i] = 0;
+                aoff[i] = (unsigned)((int64_t)m * p.lda * 2 + sw);
+                yx0[i] = 0;
             }
             int n = n0 + r;
             n = n < p.N ? n : p.N - 1;
-            bsrc[i] = w8 + (int64_t)n * p.ldw * 2 + sw;
+            boff[i] = (unsigned)((int64_t)n * p.ldw * 2 + sw);
         }
     };
 
-    // One stage = 8 LDS-DMA wave-instructions per wave (4 A blocks, 4 W blocks), issued back to back
-    // at the top of the previous stage's MFMAs.  (Measured alternatives, all slower on MI355X:
-    // pieces spread between the MFMA groups, register double-buffered fragments with the emitted
-    // order pinned by sched_group_barrier, the last k-step rotated behind the barrier: -7 %.)
-    auto stage = [&](int s, int kt) {
-        char* const As = smem + s * STAGE;
-        char* const Bs = As + TB * ROWB;
-        int tap_ky = 0, tap_kx = 0, c0 = kt * 64;
+    // One stage = 8 LDS-DMA wave-instructions per wave: `stage_piece(s, kt, i)` issues 8-row block i of A
+    // and of W (two instructions); `stage()` issues all four pieces back to back (prologue, next tile).
+    int tap_ky = 0, tap_kx = 0, tap_c0 = 0;
+    auto stage_tap = [&](int kt) {
+        tap_c0 = kt * 64;
         if (CONV) {
-            const int tap = c0 / p.C;                        // wave-uniform: a stage lies inside one tap
-            c0 -= tap * p.C;
+            const int tap = tap_c0 / p.C;                    // wave-uniform: a stage lies inside one tap
+            tap_c0 -= tap * p.C;
             tap_ky = tap / p.kw;
             tap_kx = tap - tap_ky * p.kw;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* src;
-            if (CONV) {
-                const int iy = iy0[i] + tap_ky, ix = ix0[i] + tap_kx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                src = ok ? abase[i] + ((int64_t)(iy * p.W + ix) * p.C + c0) * 2 : zrow;
-            } else {
-                src = abase[i] + (int64_t)kt * ROWB;
-            }
-            glds16(src, As + (wave + 8 * i) * 1024);
+    };
+    auto stage_piece = [&](int s, int kt, int i) {
+        char* const As = smem + s * STAGE;
+        char* const Bs = As + TB * ROWB;
+        const char* src;
+        if (CONV) {
+            const int iy = (int)(yx0[i] >> 16) - 1 + tap_ky, ix = (int)(yx0[i] & 0xffff) - 1 + tap_kx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            src = ok ? a8 + (aoff[i] + (unsigned)(((iy * p.W + ix) * p.C + tap_c0) * 2)) : zrow;
+        } else {
+            src = a8 + (aoff[i] + (unsigned)kt * ROWB);
         }
+        glds16(src, As + (wave + 8 * i) * 1024);
+        glds16(w8 + (boff[i] + (unsigned)kt * ROWB), Bs + (wave + 8 * i) * 1024);
+    };
+    auto stage = [&](int s, int kt) {
+        stage_tap(kt);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(bsrc[i] + (int64_t)kt * ROWB, Bs + (wave + 8 * i) * 1024);
+        for (int i = 0; i < 4; ++i) stage_piece(s, kt, i);
     };
 
     const int frow = lane & 31, fhalf = lane >> 5;
     const int fsw = (frow >> 1) & 7;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;       // LDS byte address of the stage buffers
     const int nk = p.K / 64;
     // epilogue slab of this wave: 32 x 64 fp32 in the SECOND stage buffer (the next tile's first
     // stage is already landing in the first one); 16-byte chunks XOR-swizzled by (row >> 1) & 1
@@ -157,26 +161,71 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         __syncthreads();          // stage 0 of this tile has landed; every wave is out of the previous epilogue
-        for (int kt = 0; kt < nk; ++kt) {
+        // One stage.  Fragments are double-buffered in registers: k-step q+1's six ds_read_b128 are
+        // issued BEFORE k-step q's eight MFMAs and waited for with a counted lgkmcnt(6), and the DMA
+        // pieces of stage kt+1 (`more`, compile time) are issued in the shadow of the LDS latency /
+        // behind queued MFMAs -- the two waves of a SIMD run in lockstep behind the stage barrier, so
+        // anything both of them do back to back leaves the matrix pipe idle.  hipcc sinks plain loads
+        // below the MFMAs again (shortest live ranges), hence inline asm reads, explicit waits and
+        // sched_barriers fencing the MFMA groups.
+        auto do_stage = [&](auto more, int kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);        // in flight under this stage's MFMAs
-            const char* const Ab = smem + cur * STAGE + (wr * 128 + frow) * ROWB;
-            const char* const Bb = smem + cur * STAGE + TB * ROWB + (wc * 64 + frow) * ROWB;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                   // four k-steps of 16
-                const int ch = ((2 * q + fhalf) ^ fsw) << 4;
-                bf16x8 af[4], bf[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROWB + ch);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROWB + ch);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
+            const unsigned a_lds = lds0 + cur * STAGE + (wr * 128 + frow) * ROWB;
+            const unsigned b_lds = lds0 + cur * STAGE + TB * ROWB + (wc * 64 + frow) * ROWB;
+            bf16x8 af[2][4], bf[2][2];
+#define GRL_RD(set, q)                                                                               \
+            do {                                                                                     \
+                const unsigned ch_ = ((2 * (q) + fhalf) ^ fsw) << 4;                                 \
+                const unsigned aa_ = a_lds + ch_, bb_ = b_lds + ch_;                                 \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[set][0]) : "v"(aa_));                   \
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[set][1]) : "v"(aa_));       \
+                asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(af[set][2]) : "v"(aa_));       \
+                asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(af[set][3]) : "v"(aa_));      \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bf[set][0]) : "v"(bb_));                   \
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[set][1]) : "v"(bb_));       \
+            } while (0)
+#define GRL_MM(set)                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bf[set][j], acc[i][j], 0, 0, 0)
+#define GRL_WAIT(n)                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");                                  \
+            __builtin_amdgcn_sched_barrier(0)
+            // dense A: the pieces ride between the groups (+7 % over all eight at the top); the conv
+            // gather's per-piece address arithmetic costs more there than it hides (-5 %): at the top
+            constexpr bool SPREAD = !CONV;
+            if (more && SPREAD) stage_tap(kt + 1);
+            GRL_RD(0, 0);
+            GRL_RD(1, 1);
+            if (more && SPREAD) { stage_piece(cur ^ 1, kt + 1, 0); stage_piece(cur ^ 1, kt + 1, 1); }
+            GRL_WAIT(6);
+            GRL_MM(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && SPREAD) stage_piece(cur ^ 1, kt + 1, 2);
+            GRL_RD(0, 2);
+            GRL_WAIT(6);
+            GRL_MM(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && SPREAD) stage_piece(cur ^ 1, kt + 1, 3);
+            GRL_RD(1, 3);
+            GRL_WAIT(6);
+            GRL_MM(0);
+            __builtin_amdgcn_sched_barrier(0);
+            GRL_WAIT(0);
+            GRL_MM(1);
+#undef GRL_RD
+#undef GRL_MM
+#undef GRL_WAIT
             __syncthreads();                                // (vmcnt(0): stage kt+1 has landed)
+        };
+        if constexpr (CONV) {
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) stage((kt & 1) ^ 1, kt + 1);      // all eight pieces, then the stage body
+                do_stage(std::false_type{}, kt);
+            }
+        } else {
+            for (int kt = 0; kt + 1 < nk; ++kt) do_stage(std::true_type{}, kt);
+            do_stage(std::false_type{}, nk - 1);
         }
 
         // the K loop ended on a barrier: both stage buffers are free.  Request the NEXT tile's first
@@ -272,6 +321,9 @@ int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     if (d.conv && d.C % 64) return 0;
     if (!al16(d.a) || !al16(d.w) || !al16(d.y) || !al16(d.res) || !al16(d.scale) || !al16(d.shift) || !al16(d.gbias))
         return 0;
+    // 32-bit operand offsets inside the kernel
+    const int64_t a_bytes = d.conv ? (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W * d.C * 2 : (int64_t)d.M * d.lda * 2;
+    if (a_bytes >= (1ll << 32) || (int64_t)d.N * d.ldw * 2 >= (1ll << 32) || (d.conv && (d.H + 2 > 65535 || d.W + 2 > 65535))) return 0;
     const int tiles_m = (d.M + TB - 1) / TB, tiles_n = (d.N + TB - 1) / TB;
     const int64_t num_tiles = (int64_t)tiles_m * tiles_n;
     // one workgroup per CU: fewer than ~3/4 of a wave of tiles leaves the chip idle and the

@@ -167,19 +167,29 @@ __global__ void bn_apply_centered_kernel(const float* __restrict__ z, const floa
 }
 
 // BN backward, pass 1: g = dy * (act > 0) ; slab[chunk][0][c] = sum g, [1][c] = sum g*xhat
+// LPR lanes cover one row's 4*LPR channels (LPR = 16 / 32 / 64 for C = 64 / 128 / >= 256), so a wave
+// reads 64 / LPR rows per instruction and every lane works on the 64- and 128-channel layers too
+// (the largest tensors of the step; one lane group per row left 48 of 64 lanes idle there).
+// Fixed summation order: per lane over its rows, then across the lane groups of the wave
+// (xor-shuffles), then the four waves through LDS.
+template <int LPR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
     int M, int C) {
-    __shared__ f32x4 red[2][4][64];
-    const int chunk = blockIdx.y, c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
+    __shared__ f32x4 red[2][4][LPR];
+    const int chunk = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int c = blockIdx.x * (LPR * 4) + cl * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
     if (c < C) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
         const int r1 = min(M, (chunk + 1) * CHUNK);
-        for (int r = chunk * CHUNK + wave; r < r1; r += 4) {
+        const int rend = min(r1, chunk * CHUNK + (wave + 1) * (CHUNK / 4));
+#pragma unroll 4
+        for (int r = chunk * CHUNK + wave * (CHUNK / 4) + sub; r < rend; r += RPW) {       // 12 loads in flight
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)r * C + c);
             if (act) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(act + (int64_t)r * C + c);
@@ -190,11 +200,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             s += g; q += g * xh;
         }
     }
-    red[0][wave][lane] = s; red[1][wave][lane] = q;
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {              // lane groups of the wave (same channels, other rows)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += __shfl_xor(s[e], o); q[e] += __shfl_xor(q[e], o); }
+    }
+    if (sub == 0) { red[0][wave][cl] = s; red[1][wave][cl] = q; }
     __syncthreads();
-    if (wave == 0 && c < C) {
-        s = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        q = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    if (wave == 0 && sub == 0 && c < C) {
+        s = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        q = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
         *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 0) * C + c) = s;
         *reinterpret_cast<f32x4*>(slab + ((int64_t)chunk * 2 + 1) * C + c) = q;
     }
@@ -584,12 +599,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t stride,
                                     int N, int C, int taps, int Kslab, float* __restrict__ dw,
                                     int Kout, int accumulate) {
+    if (taps > 1) {
+        // walk the slabs in THEIR order (tap-major, channel-minor: coalesced reads of `splits` slabs)
+        // and scatter into torch's [N][C][taps] -- the reads are `splits` times the writes
+        const int64_t total = (int64_t)N * Kslab;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const int n = i / Kslab, kk = i - (int64_t)n * Kslab;   // kk = t*C + c
+            const int t = kk / C, c = kk - t * C;
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * stride + i];
+            const int64_t dst = (int64_t)n * Kout + (int64_t)c * taps + t;
+            dw[dst] = (accumulate ? dw[dst] : 0.f) + s;
+        }
+        return;
+    }
     const int64_t total = (int64_t)N * Kout;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int n = i / Kout, ko = i - (int64_t)n * Kout;        // ko = c*taps + t
-        const int c = ko / taps, t = ko - c * taps;
-        const int64_t src = (int64_t)n * Kslab + (int64_t)t * C + c;
+        const int n = i / Kout, ko = i - (int64_t)n * Kout;        // taps == 1: ko = c (Kout <= Kslab: stem padding)
+        const int64_t src = (int64_t)n * Kslab + ko;
         float s = 0.f;
         for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * stride + src];
         dw[i] = (accumulate ? dw[i] : 0.f) + s;
@@ -660,8 +689,15 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
-                       invstd, slab_ws, M, C);
+    if (C <= 64)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<16>, dim3(grl_ceil_div(C, 64), rows), dim3(256), 0, s, dy, z, act, mean,
+                           invstd, slab_ws, M, C);
+    else if (C <= 128)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(grl_ceil_div(C, 128), rows), dim3(256), 0, s, dy, z, act, mean,
+                           invstd, slab_ws, M, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
+                           invstd, slab_ws, M, C);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, s, slab_ws, rows, C,
                        (double)M, dgamma, dbeta, coef_ws);
     const int64_t total4 = (int64_t)M * C / 4;
@@ -817,7 +853,7 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     const int taps = d.conv ? d.kh * d.kw : 1;
     const int Cc = d.conv ? d.C : d.K;
     const int kout = d.k_out > 0 ? d.k_out : d.K;      // stem: K padded to 160, 147 real
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)d.N * kout)), dim3(256), 0, s, d.workspace,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)d.N * (taps > 1 ? d.K : kout))), dim3(256), 0, s, d.workspace,
                        real_splits, a.slab_stride, d.N, Cc, taps, d.K, d.dw, kout, d.accumulate);
     return grl_check_launch("grl_conv_wgrad_f32");
 }

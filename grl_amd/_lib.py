@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
 
-EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID = 0, 1, 2
+EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
 _fp = C.c_void_p      # device float*
 _i32 = C.c_int32
@@ -24,7 +24,7 @@ class GrlGemm(C.Structure):
                                    'rnorm', 'cnorm', 'stats')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
-                                    'kw', 'stride', 'pad', 'math', 'out_f32', 'kblock')]
+                                    'kw', 'stride', 'pad', 'math', 'out_f32', 'res_rows', 'res_gstride', 'kblock')]
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2

@@ -408,6 +408,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         constexpr int RPI = 64 / LPR;                       // rows per pass
         const int lrow = lane / LPR, lcol = (lane % LPR) * 4;
         const int n = n0 + wn * WTN + lcol;
+        if constexpr (MATH != 2 && BM == 128 && BN == 128) {
+            if (p.epilogue == GRL_EPI_SQDIFF) {
+                // TRL step: v = relu(acc*scale + shift) is compared with the hoisted conv_f2 output and only
+                // the squared difference, summed over each 32-row quarter of a clip, leaves the workgroup
+                // (grl_model.py:146-149).  Fixed order: a lane adds its 8 rows of the quarter (rows
+                // 4k + lrow), then the 4 lanes of a channel group combine by xor-shuffles 16, 32; the
+                // consumer adds the four quarters of a clip.  The tile shape is pinned (128 x 128), so
+                // the order -- and a clip's feature row -- does not depend on the batch size.
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+                for (int it = 0; it < WTM / RPI; ++it) {           // RPI = 4, WTM = 64: 16 passes, 8 per quarter
+                    const int row = wm * WTM + it * RPI + lrow;
+                    const int m = m0 + row;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol);
+                    v = v * sc + sh;
+                    const int64_t rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
+                    const f32x4 f2 = *reinterpret_cast<const f32x4*>(p.res + rr * p.ldres + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = (v[e] > 0.f ? v[e] : 0.f) - f2[e];
+                        part[it >> 3][e] += t * t;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        part[h][e] += __shfl_xor(part[h][e], 16);
+                        part[h][e] += __shfl_xor(part[h][e], 32);
+                    }
+                    if (lrow == 0 && n < p.N)
+                        *reinterpret_cast<f32x4*>(p.y + (int64_t)((m0 + wm * WTM) / 32 + h) * p.ldy + n) = part[h];
+                }
+                return;
+            }
+        }
         if (n < p.N) {
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, cn = sh;
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
@@ -537,6 +576,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 struct TileChoice { int bm, bn; };
 
 TileChoice choose_tile(const GrlGemm& d) {
+    if (d.epilogue == GRL_EPI_SQDIFF) return {128, 128};          // pinned: fixed reduction order (see the epilogue)
     // GRL_GEMM_TILE=128x128|128x64|64x64 forces a tile (kernel tuning only)
     if (const char* e = getenv("GRL_GEMM_TILE")) {
         int bm = 0, bn = 0;
@@ -647,6 +687,13 @@ int validate(const GrlGemm& d) {
     if (d.epilogue == GRL_EPI_EUCLID && (!d.rnorm || !d.cnorm))
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");
+    if (d.epilogue == GRL_EPI_SQDIFF) {
+        if (d.math == GRL_MATH_BF16S || d.conv || d.stats || d.rowscale || d.gbias || !d.res)
+            return grl_fail(GRL_EINVAL, "gemm: SQDIFF epilogue is fp32-storage, dense, with res = the f2 tensor");
+        if (d.M % 128 || d.N % 128 || d.res_rows <= 0 || d.res_rows % 32 || d.ldres % 4 || d.ldy % 4 ||
+            ((uintptr_t)d.res & 15) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.scale & 15) || ((uintptr_t)d.shift & 15))
+            return grl_fail(GRL_EINVAL, "gemm: SQDIFF needs M, N % 128 == 0, res_rows % 32 == 0, aligned operands");
+    }
     if (d.kblock && d.math != GRL_MATH_F32) return grl_fail(GRL_EINVAL, "gemm: kblock needs GRL_MATH_F32");
     return GRL_OK;
 }

@@ -20,7 +20,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, check, ptr, require_device
+from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF, check, ptr, require_device
 
 import contextlib
 import os
@@ -56,6 +56,7 @@ def math_mode(name):
         _math[0] = old
 
 
+FUSE_TRL_SQDIFF = True     # TRL step: (ReLU(f1) - f2)^2 GAP inside the f1 GEMM epilogue (A/B switch for tools/)
 PIX = 128            # 16 x 8 feature map of layer4 (basebranch.py:59 hard-codes it)
 
 
@@ -142,7 +143,7 @@ def augment_normalize_u8(clips, params):
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False,
-         kblock=False):
+         kblock=False, res_rows=0, res_gstride=0):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -166,6 +167,7 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.math = (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if math is None else math
     d.out_f32 = 1 if out_f32 else 0
     d.kblock = 1 if kblock else 0
+    d.res_rows, d.res_gstride = res_rows, res_gstride
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
@@ -444,14 +446,22 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device)
     memo = [memo0, memo0]
     dvec = _new((b, Cc), xu)
+    dpart = _new((Mb // 32, Cc), xu)
     catte = _new((b, Cc), xu) if taps is not None else None
     hid = _new((b, 128), xu)
     for i in range(t):
         for di, d in enumerate(plan.dirs):
             ti = i if di == 0 else t - 1 - i
-            f1 = _new((Mb, Cc), xu)
-            gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
-            _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+            # d = GAP((ReLU(conv_f1(memo)) - f2_t)^2): the squared difference is reduced in the GEMM
+            # epilogue (32-row partial sums), conv_f1's output never reaches HBM (grl_model.py:146-149)
+            if FUSE_TRL_SQDIFF:
+                gemm(memo[di], d['f1'].w, dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
+                     res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX)
+                _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
+            else:
+                f1 = _new((Mb, Cc), xu)
+                gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
+                _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
             _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
                   ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
             if taps is not None:

@@ -38,6 +38,10 @@ int grl_abi_version(void);
 #define GRL_EPI_AFFINE  0   /* y = relu?( rs[m]*(acc + gbias[m/rpg][n])*scale[n] + shift[n] + res[m][n] ) */
 #define GRL_EPI_NEGDOT  1   /* y = -acc                                     (attevaluator.py:44-46)  */
 #define GRL_EPI_EUCLID  2   /* y = sqrt(max(rnorm[m]+cnorm[n]-2acc,1e-12))  (attevaluator.py:33-41)  */
+#define GRL_EPI_SQDIFF  3   /* TRL step (grl_model.py:146-149): v = relu(acc*scale + shift) is NOT stored;
+                               y[m/32][n] = sum over the 32 rows of (v - res[row'][n])^2, row' = (m/res_rows)*
+                               res_gstride + m%res_rows -- the conv_f1 output never reaches HBM.  fp32 storage,
+                               128 x 128 tiles (M % 128 == 0), y is [M/32][ldy] fp32 partial sums            */
 
 /* multiplier datapath of grl_conv_gemm_f32 (operands are fp32 in HBM in every mode) */
 #define GRL_MATH_F32     0  /* exact fp32 MFMA: the documented fmaf chain (default)              */
@@ -83,6 +87,7 @@ typedef struct GrlGemm {
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
     int32_t math;          /* GRL_MATH_*: multiplier datapath (accumulation is always fp32)   */
     int32_t out_f32;       /* GRL_MATH_BF16S only: write y as fp32                            */
+    int32_t res_rows, res_gstride;   /* GRL_EPI_SQDIFF: row mapping of `res` (rows per group, row stride between groups) */
     int32_t kblock;        /* GRL_MATH_F32 only: 1 = cut the accumulation chain every 512 k and sum the
                               segments (K-blocked accumulation: the accuracy class of a blocked CPU
                               sgemm; ~4 % slower on K >= 1024).  The train-mode forward sets it -- ReLU

@@ -592,3 +592,36 @@ def test_device_rect_scale_matches_reference_and_pil(dev, golden):
             assert np.array_equal(y[n].transpose(1, 2, 0), ref), (hh, ww)
     x = torch.from_numpy(rng.integers(0, 256, (1, 2, 3, 256, 128), dtype=np.uint8)).to(dev)
     assert engine.rect_scale_u8(x) is x
+
+
+@pytest.mark.parametrize('b,t', [(2, 3), (5, 2)])
+def test_gemm_sqdiff_epilogue_matches_unfused_path(dev, b, t):
+    """GRL_EPI_SQDIFF (TRL step: GAP((ReLU(conv_f1(memo)) - f2_t)^2) reduced inside the GEMM epilogue,
+    the conv output never stored) against the unfused launches (GEMM -> grl_sqdiff_mean) and a
+    float64 reference; a clip's result does not depend on the batch around it."""
+    from grl_amd import engine
+    from grl_amd._lib import ptr, EPI_SQDIFF
+    rng = np.random.default_rng(b * 10 + t)
+    Cc, PIX = 256, 128
+    memo = torch.from_numpy(rng.standard_normal((b * PIX, Cc)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((Cc, Cc)) / 16).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32)).to(dev)
+    f2 = torch.from_numpy(np.maximum(rng.standard_normal((b * t * PIX, Cc)), 0).astype(np.float32)).to(dev)
+    ti = t - 1
+    dpart = torch.empty(b * 4, Cc, device=dev)
+    engine.gemm(memo, w, dpart, b * PIX, Cc, Cc, shift=bias, epilogue=EPI_SQDIFF, res=f2[ti * PIX:], res_rows=PIX,
+                res_gstride=t * PIX)
+    d = torch.empty(b, Cc, device=dev)
+    engine._call('grl_group_mean', ptr(dpart), ptr(d), b, 4, Cc, Cc, C.c_float(1.0 / 32.0), 0)
+    f1 = torch.empty(b * PIX, Cc, device=dev)
+    engine.gemm(memo, w, f1, b * PIX, Cc, Cc, shift=bias, relu=True)
+    d_ref = torch.empty(b, Cc, device=dev)
+    engine._call('grl_sqdiff_mean', ptr(f1), ptr(f2[ti * PIX:]), ptr(d_ref), b, PIX, Cc, t * PIX * Cc)
+    exact = ((f1.double().view(b, PIX, Cc) - f2.double().view(b, t, PIX, Cc)[:, ti]) ** 2).mean(1)
+    assert _rel(d.cpu().numpy(), exact.cpu().numpy()) < 1e-6
+    assert _rel(d.cpu().numpy(), d_ref.cpu().numpy()) < 1e-6
+    # clip 0 alone: identical bits
+    dp1 = torch.empty(4, Cc, device=dev)
+    engine.gemm(memo[:PIX], w, dp1, PIX, Cc, Cc, shift=bias, epilogue=EPI_SQDIFF, res=f2[ti * PIX:], res_rows=PIX,
+                res_gstride=t * PIX)
+    assert torch.equal(dp1, dpart[:4])

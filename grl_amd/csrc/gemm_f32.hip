@@ -577,13 +577,18 @@ struct TileChoice { int bm, bn; };
 
 TileChoice choose_tile(const GrlGemm& d) {
     if (d.epilogue == GRL_EPI_SQDIFF) return {128, 128};          // pinned: fixed reduction order (see the epilogue)
-    // GRL_GEMM_TILE=128x128|128x64|64x64 forces a tile (kernel tuning only)
-    if (const char* e = getenv("GRL_GEMM_TILE")) {
-        int bm = 0, bn = 0;
-        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) &&
-            !(bm == 64 && bn == 128))
-            return {bm, bn};
-    }
+    // GRL_GEMM_TILE=128x128|128x64|64x64 forces a tile (kernel tuning only; read once per process)
+    static const TileChoice forced = [] {
+        TileChoice f{0, 0};
+        if (const char* e = getenv("GRL_GEMM_TILE")) {
+            int bm = 0, bn = 0;
+            if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) &&
+                !(bm == 64 && bn == 128))
+                f = {bm, bn};
+        }
+        return f;
+    }();
+    if (forced.bm) return forced;
     // Measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 128x128
     // tile wins when the K loop is long (>= 1024: 131-135 TFLOP/s); short-K layers are
     // prologue/epilogue bound and want more, smaller workgroups per CU (K <= 128: 64x64,
@@ -605,10 +610,11 @@ TileChoice choose_tile(const GrlGemm& d) {
 // GRL_GEMM_GRID overrides it (kernel tuning only; 0 = one workgroup per tile).
 int resident_workgroups(const void* kernel, size_t lds) {
     if (lds > 65536) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (const char* e = getenv("GRL_GEMM_GRID")) {
-        const int g = atoi(e);
-        return g > 0 ? (g + 7) / 8 * 8 : 0x7fffffff;
-    }
+    static const int forced_grid = [] {                       // GRL_GEMM_GRID: tuning only, read once
+        const char* e = getenv("GRL_GEMM_GRID");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced_grid >= 0) return forced_grid > 0 ? (forced_grid + 7) / 8 * 8 : 0x7fffffff;
     int dev = 0, cus = 256, occ = 2;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipDeviceProp_t prop;
@@ -622,7 +628,14 @@ int resident_workgroups(const void* kernel, size_t lds) {
 
 template <auto KERNEL>
 void launch_kernel(const GrlGemm& d, hipStream_t s, size_t lds, int tiles_n, int num_tiles, int vec_epi) {
-    static const int slots = resident_workgroups((const void*)KERNEL, lds);      // per instantiation
+    // persistent grid = the workgroups the CURRENT device keeps resident, cached per instantiation and
+    // per device (one process normally drives one GPU, but nothing here assumes it)
+    static int slots_of[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cached = slots_of[dev & 15];
+    if (cached == 0) cached = resident_workgroups((const void*)KERNEL, lds);
+    const int slots = cached;
     hipLaunchKernelGGL(KERNEL, dim3(num_tiles < slots ? num_tiles : slots), dim3(256), lds, s, d, tiles_n, num_tiles,
                        vec_epi);
 }

@@ -63,7 +63,7 @@ struct RowInfo {          // per staged A row: where it comes from
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
 // SEG: cut the fp32 accumulation chain every SEG_STAGES stages (launched when K > 512; K <= 512
 // layers run the instantiation without the second accumulator set).
-template <int BM, int BN, bool CONV, int MATH, bool SEG>
+template <int BM, int BN, bool CONV, int MATH, bool SEG, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
                                                            const int num_tiles, const int vec_epi) {
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const int d_row = lane >> 3, d_chunk = lane & 7;          // LDS-DMA staging: lane = (row of an 8-row block, chunk)
 
     // Persistent workgroups: the grid holds as many workgroups as the chip keeps resident and
     // each walks tiles t = blockIdx.x, + gridDim.x, ...  The next tile's first K stage is
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     // run of tiles so that the W panel / A panel re-reads of neighbouring tiles hit that XCD's L2.
     RowInfo ai[A_ITEMS];
     int64_t bofs[B_ITEMS];
+    const char* dma_a[DMA ? BM / 32 : 1];
+    const char* dma_b[DMA ? BN / 32 : 1];
     int m0, n0, tile_m;
     auto setup_tile = [&](int t) {
         int bid = t;
@@ -130,10 +133,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             n = n < p.N ? n : p.N - 1;
             bofs[i] = (int64_t)n * p.ldw;
         }
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) {
+                const int r = (wave + 4 * i) * 8 + d_row;
+                int m = m0 + r;
+                m = m < p.M ? m : p.M - 1;
+                dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)m * p.lda) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int r = (wave + 4 * i) * 8 + d_row;
+                int n = n0 + r;
+                n = n < p.N ? n : p.N - 1;
+                dma_b[i] = reinterpret_cast<const char*>(p.w) + ((int64_t)n * p.ldw) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
+            }
+        }
+    };
+
+    // DMA (dense fp32 / bf16-storage operands): the stage goes global -> LDS by LDS-DMA
+    // (`global_load_lds_dwordx4`): no staging VGPRs, no ds_write, no vmcnt wait in front of them.  A
+    // wave-instruction fills 8 rows x 128 B linearly; the chunk swizzle moves to the per-lane SOURCE.
+    // Wave w owns the 8-row blocks w, w+4, ... of both tiles; lane l is (row l>>3, chunk l&7).
+    auto dma_stage = [&](int buf, int ks) {
+        if constexpr (DMA) {
+            char* const Asb = reinterpret_cast<char*>(As + buf * BM * BK);
+            char* const Bsb = reinterpret_cast<char*>(Bs + buf * BN * BK);
+            const int64_t kb = (int64_t)ks * KST * ESZ;
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) {
+                const int rb = wave + 4 * i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_a[i] + kb),
+                                                 (__attribute__((address_space(3))) void*)(Asb + rb * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int rb = wave + 4 * i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_b[i] + kb),
+                                                 (__attribute__((address_space(3))) void*)(Bsb + rb * 1024), 16, 0, 0);
+            }
+        }
     };
 
     f32x4 areg[A_ITEMS], breg[B_ITEMS];
     auto load_stage = [&](int ks) {
+        if constexpr (DMA) return;
         const int k0 = ks * KST;
         if (CONV) {
             const int tap = k0 / p.C, c0 = k0 - tap * p.C;          // wave-uniform
@@ -173,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         }
     };
     auto store_stage = [&](int buf) {
+        if constexpr (DMA) return;
         if constexpr (MATH == 0 || MATH == 2) {
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i) {
@@ -203,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     int t = blockIdx.x;
     setup_tile(t);
     load_stage(0);
+    dma_stage(0, 0);
     for (;;) {
     f32x16 acc[MT][NT], tot[SEG ? MT : 1][SEG ? NT : 1];
 #pragma unroll
@@ -225,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
 
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) load_stage(ks + 1);
+        if (ks + 1 < nk) { load_stage(ks + 1); dma_stage(buf ^ 1, ks + 1); }
         if constexpr (MATH == 2) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
@@ -342,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         setup_tile(next_t);
         load_stage(0);
     }
+    // (DMA: the next tile's first stage is issued AFTER the epilogue has left the LDS it parks C in)
 
     // ---- epilogue --------------------------------------------------------------
     // acc[i][j][r] is Y[row][col] with row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31
@@ -570,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     if (next_t >= num_tiles) break;
     t = next_t;
     __syncthreads();          // every wave is done with the C staging before the stages are rewritten
+    dma_stage(0, 0);
     }
 }
 
@@ -660,7 +708,12 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
         if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     } else {
-        if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        // dense fp32 with a long K loop: LDS-DMA staging (GRL_GEMM_DMA=0 switches it off: tuning only)
+        static const bool dma_on = [] { const char* e = getenv("GRL_GEMM_DMA"); return !e || atoi(e) != 0; }();
+        constexpr bool CAN_DMA = MATH == 0 && BM == 128;
+        if (CAN_DMA && dma_on && !seg && d.K >= 256)
+            launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");

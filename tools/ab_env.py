@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""A/B of one environment knob of libgrl_hip.so that is read once per process: runs the headline
+step in two child processes per round, interleaved.   python tools/ab_env.py GRL_GEMM_DMA 0 1 [rounds]"""
+import os, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch, bench
+from grl_amd import engine
+from grl_amd.synthetic import synth_clips
+dev = torch.device('cuda:0')
+cnn, siam, _, _ = bench.build_models(dev)
+clips = synth_clips(32, 4, seed=0).to(dev)
+for _ in range(5): f = engine.extract_features(cnn, siam, clips)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(30): f = engine.extract_features(cnn, siam, clips)
+torch.cuda.synchronize()
+print('MS %%.4f %%.10f' %% ((time.perf_counter() - t0) / 30 * 1e3, float(f.double().abs().sum())))
+''' % R
+key, a, b = sys.argv[1:4]
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+res = {a: [], b: []}
+for _ in range(rounds):
+    for v in (a, b):
+        out = subprocess.run([sys.executable, '-c', CODE], env=dict(os.environ, **{key: v}), capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith('MS')]
+        if not line:
+            print(out.stderr[-2000:]); sys.exit(1)
+        res[v].append(line[0].split()[1:])
+for v in (a, b):
+    ms = sorted(float(x[0]) for x in res[v])
+    print('%s=%s: median %.3f ms min %.3f  checksum %s' % (key, v, ms[len(ms) // 2], ms[0], res[v][0][1]))

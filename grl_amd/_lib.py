@@ -33,7 +33,7 @@ MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
 class GrlWgrad(C.Structure):
     _fields_ = [(n, _fp) for n in ('dz', 'x', 'dw', 'workspace')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'ldz', 'ldx', 'k_out', 'accumulate', 'conv', 'H', 'W',
-                                    'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad')]
+                                    'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math')]
 
 
 _SIGNATURES = {

@@ -465,8 +465,20 @@ struct WgradArgs {
     int conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
 };
 
-template <int BM, int BN, bool CONV>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// MATH 0: exact fp32 (above).  MATH 3 / 1 (128 x 128 tiles only): the staging pass splits every
+// operand value into bf16 hi (+ lo = bf16(v - hi) for MATH 3) and writes [m][out] bf16 planes with
+// 256-byte rows, the 16-byte chunk XOR-swizzled by ((m & 3) << 2) | ((m >> 2) & 3); the reduction index
+// m is the ROW of both tiles, so the MFMA fragments (8 consecutive m of one output column) are read
+// with the hardware transpose read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16-lane group,
+// conflict-free with that swizzle) and feed v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi.
+template <int BM, int BN, bool CONV, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
+    static_assert(MATH == 0 || (BM == 128 && BN == 128), "the bf16 datapaths are written for 128 x 128 tiles");
     constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // float4 per thread per stage (32 rows)
     constexpr int A_TPR = BM / 4, B_TPR = BN / 4;         // threads per row
@@ -530,16 +542,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
             breg[i] = v;
         }
     };
-    auto store_stage = [&](int buf) {
+    constexpr int PLANE = 32 * 256;                       // bytes of one bf16 plane: 32 rows x 128 columns
+    constexpr int NPL = MATH == 3 ? 2 : 1;                // planes per operand (hi, lo)
+    char* const sm8 = reinterpret_cast<char*>(smem);      // MATH != 0: [2 buf][A hi, (A lo), B hi, (B lo)][PLANE]
+    auto split_store = [&](char* plane0, int e, const f32x4 v) {
+        const int row = e >> 5, col = (e & 31) * 4;       // 32 threads per 128-wide row
+        const int off = 256 * row + 16 * ((col >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 2 * (col & 7);
+        bf16x4 hi;
 #pragma unroll
-        for (int i = 0; i < A_ITEMS; ++i) {
-            const int e = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(As + buf * 32 * BM + e * 4) = areg[i];
+        for (int k = 0; k < 4; ++k) hi[k] = (__bf16)v[k];
+        *reinterpret_cast<bf16x4*>(plane0 + off) = hi;
+        if (MATH == 3) {
+            bf16x4 lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lo[k] = (__bf16)(v[k] - (float)hi[k]);
+            *reinterpret_cast<bf16x4*>(plane0 + PLANE + off) = lo;
         }
+    };
+    auto store_stage = [&](int buf) {
+        if constexpr (MATH == 0) {
 #pragma unroll
-        for (int i = 0; i < B_ITEMS; ++i) {
-            const int e = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(Bs + buf * 32 * BN + e * 4) = breg[i];
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int e = tid + 256 * i;
+                *reinterpret_cast<f32x4*>(As + buf * 32 * BM + e * 4) = areg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i) {
+                const int e = tid + 256 * i;
+                *reinterpret_cast<f32x4*>(Bs + buf * 32 * BN + e * 4) = breg[i];
+            }
+        } else {
+            char* const base = sm8 + buf * (2 * NPL * PLANE);
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) split_store(base, tid + 256 * i, areg[i]);
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i) split_store(base + NPL * PLANE, tid + 256 * i, breg[i]);
         }
     };
 
@@ -553,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 
     const int nst = (m_end - m_begin + 31) / 32;
     const int frow = lane & 31, fhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     if (nst > 0) {
         load_stage(m_begin);
         store_stage(0);
@@ -561,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         if (st + 1 < nst) load_stage(m_begin + (st + 1) * 32);
+        if constexpr (MATH == 0) {
         const float* Ab = As + buf * 32 * BM + wm * WTM;
         const float* Bb = Bs + buf * 32 * BN + wn * WTN;
 #pragma unroll
@@ -575,6 +614,72 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        } else {
+            // transpose reads: 16-lane group g = lane >> 4 reads the 4-row x 16-column block
+            // rows 16*ks + 8*(g >> 1) + 4*rd .. +3, columns tile + 16*(g & 1) .. +15; lane 4q + p of the
+            // group supplies the address of row q, columns 4p .. 4p+3 and receives column (lane & 15)
+            const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+            const unsigned sbase = lds_base + buf * (2 * NPL * PLANE);
+            unsigned aaddr[MT][2], baddr[NT][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int row = 8 * (g >> 1) + 4 * rd + q;
+                const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int col = wm * WTM + i * 32 + 16 * (g & 1) + 4 * pp;
+                    aaddr[i][rd] = sbase + 256 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = wn * WTN + j * 32 + 16 * (g & 1) + 4 * pp;
+                    baddr[j][rd] = sbase + NPL * PLANE + 256 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+                }
+            }
+#define GRL_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define GRL_FRAG(lo4, hi4) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7))
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {               // two k-steps of 16 rows per 32-row stage
+                s16x4 ra[NPL][MT][2], rb[NPL][NT][2];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            if (ks == 0 && pl == 0) GRL_TR(ra[pl][i][rd], aaddr[i][rd], 0);
+                            if (ks == 0 && pl == 1) GRL_TR(ra[pl][i][rd], aaddr[i][rd], PLANE);
+                            if (ks == 1 && pl == 0) GRL_TR(ra[pl][i][rd], aaddr[i][rd], 4096);
+                            if (ks == 1 && pl == 1) GRL_TR(ra[pl][i][rd], aaddr[i][rd], PLANE + 4096);
+                        }
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            if (ks == 0 && pl == 0) GRL_TR(rb[pl][j][rd], baddr[j][rd], 0);
+                            if (ks == 0 && pl == 1) GRL_TR(rb[pl][j][rd], baddr[j][rd], PLANE);
+                            if (ks == 1 && pl == 0) GRL_TR(rb[pl][j][rd], baddr[j][rd], 4096);
+                            if (ks == 1 && pl == 1) GRL_TR(rb[pl][j][rd], baddr[j][rd], PLANE + 4096);
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const bf16x8 ah = GRL_FRAG(ra[0][i][0], ra[0][i][1]), bh = GRL_FRAG(rb[0][j][0], rb[0][j][1]);
+                        if (MATH == 3) {                   // small terms first
+                            const bf16x8 al = GRL_FRAG(ra[NPL - 1][i][0], ra[NPL - 1][i][1]);
+                            const bf16x8 bl = GRL_FRAG(rb[NPL - 1][j][0], rb[NPL - 1][j][1]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef GRL_TR
+#undef GRL_FRAG
         }
         if (st + 1 < nst) store_stage(buf ^ 1);
         __syncthreads();
@@ -819,6 +924,7 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     GRL_REQUIRE(d.dz && d.x && d.dw && d.workspace, "wgrad: null pointer");
     GRL_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.ldz % 4 == 0, "wgrad: bad shape");
     GRL_REQUIRE(d.N % 4 == 0 && d.K % 4 == 0, "wgrad: N and K must be multiples of 4");
+    GRL_REQUIRE(d.math == GRL_MATH_F32 || d.math == GRL_MATH_BF16X3 || d.math == GRL_MATH_BF16, "wgrad: unknown math mode");
     if (d.conv) {
         GRL_REQUIRE(d.C % 64 == 0 && d.K == d.kh * d.kw * d.C, "wgrad conv: C % 64, K = kh*kw*C");
         GRL_REQUIRE(d.M % (d.Ho * d.Wo) == 0, "wgrad conv: M must be nimg*Ho*Wo");
@@ -845,7 +951,13 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
         if (d.conv) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true>), grid, dim3(256), lds, s, a, tiles_k);  \
         else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, false>), grid, dim3(256), lds, s, a, tiles_k);        \
     } while (0)
-    if (bm == 128 && bn == 128) GRL_WGRAD_LAUNCH(128, 128);
+    if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16X3) {
+        if (d.conv) hipLaunchKernelGGL((wgrad_kernel<128, 128, true, 3>), grid, dim3(256), lds, s, a, tiles_k);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 128, false, 3>), grid, dim3(256), lds, s, a, tiles_k);
+    } else if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16) {
+        if (d.conv) hipLaunchKernelGGL((wgrad_kernel<128, 128, true, 1>), grid, dim3(256), lds, s, a, tiles_k);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 128, false, 1>), grid, dim3(256), lds, s, a, tiles_k);
+    } else if (bm == 128 && bn == 128) GRL_WGRAD_LAUNCH(128, 128);
     else if (bm == 128 && bn == 64) GRL_WGRAD_LAUNCH(128, 64);
     else if (bm == 64 && bn == 128) GRL_WGRAD_LAUNCH(64, 128);
     else GRL_WGRAD_LAUNCH(64, 64);

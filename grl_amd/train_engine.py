@@ -209,9 +209,10 @@ class Tape(object):
         self.ops = []
 
 
-def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1):
-    """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32."""
+def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
+    """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32 (datapath: the training math mode)."""
     d = GrlWgrad()
+    d.math = _train_math[0] if math is None else math
     d.dz, d.x, d.dw = ptr(dz), ptr(x), ptr(dw)
     d.M, d.N, d.K = M, N, K
     d.ldz = ldz or N

@@ -321,6 +321,9 @@ typedef struct GrlWgrad {
     int32_t k_out;          /* dense: columns of dw actually written (0 = K) */
     int32_t accumulate;
     int32_t conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
+    int32_t math;           /* GRL_MATH_F32 (exact), GRL_MATH_BF16X3 (split-bf16 products) or GRL_MATH_BF16: the
+                               bf16 MFMA datapaths apply to 128 x 128 tiles (N >= 128, C or K % 128 == 0), other
+                               shapes run exact fp32; accumulation and the slab reduction are always fp32 */
 } GrlWgrad;
 int64_t grl_wgrad_workspace_floats(const GrlWgrad* desc);
 int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream);

@@ -337,3 +337,35 @@ def test_wgrad_tiny_M_ignores_memory_past_the_operands(M, N, K):
         assert np.isfinite(outs[-1]).all(), poison
         assert _rel(outs[-1], ref) < 1e-5, poison
     assert np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize('M,N,K,conv', [(4096, 128, 2048, None), (1000, 256, 128, None), (40, 2048, 128, None),
+                                        (2 * 16 * 8, 128, 9 * 128, (16, 8, 128, 16, 8, 3, 3, 1, 1)),
+                                        (2 * 8 * 8, 256, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1))])
+def test_wgrad_bf16_datapaths(M, N, K, conv):
+    """Weight gradient on the bf16 MFMA (GrlWgrad.math): transpose reads of [m][out] bf16 planes.
+    On bf16-representable operands 'bf16x3' and 'bf16' reproduce the exact fp32 kernel up to fp32
+    summation order; on general fp32 operands 'bf16x3' stays at ~1e-5 of the float64 product and
+    'bf16' at the 2^-8 operand rounding."""
+    from grl_amd import train_engine as TE
+    from grl_amd._lib import MATH_F32, MATH_BF16, MATH_BF16X3
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(M + N + K)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+
+    def run(dz, x, math):
+        dw = torch.zeros((N, cin, 3, 3) if conv else (N, K), device=dev)
+        TE.wgrad(dz, x, dw, M, N, K, conv=conv, accumulate=0, math=math)
+        return dw
+    for representable in (True, False):
+        dz = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+        x = torch.from_numpy(np.maximum(rng.standard_normal((rows_in, cin)), -0.5).astype(np.float32))
+        if representable:
+            dz, x = dz.bfloat16().float(), x.bfloat16().float()
+        dzd, xd = dz.to(dev), x.to(dev)
+        ref32 = run(dzd, xd, MATH_F32).cpu().double()
+        for math, tol in ((MATH_BF16X3, 2e-6 if representable else 3e-5), (MATH_BF16, 2e-6 if representable else 2e-2)):
+            got = run(dzd, xd, math).cpu().double()
+            err = float((got - ref32).abs().max() / ref32.abs().max())
+            assert err < tol, (representable, math, err)

@@ -105,6 +105,94 @@ def cpu_baseline(sd, ssd):
                       "step, T=%d, %d timed passes (%.1f s)" % (cores, nb, T, passes, dt)}
 
 
+def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4):
+    """One SEQTrainer step (forward + 5-term loss + HIP backward + SGD) timed in this process;
+    used by the default run's `secondary` block.  Returns ms per step."""
+    from grl_amd.reid import models
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.synthetic import synth_clips, synth_state_dict
+    from grl_amd import train_engine
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    cnn.load_state_dict(synth_state_dict(cnn, seed=0))
+    siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'))
+    siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
+    cnn, siam, siamv = cnn.to(dev).train(), siam.to(dev).train(), siamv.to(dev).train()
+    tr = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev),
+                    OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), None)
+    opt = torch.optim.SGD(tr._all_params(), lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    clips = synth_clips(b, t, seed=0).to(dev)
+    pids = (torch.arange(b, device=dev) // 2 * 7) % 625
+    old = train_engine.set_math(math)
+    try:
+        def step():
+            loss, _, _, _ = tr._forward([clips], pids, 0, 0)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        assert bool(torch.isfinite(loss).all())
+    finally:
+        train_engine.set_math(old)
+    return ms
+
+
+def secondary_block(dev, cnn, siam, steps):
+    """Informational series measured by the SAME default run (so the driver's record holds them too):
+    BASELINE configs[2] (64 clips x 8 frames, bf16 storage), the train step (fp32 and the bf16x3
+    datapath) and the MARS-size distance matrix of configs[4].  Never `value`."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_clips, synth_eval_features
+    out = {}
+    c3 = synth_clips(64, 8, seed=0).to(dev)
+    with engine.math_mode('bf16s'):
+        for _ in range(3):
+            engine.extract_features(cnn, siam, c3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.extract_features(cnn, siam, c3)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    out["configs[2] bf16s, 64 clips x 8 frames"] = {"clip_features_per_sec": round(64 / ms * 1e3, 1), "ms_per_step": round(ms, 3),
+                                                     "frames_per_sec": round(512 / ms * 1e3)}
+    del c3
+    out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
+        m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
+        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'bf16x3'))}
+    qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
+    qd, gd = qf.to(dev), gf.to(dev)
+    for _ in range(2):
+        d = engine.cosin_dist(qd, gd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        d = engine.cosin_dist(qd, gd)
+    torch.cuda.synchronize()
+    dms = (time.perf_counter() - t0) / 5 * 1e3
+    engine.rank_rows(d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        engine.rank_rows(d)
+    torch.cuda.synchronize()
+    out["configs[4] distance matrix 1980 x 11310 x 6144 (fp32)"] = {
+        "ms": round(dms, 3), "tflops": round(2.0 * 1980 * 11310 * 6144 / dms / 1e9, 1),
+        "row_argsort_ms": round((time.perf_counter() - t0) / 3 * 1e3, 3)}
+    return out
+
+
 def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
     """Secondary series: train clips/sec.  One step = SEQTrainer's
     forward (train-mode BN) + reference loss composition + HIP backward + the flat
@@ -320,7 +408,7 @@ def main():
         # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
         peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_gemm_pmc.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r02_gemm_pmc.json')
         if os.path.isfile(pmc):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
         out = {
@@ -342,7 +430,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic if args.math == 'f32' else None,
                          "traffic_note": "HBM bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) summed "
                                          "over the kernel's launches of ONE step, like the GFLOP figure; "
-                                         "profiles/r01_gemm_pmc.json",
+                                         "profiles/r02_gemm_pmc.json",
                          "kernel": "gemm_f32_kernel (%s MFMA implicit-GEMM conv), %d launches/step, "
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
                                        'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
@@ -388,6 +476,8 @@ def main():
                 host[name] = round(B * args.steps / (time.perf_counter() - t1), 2)
             out["host_resident_inputs"] = {"clip_features_per_sec": host,
                                            "note": "pinned host batches, H2D overlapped; uint8 is normalised in the stem"}
+        if n == 1 and not args.no_alt and (B, T, args.math) == (32, 4, 'f32'):
+            out["secondary"] = secondary_block(dev, cnn, siam, args.steps)
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
         print(json.dumps(out))

@@ -33,14 +33,22 @@ def main(args):
     torch.manual_seed(args.seed)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    rank = int(os.environ.get('RANK', '0'))
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ.get('GRL_SINGLE_DEVICE'):          # functional test on a 1-GPU box: every rank on cuda:0, gloo
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if os.environ.get('GRL_DIST_BACKEND', 'nccl') == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(os.environ['GRL_DIST_BACKEND'])
     device = torch.device('cuda', local)
     num_classes = 625
     from torch.utils.data import DataLoader
-    train_loader = DataLoader(SyntheticPairs(args.iters * args.batch_size // 2, args.seq_len, seed=local),
+    # every rank iterates the SAME global batches; SEQTrainer keeps this rank's pair shard of each
+    train_loader = DataLoader(SyntheticPairs(args.iters * args.batch_size // 2, args.seq_len, seed=0, augment=args.augment),
                               batch_size=args.batch_size, drop_last=True)
     query_loader = DataLoader(SyntheticPairs(4, args.seq_len, seed=11), batch_size=8)
     gallery_loader = DataLoader(SyntheticPairs(12, args.seq_len, seed=12), batch_size=8)
@@ -75,13 +83,16 @@ def main(args):
         top1 = evaluator.evaluate(None, None, query_loader, gallery_loader, args.logs_dir, False, False)
         is_best = top1 >= best_top1
         best_top1 = max(best_top1, top1)
-        if local == 0:
+        if rank == 0:
             save_cnn_checkpoint({'state_dict': cnn_model.state_dict(), 'epoch': epoch + 1, 'best_top1': best_top1},
                                 is_best, fpath=osp.join(args.logs_dir, 'cnn_checkpoint.pth.tar'))
             save_siamese_checkpoint({'state_dict': siamese_model.state_dict(), 'epoch': epoch + 1,
                                      'best_top1': best_top1}, is_best,
                                     fpath=osp.join(args.logs_dir, 'siamese_checkpoint.pth.tar'))
-    if local == 0:                                       # eval-only reload (mars_train.py:38-43)
+    if world > 1:
+        torch.distributed.barrier()
+    # eval-only reload (mars_train.py:38-43) -- on every rank: the evaluator is collective under data parallel
+    if True:
         cnn_model.load_state_dict(load_checkpoint(osp.join(args.logs_dir, 'cnnmodel_best.pth.tar'))['state_dict'])
         siamese_model.load_state_dict(
             load_checkpoint(osp.join(args.logs_dir, 'siamesemodel_best.pth.tar'))['state_dict'])
@@ -97,6 +108,7 @@ if __name__ == '__main__':
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--iters', type=int, default=4)
     ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--augment', action='store_true', help='raw uint8 clips + on-device flip / erase / normalise')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--logs-dir', type=str, default='/tmp/grl_logs')
     main(ap.parse_args())

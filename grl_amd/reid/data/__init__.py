@@ -39,3 +39,43 @@ def get_data(dataset_name, split_id, data_dir, batch_size, seq_len, seq_srd, wor
     q = DataLoader(SyntheticPairs(15, seq_len, seed=1), batch_size=30, num_workers=0)
     g = DataLoader(SyntheticPairs(60, seq_len, seed=2), batch_size=30, num_workers=0)
     return train, 625, loader, q, g
+
+
+class RawVideoDataset(Dataset):
+    """Tracklets -> RAW uint8 clips for the on-device input pipeline (the counterpart of the
+    reference's VideoDataset + T.Compose, reid/data/video_loader.py:18-155, dataloader.py:51-72):
+    the worker only decodes; RectScale, flip, erase, ToTensor and Normalize run on the GPU.
+
+    ``tracklets``: [(img_paths, pid, camid)] as the reference's dataset objects provide
+    (reid/dataset/mars.py); ``sample``: 'rrs_train' | 'rrs_test' | 'dense' with the reference's frame
+    selection (``augment.sample_frame_indices``).  Items: (uint8 [T,3,H,W], pid, camid) -- 'dense':
+    [n_clips,T,3,H,W] -- plus, with ``augment=True`` (training), the int32 block of
+    ``augment.draw_clip_params`` that SEQTrainer hands to grl_augment_normalize_u8.  All frames of a
+    batch must share one size (MARS crops are 256 x 128; other sizes are RectScale'd on the device)."""
+
+    def __init__(self, tracklets, seq_len=4, sample='rrs_train', augment=False, height=256, width=128):
+        self.tracklets, self.seq_len, self.sample = list(tracklets), seq_len, sample
+        self.augment, self.height, self.width = augment, height, width
+
+    def __len__(self):
+        return len(self.tracklets)
+
+    @staticmethod
+    def _decode(path):
+        import numpy as np
+        from PIL import Image
+        with Image.open(path) as im:
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(im.convert('RGB')).transpose(2, 0, 1)))
+
+    def __getitem__(self, index):
+        from .augment import draw_clip_params, sample_frame_indices
+        paths, pid, camid = self.tracklets[index]
+        idx = sample_frame_indices(len(paths), self.seq_len, self.sample)
+        if self.sample == 'dense':
+            clip = torch.stack([torch.stack([self._decode(paths[int(i)]) for i in row]) for row in idx])
+        else:
+            clip = torch.stack([self._decode(paths[int(i)]) for i in idx])
+        item = (clip, pid, camid)
+        if self.augment:
+            item += (torch.tensor(draw_clip_params(self.seq_len, self.height, self.width), dtype=torch.int32),)
+        return item

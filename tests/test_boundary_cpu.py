@@ -143,3 +143,31 @@ def test_re_ranking_matches_reference_golden(golden):
     assert np.abs(final - g['final']).max() < 1e-6
     cmc, mAP = evaluate(final, qp, gp, qc, gc)
     assert np.allclose(cmc[:20], g['cmc'], atol=1e-6) and abs(mAP - float(g['mAP'])) < 1e-6
+
+
+def test_raw_video_dataset_decodes_and_samples_like_the_reference(tmp_path):
+    """RawVideoDataset: the loader side of the on-device input pipeline -- decode only, the
+    reference's frame selection, the augmentation block for training."""
+    import random
+    import numpy as np
+    import torch
+    from PIL import Image
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.augment import sample_frame_indices
+    rng = np.random.default_rng(0)
+    paths, frames = [], []
+    for i in range(11):
+        a = rng.integers(0, 256, (64, 32, 3), dtype=np.uint8)
+        p = tmp_path / ('f%02d.png' % i)
+        Image.fromarray(a, 'RGB').save(p)
+        paths.append(str(p)); frames.append(a)
+    ds = RawVideoDataset([(tuple(paths), 7, 2)], seq_len=4, sample='rrs_test')
+    clip, pid, cam = ds[0]
+    assert clip.dtype == torch.uint8 and tuple(clip.shape) == (4, 3, 64, 32) and (pid, cam) == (7, 2)
+    want = sample_frame_indices(11, 4, 'rrs_test')
+    assert all(np.array_equal(clip[k].numpy().transpose(1, 2, 0), frames[int(want[k])]) for k in range(4))
+    dense = RawVideoDataset([(tuple(paths), 7, 2)], seq_len=4, sample='dense')[0][0]
+    assert tuple(dense.shape) == (3, 4, 3, 64, 32)
+    random.seed(3); np.random.seed(3)
+    item = RawVideoDataset([(tuple(paths), 7, 2)], seq_len=4, sample='rrs_train', augment=True, height=64, width=32)[0]
+    assert len(item) == 4 and item[3].dtype == torch.int32 and tuple(item[3].shape) == (1 + 8 * 4,)

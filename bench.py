@@ -61,12 +61,14 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         return out
 
     engine.gemm = timed
+    streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)
         torch.cuda.synchronize()
     finally:
         engine.gemm = orig
+        engine.TRL_STREAMS = streams
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
     launches = len(recs) // iters

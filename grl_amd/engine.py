@@ -428,6 +428,48 @@ def gce_eval(plan, x4, b, t, taps=None):
     return xu, xc, cmap
 
 
+# The two TRL directions (forward / backward in time, grl_model.py:170-208) are independent recurrences over
+# their own weights: each step's GEMMs have M = B*128 rows -- 128..256 tiles, half a chip -- and six small
+# latency-bound kernels.  They are issued on two HIP streams (fork after the shared inputs, join before the
+# pooled outputs) so the chip runs one direction's GEMM next to the other's small kernels.  Same kernels,
+# same per-direction order, per-direction scratch: bit-identical to the single-stream order
+# (GRL_TRL_STREAMS=0, or taps requested).
+TRL_STREAMS = os.environ.get('GRL_TRL_STREAMS', '1') != '0'
+_side_streams = {}
+
+
+class _TrlFork(object):
+    """streams[di] for the two TRL directions; ``with fork.on(di):`` routes launches and allocations."""
+
+    def __init__(self, dev, enable):
+        self.main = torch.cuda.current_stream(dev)
+        self.two = bool(enable and TRL_STREAMS)
+        if self.two:
+            key = (dev.index if dev.index is not None else torch.cuda.current_device())
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(dev)
+            self.side = _side_streams[key]
+        else:
+            self.side = self.main
+
+    def fork(self):
+        if self.two:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+
+    def on(self, di):
+        return torch.cuda.stream(self.side if di == 1 else self.main)
+
+    def join(self, *side_tensors):
+        if self.two:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+            for x in side_tensors:
+                x.record_stream(self.main)
+
+
 def trl_eval(plan, xu, xc, b, t, taps=None):
     """xu, xc [b][t][128][2048] (flat) -> f_uncorr [b][2048], f_corr [b][t][2048]."""
     Cc = 2048
@@ -438,20 +480,26 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     gapc = _new((b * t, Cc), xu)
     _call('grl_group_mean', ptr(xc), ptr(gapc), b * t, PIX, Cc, Cc, C.c_float(1.0), 0)
     # conv_f2(x_corr_i) does not depend on the recurrence: one GEMM over all T per direction
-    f2 = []
-    for d in plan.dirs:
-        y = _new((b * t * PIX, Cc), xu)
-        gemm(xc, d['f2'].w, y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True)
-        f2.append(y)
-    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device)
+    fk = _TrlFork(xu.device, taps is None and len(plan.dirs) == 2)
+    fk.fork()
+    f2, fc, scr = [], [], []
+    for di, d in enumerate(plan.dirs):
+        with fk.on(di):
+            y = _new((b * t * PIX, Cc), xu)
+            gemm(xc, d['f2'].w, y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True)
+            f2.append(y)
+            # per-direction accumulators / scratch (a + b == b + a: summing the two directions' f_corr
+            # contributions at the join gives the bits the shared accumulator got in either arrival order)
+            fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device) if (fk.two or di == 0) else fc[0])
+            scr.append((_new((b, Cc), xu), _new((Mb // 32, Cc), xu), _new((b, 128), xu)))
     memo = [memo0, memo0]
-    dvec = _new((b, Cc), xu)
-    dpart = _new((Mb // 32, Cc), xu)
     catte = _new((b, Cc), xu) if taps is not None else None
-    hid = _new((b, 128), xu)
     for i in range(t):
         for di, d in enumerate(plan.dirs):
+          with fk.on(di):
             ti = i if di == 0 else t - 1 - i
+            dvec, dpart, hid = scr[di]
+            fcorr = fc[di]
             # d = GAP((ReLU(conv_f1(memo)) - f2_t)^2): the squared difference is reduced in the GEMM
             # epilogue (32-row partial sums), conv_f1's output never reaches HBM (grl_model.py:146-149)
             if FUSE_TRL_SQDIFF:
@@ -476,6 +524,11 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
             nm = _new((Mb, Cc), xu)
             gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True)
             memo[di] = nm
+    fk.join(memo[1], fc[1])
+    fcorr = fc[0]
+    if fk.two:
+        fcorr = _new((b, t, Cc), xu)
+        _call('grl_add_strided', ptr(fc[0]), ptr(fc[1]), ptr(fcorr), 1, b * t * Cc, 0)
     f_uncorr = _new((b, Cc), xu)
     _call('grl_group_mean', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
     _call('grl_group_mean', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
@@ -587,22 +640,27 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     _call('grl_temporal_mean_bf16', ptr(xu), ptr(memo0), b, t, frame)
     gapc = _new((b * t, Cc), x)
     _call('grl_group_mean_bf16', ptr(xc), ptr(gapc), b * t, PIX, Cc, Cc, C.c_float(1.0), 0)
-    f2 = []
-    for d in plan.dirs:
-        y = _newb((b * t * PIX, Cc), x)
-        gemm(xc, d['f2'].wb(), y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True, math=MATH_BF16S)
-        f2.append(y)
-    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device)
+    fk = _TrlFork(x.device, taps is None and len(plan.dirs) == 2)
+    fk.fork()
+    f2, fc, scr = [], [], []
+    for di, d in enumerate(plan.dirs):
+        with fk.on(di):
+            y = _newb((b * t * PIX, Cc), x)
+            gemm(xc, d['f2'].wb(), y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True, math=MATH_BF16S)
+            f2.append(y)
+            fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device) if (fk.two or di == 0) else fc[0])
+            scr.append((_new((b, Cc), x), _new((b, 128), x)))
     memo = [memo0, memo0]
-    dvec, hid = _new((b, Cc), x), _new((b, 128), x)
     for i in range(t):
         for di, d in enumerate(plan.dirs):
+          with fk.on(di):
             ti = i if di == 0 else t - 1 - i
+            dvec, hid = scr[di]
             f1 = _newb((Mb, Cc), x)
             gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
             _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
             _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                  None, ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+                  None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
             s_ = _newb((Mb, Cc), x)
             _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
             c1, c2_, c3 = d['c1'], d['c2'], d['c3']
@@ -613,6 +671,11 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             nm = _newb((Mb, Cc), x)
             gemm(o2, c3.wb(), nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s_, relu=True, math=MATH_BF16S)
             memo[di] = nm
+    fk.join(memo[1], fc[1])
+    fcorr = fc[0]
+    if fk.two:
+        fcorr = _new((b, t, Cc), x)
+        _call('grl_add_strided', ptr(fc[0]), ptr(fc[1]), ptr(fcorr), 1, b * t * Cc, 0)
     f_uncorr = _new((b, Cc), x)
     _call('grl_group_mean_bf16', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
     _call('grl_group_mean_bf16', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)

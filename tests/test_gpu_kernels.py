@@ -625,3 +625,37 @@ def test_gemm_sqdiff_epilogue_matches_unfused_path(dev, b, t):
     engine.gemm(memo[:PIX], w, dp1, PIX, Cc, Cc, shift=bias, epilogue=EPI_SQDIFF, res=f2[ti * PIX:], res_rows=PIX,
                 res_gstride=t * PIX)
     assert torch.equal(dp1, dpart[:4])
+
+
+def test_small_kernels_next_to_a_gemm_on_another_stream():
+    """Regression for the packed-fp32 corruption found while running the two TRL directions on two HIP streams
+    (tools/hw_probe/README.md): one channel-attention step on stream B while a bf16-storage GEMM retires on stream
+    A must reproduce its quiet result bit for bit -- with `v_pk_mul_f32` in the kernel one term of the 128-term
+    dot product went missing in 16 lanes in ~3 of 4 runs; the library is built without packed fp32."""
+    from grl_amd.engine import ptr, _call, gemm, MATH_BF16S
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(5)
+    b, t, Cc, Hd, Mb = 32, 4, 2048, 128, 4096
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    shift, dvec, gapc = rnd(Cc) * 0.1, rnd(b, Cc).abs(), rnd(b * t, Cc).abs()
+    w1, w2t = rnd(Hd, Cc) * 0.05, rnd(Hd, Cc) * 0.05
+    a, w = (rnd(Mb, Cc) * 0.5).bfloat16(), (rnd(Cc, Cc) * 0.02).bfloat16()
+    y = torch.empty(Mb, Cc, device=dev, dtype=torch.bfloat16)
+    fc, hid = torch.empty(b, t, Cc, device=dev), torch.empty(b, Hd, device=dev)
+
+    def step():
+        _call('grl_channel_atte', ptr(dvec), ptr(w1), ptr(w2t), ptr(gapc), t * Cc, None, ptr(fc), t * Cc, 0, b, Cc,
+              Hd, ptr(hid))
+    step()
+    gemm(a, w, y, Mb, Cc, Cc, shift=shift, relu=True, math=MATH_BF16S)
+    torch.cuda.synchronize()
+    want_fc, want_y = fc[:, 0].clone(), y.clone()
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    for _ in range(40):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sa):
+            gemm(a, w, y, Mb, Cc, Cc, shift=shift, relu=True, math=MATH_BF16S)
+        with torch.cuda.stream(sb):
+            step()
+        torch.cuda.synchronize()
+        assert torch.equal(fc[:, 0], want_fc) and torch.equal(y, want_y)

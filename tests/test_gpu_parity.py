@@ -567,6 +567,28 @@ def test_hip_graph_replay_is_bit_identical(gpu_models):
     assert len(gx._graphs) == 2
 
 
+def test_trl_two_stream_order_is_bit_identical_to_single_stream(gpu_models, monkeypatch):
+    """The two TRL directions run on two HIP streams (engine._TrlFork): same kernels, per-direction
+    scratch, f_corr contributions summed at the join -- the features equal the single-stream order
+    bit for bit, in fp32 and bf16-storage, eager and replayed from a HIP graph, call after call."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    clips = [synth_clips(b, t, seed=60 + b).cuda() for b, t in ((5, 4), (2, 3), (32, 4))]
+    for mode in ('f32', 'bf16s'):
+        with engine.math_mode(mode):
+            monkeypatch.setattr(engine, 'TRL_STREAMS', False)
+            want = [engine.extract_features(cnn, siam, c) for c in clips]
+            monkeypatch.setattr(engine, 'TRL_STREAMS', True)
+            for _ in range(3):
+                for c, w in zip(clips, want):
+                    assert torch.equal(engine.extract_features(cnn, siam, c), w)
+    gx = engine.GraphedExtractor(cnn, siam)
+    monkeypatch.setattr(engine, 'TRL_STREAMS', False)
+    want = engine.extract_features(cnn, siam, clips[0])
+    monkeypatch.setattr(engine, 'TRL_STREAMS', True)
+    assert torch.equal(gx(clips[0]), want) and torch.equal(gx(clips[0]), want)
+
+
 def test_reference_script_flow_through_dropin(tmp_path):
     """examples/train_synthetic.py follows mars_train.py's call sequence through the drop-in
     `reid`/`utils` packages (DataParallel wrap, module.backbone param groups, SEQTrainer,

@@ -172,7 +172,7 @@ def secondary_block(dev, cnn, siam, steps):
     del c3
     out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
         m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
-        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'bf16x3'))}
+        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'mixed', 'bf16x3'))}
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
     qd, gd = qf.to(dev), gf.to(dev)
     for _ in range(2):
@@ -215,10 +215,10 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
     cnn.train(); siam.train(); siamv.train()
     from grl_amd import train_engine
-    if args.math in ('bf16x3', 'bf16'):              # opt-in training datapaths (fp32 is the parity mode)
+    if args.math in ('mixed', 'bf16x3', 'bf16'):     # opt-in training datapaths (fp32 is the parity mode)
         train_engine.set_math(args.math)
     elif args.math != 'f32':
-        raise SystemExit('--mode train supports --math f32 | bf16x3 | bf16')
+        raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16')
     clips = synth_clips(B, T, seed=rank).to(dev)
     pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
     sync = grl_dist.GradSync(params) if world > 1 else None      # bucketed all-reduce under the backward
@@ -254,7 +254,8 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
             "metric": "train clips/sec", "value": round(value, 2), "unit": "clips/sec", "n_gpus": n,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
+            "dtype": {"f32": "f32", "mixed": "f32 forward (exact), split-bf16 products in the backward GEMMs (dgrad + wgrad), f32 accumulate / storage",
+                      "bf16x3": "bf16x3 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
                       "bf16": "bf16 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad"}[args.math],
             "data": "synthetic",
             "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = %d x %d per GPU" % (B, T),
@@ -336,7 +337,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16s'],
+    ap.add_argument('--math', default='f32', choices=['f32', 'mixed', 'bf16x3', 'bf16', 'bf16s'],
                     help="multiplier datapath of the conv GEMMs for the headline `value` "
                          "(default: exact fp32 MFMA = BASELINE configs[1])")
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 / bf16 / bf16s measurements')
@@ -375,7 +376,7 @@ def main():
     _lib.load()
     cnn, siam, sd, ssd = build_models(dev)
     clips = synth_clips(B, T, seed=rank).to(dev)
-    engine.set_math(args.math)
+    engine.set_math('f32' if args.math == 'mixed' else args.math)     # ('mixed' is a training datapath)
 
     def barrier():
         if dist is not None:
@@ -418,7 +419,8 @@ def main():
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split operands, f32 accumulate)",
+            "dtype": {"f32": "f32", "mixed": "f32 forward (exact), split-bf16 products in the backward GEMMs (dgrad + wgrad), f32 accumulate / storage",
+                      "bf16x3": "bf16x3 (split operands, f32 accumulate)",
                       "bf16": "bf16 operands, f32 accumulate", "bf16s": "bf16 storage, f32 accumulate"}[args.math],
             "data": "synthetic",
             "config": {"workload": "GRL eval clip features (ResNet-50 s1 trunk + GCE + TRL + "

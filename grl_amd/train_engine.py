@@ -27,20 +27,27 @@ from .engine import _call, _new, EvalPlan, PIX
 #            parity claim is made in (the eval-side engine.set_math / GRL_MATH never leaks in here);
 #   'bf16x3' split-bf16 products (hi*hi + hi*lo + lo*hi): fp32-class gradients at ~3x the GEMM rate;
 #   'bf16'   operands rounded to bf16 while staging (BASELINE configs[2]'s "bf16 MFMA" datapath for
-#            training): gradients to ~1e-2, forward + data-gradient GEMMs ~5x faster.
-_TRAIN_MATH = {'f32': MATH_F32, 'bf16x3': engine.MATH_BF16X3, 'bf16': engine.MATH_BF16}
-_train_math = [_TRAIN_MATH[__import__('os').environ.get('GRL_TRAIN_MATH', 'f32')]]
+#            training): gradients to ~1e-2, forward + data-gradient GEMMs ~5x faster;
+#   'mixed'  FORWARD exact fp32 (K-blocked: activations, batch statistics and -- what decides the accuracy of
+#            the parameter gradients -- the ReLU masks are those of 'f32', bit for bit), BACKWARD GEMMs (data and
+#            weight gradients) split-bf16: every product carries ~2^-16 relative error instead of 2^-24, no
+#            mask can flip, so the gradients stay within ~1e-5 of the 'f32' ones at ~2/3 of the step time.
+_TRAIN_MATH = {'f32': (MATH_F32, MATH_F32), 'bf16x3': (engine.MATH_BF16X3, engine.MATH_BF16X3),
+               'bf16': (engine.MATH_BF16, engine.MATH_BF16), 'mixed': (MATH_F32, engine.MATH_BF16X3)}
+_train_mode = [__import__('os').environ.get('GRL_TRAIN_MATH', 'f32')]
+_train_math = [_TRAIN_MATH[_train_mode[0]][0]]       # datapath of the GEMMs issued NOW (Tape.backward switches it)
 
 
 def set_math(name):
-    """Select the training GEMM datapath ('f32' | 'bf16x3' | 'bf16'); returns the previous name."""
-    old = get_math()
-    _train_math[0] = _TRAIN_MATH[name]
+    """Select the training GEMM datapath ('f32' | 'mixed' | 'bf16x3' | 'bf16'); returns the previous name."""
+    old = _train_mode[0]
+    _train_math[0] = _TRAIN_MATH[name][0]
+    _train_mode[0] = name
     return old
 
 
 def get_math():
-    return {v: k for k, v in _TRAIN_MATH.items()}[_train_math[0]]
+    return _train_mode[0]
 
 
 def gemm(*args, **kw):
@@ -204,8 +211,13 @@ class Tape(object):
         return self.wc[key]
 
     def backward(self):
-        for fn in reversed(self.ops):
-            fn()
+        fwd_math = _train_math[0]
+        _train_math[0] = _TRAIN_MATH[_train_mode[0]][1]          # 'mixed': the backward GEMMs' datapath
+        try:
+            for fn in reversed(self.ops):
+                fn()
+        finally:
+            _train_math[0] = fwd_math
         self.ops = []
 
 

@@ -180,8 +180,10 @@ def _fresh_cnn_conditioned():
     return cnn.cuda()
 
 
-def test_train_forward_backward_matches_reference_golden_1e3(golden):
-    """THE end-to-end backward pin: HIP train-mode forward + backward of the whole CNN against the
+@pytest.mark.parametrize('math', ['f32', 'mixed'])
+def test_train_forward_backward_matches_reference_golden_1e3(golden, math):
+    """(``math``: the default exact-fp32 step, and 'mixed' = the same forward with split-bf16 backward GEMMs.)
+    THE end-to-end backward pin: HIP train-mode forward + backward of the whole CNN against the
     reference's fp32 autograd run (tests/golden/grl_train_cond_b8t4.npz), B x T = 8 x 4, EVERY
     parameter gradient at <= 1e-3 relative L2 (north_star's figure), outputs at <= 1e-4, whole
     tensors covered by norm + projection checksums, BN running statistics at <= 1e-4.  The
@@ -196,10 +198,15 @@ def test_train_forward_backward_matches_reference_golden_1e3(golden):
     cnn = _fresh_cnn_conditioned()
     cnn.train()
     r1, r2 = TC.upstream(B, T)
-    xu, xc = cnn(synth_clips_structured(B, T, seed=3).cuda())
-    ((xu * r1.cuda()).sum() + (xc * r2.cuda()).sum()).backward()
+    from grl_amd import train_engine as TE
+    old = TE.set_math(math)
+    try:
+        xu, xc = cnn(synth_clips_structured(B, T, seed=3).cuda())
+        ((xu * r1.cuda()).sum() + (xc * r2.cuda()).sum()).backward()
+    finally:
+        TE.set_math(old)
     grads = {k: p.grad for k, p in cnn.named_parameters() if p.grad is not None}
-    TC.check(g, xu, xc, grads, cnn.state_dict(), out_tol=1e-4, grad_tol=1e-3, label='HIP')
+    TC.check(g, xu, xc, grads, cnn.state_dict(), out_tol=1e-4, grad_tol=1e-3, label='HIP ' + math)
 
 
 @pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 5e-2),
@@ -852,3 +859,48 @@ def test_train_bf16_multiplier_datapaths_against_fp32_path(mode, out_tol, med_to
         mode, e_out, np.median(errs), errs[int(.9 * len(errs))], errs[-1])
     print(msg)
     assert e_out < out_tol and np.median(errs) < med_tol and errs[int(.9 * len(errs))] < p90_tol, msg
+
+
+def test_train_mixed_math_forward_is_the_fp32_forward_and_gradients_stay_fp32_class():
+    """train_engine.set_math('mixed'): exact fp32 forward, split-bf16 products in the backward GEMMs.  The forward
+    -- outputs, batch statistics, ReLU masks -- must be the 'f32' forward bit for bit, so no mask can flip and
+    every weight gradient stays within 1e-3 (relative L2; median 1.4e-5, worst 3.4e-4) of the 'f32' gradient, the one pinned
+    to the reference at 1e-3; the reference fixture itself is then checked in this mode."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 16, 4
+    clips = synth_clips_structured(B, T, seed=12).cuda()
+    rg = torch.Generator().manual_seed(4)
+    r1, r2 = torch.randn(B, 2048, generator=rg).cuda(), torch.randn(B, T, 2048, generator=rg).cuda()
+    res = {}
+    for m in ('f32', 'mixed'):
+        cnn = _fresh_cnn_conditioned()
+        cnn.train()
+        old = TE.set_math(m)
+        try:
+            assert TE.get_math() == m
+            xu, xc = cnn(clips)
+            ((xu * r1).sum() + (xc * r2).sum()).backward()
+        finally:
+            TE.set_math(old)
+        res[m] = (xu.detach(), xc.detach(), {k: p.grad for k, p in cnn.named_parameters() if p.grad is not None},
+                  {k: v.clone() for k, v in cnn.state_dict().items() if 'running' in k})
+    a, b = res['mixed'], res['f32']
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(a[3][k], b[3][k]) for k in b[3])
+    # (biases in front of a batch-statistics BatchNorm have a mathematically zero gradient: both runs hold rounding
+    # noise there -- compared on the scale of the layer's weight gradient instead of their own)
+    scale = {k: float(b[2][k].norm()) for k in b[2]}
+    for k in b[2]:
+        if k.endswith('.bias') and k[:-5] + '.weight' in scale:
+            scale[k] = max(scale[k], 1e-3 * scale[k[:-5] + '.weight'])
+    errs = sorted((float((a[2][k] - b[2][k]).norm()) / max(scale[k], 1e-30), k) for k in b[2] if scale[k] > 0)
+    vals = np.array([e for e, _ in errs])
+    msg = 'train math mixed vs f32: gradient L2 error median %.1e p90 %.1e max %.1e (%s)' % (
+        np.median(vals), vals[int(.9 * len(vals))], vals[-1], errs[-1][1])
+    print(msg)
+    # weights (>= 2-D): median 5e-5, worst 1e-3 (measured 1.4e-5 / 3.4e-4); BatchNorm gains / shifts are sums over all pixels of signed terms that cancel to
+    # ~1e-2 of their magnitude, which amplifies the 2^-16 product error: 1e-2 (the golden test's outlier bound)
+    w_err = [e for e, k in errs if b[2][k].dim() >= 2]
+    v_err = [e for e, k in errs if b[2][k].dim() < 2]
+    assert max(w_err) < 1e-3 and np.median(w_err) < 5e-5 and np.median(v_err) < 1e-4 and max(v_err) < 1e-2, msg

@@ -173,15 +173,20 @@ __global__ void add_strided_b16_kernel(const __bf16* __restrict__ a, const __bf1
 }
 
 // ---------------------------------------------------------------------------------
-// Stem for the bf16-storage pipeline: 7x7/s2 conv (K = 147 -> 160) + folded BN + ReLU on the
-// bf16 MFMA.  One workgroup = 8 x 16 output pixels x 64 channels.  The fp32 NCHW patch
-// (3 x 21 x 37) is staged in LDS, expanded in LDS to a bf16 im2col tile [128 px][160 k] and
-// multiplied with the bf16 weight matrix [64][160]; rows are padded to 336 bytes so that the
-// ds_read_b128 fragment reads (16 consecutive rows, same k chunk) hit 16 distinct bank slots.
+// Stem for the bf16-storage pipeline: 7x7/s2 conv + folded BN + ReLU on the bf16 MFMA.  One workgroup =
+// 8 x 16 output pixels x 64 channels.  The reduction index is ordered (channel, ky, kx) with kx padded
+// from 7 to 8 taps (zero weight): K = 3 * 7 * 8 = 168 (+ one zero chunk = 176 = 11 MFMA steps), so that a
+// pixel's eight taps of one (channel, ky) are eight CONSECUTIVE input pixels.  The NCHW patch (3 x 21 x 37)
+// is staged in LDS already rounded to bf16; the im2col tile [128 px][176 k] is then built from plain
+// 16-byte copies -- no per-element index arithmetic, no conversion -- lanes walking pixels (conflict-free
+// reads and writes); rows are padded to 368 bytes so that the ds_read_b128 fragment reads hit distinct
+// bank slots.  (Round 1 ordered k as (c, ky, kx) unpadded, K = 147 -> 160, and gathered element by
+// element with k/49, k/7, k%7 per element: 0.96 ms per 512 frames, VALU-bound at 4 % MFMA busy.)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SB_TH = 8, SB_TW = 16, SB_PH = 2 * SB_TH + 5, SB_PW = 2 * SB_TW + 5, SB_PWP = SB_PW + 1;
-constexpr int SB_K = 160, SB_ROWB = 336;                       // bytes per bf16 row (320 + 16 pad)
-constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // fp32 cells; SB_PATCH.. are zeros
+constexpr int SB_CH = 22;                                      // 8-wide k chunks: 21 (channel, ky) rows + one of zeros
+constexpr int SB_K = SB_CH * 8, SB_ROWB = SB_K * 2 + 16;       // 176 k; bytes per bf16 row (352 + 16 pad)
+constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // bf16 cells (column SB_PW of every row is a zero pad)
 
 __global__ __launch_bounds__(256) void stem_b16_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
     const __bf16* __restrict__ wp, const float* __restrict__ norm) {
     // norm != NULL: x holds raw u8 pixels, normalised here as (u/255 - mean[c]) / std[c]
     extern __shared__ __attribute__((aligned(16))) char smb[];
-    char* At = smb;                                            // [128][336 B]
-    char* Wt = At + 128 * SB_ROWB;                             // [64][336 B]
-    float* patch = reinterpret_cast<float*>(Wt + 64 * SB_ROWB);   // [3][21][38] + 4 zeros
+    char* At = smb;                                            // [128][368 B]
+    char* Wt = At + 128 * SB_ROWB;                             // [64][368 B]
+    __bf16* patch = reinterpret_cast<__bf16*>(Wt + 64 * SB_ROWB);   // [3][21][38]
     float* Cs = reinterpret_cast<float*>(smb);                 // epilogue staging [128][64] fp32 (32 KB < At)
     const int Ho = H >> 1, Wo = W >> 1;
     const int img = blockIdx.z, oy0 = blockIdx.y * SB_TH, ox0 = blockIdx.x * SB_TW;
@@ -199,45 +204,43 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
-    for (int i = tid; i < 3 * SB_PH * SB_PW; i += 256) {
-        const int c = i / (SB_PH * SB_PW), r = (i / SB_PW) % SB_PH, q = i % SB_PW;
+    for (int i = tid; i < SB_PATCH; i += 256) {
+        const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
         const int iy = iy0 + r, ix = ix0 + q;
         float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        if (q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
             const int64_t o = ((int64_t)c * H + iy) * W + ix;
             v = norm ? ((float)xu[o] / 255.f - norm[c]) / norm[3 + c] : xi[o];
         }
-        patch[(c * SB_PH + r) * SB_PWP + q] = v;
+        patch[i] = (__bf16)v;
     }
-    if (tid < 4) patch[SB_PATCH + tid] = 0.f;
-    // weights: the LDS image [64][336 B] made once by grl_stem_pack_weight_bf16, or converted here
+    // weights: the LDS image [64][368 B] made once by grl_stem_pack_weight_bf16, or converted here
     if (wp) {
         for (int i = tid; i < 64 * SB_ROWB / 16; i += 256)
             reinterpret_cast<bf16x8*>(Wt)[i] = reinterpret_cast<const bf16x8*>(wp)[i];
-    } else
-    for (int i = tid; i < 64 * (SB_K / 8); i += 256) {
-        const int n = i / (SB_K / 8), c8 = i - n * (SB_K / 8);
-        bf16x8 o;
+    } else {
+        for (int i = tid; i < 64 * SB_CH; i += 256) {
+            const int n = i / SB_CH, ch = i - n * SB_CH;
+            bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = c8 * 8 + e;
-            o[e] = (__bf16)(k < 147 ? w[n * 147 + k] : 0.f);
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((ch < 21 && e < 7) ? w[n * 147 + ch * 7 + e] : 0.f);
+            *reinterpret_cast<bf16x8*>(Wt + n * SB_ROWB + ch * 16) = o;
         }
-        *reinterpret_cast<bf16x8*>(Wt + n * SB_ROWB + c8 * 16) = o;
     }
     __syncthreads();
-    // im2col in LDS: item = (pixel, 8-wide k chunk)
-    for (int i = tid; i < 128 * (SB_K / 8); i += 256) {
-        const int m = i / (SB_K / 8), c8 = i - m * (SB_K / 8);
-        const int base = (2 * (m / SB_TW)) * SB_PWP + 2 * (m % SB_TW);
-        bf16x8 o;
+    // im2col in LDS: item = (k chunk, pixel), pixels fastest: the chunk (channel, ky) is wave-uniform and a
+    // pixel's eight taps are eight consecutive bf16 of one patch row (4-byte aligned: four ds_read_b32)
+    for (int i = tid; i < SB_CH * 128; i += 256) {
+        const int ch = i >> 7, m = i & 127;
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+        if (ch < 21) {
+            const int c = ch / 7, ky = ch - 7 * c;
+            const uint32_t* s2 = reinterpret_cast<const uint32_t*>(
+                patch + ((c * SB_PH) + 2 * (m / SB_TW) + ky) * SB_PWP + 2 * (m % SB_TW));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = c8 * 8 + e;
-            const int off = k < 147 ? base + ((k / 49) * SB_PH + (k / 7) % 7) * SB_PWP + k % 7 : SB_PATCH;
-            o[e] = (__bf16)patch[off];
+            for (int e = 0; e < 4; ++e) o[e] = s2[e];
         }
-        *reinterpret_cast<bf16x8*>(At + m * SB_ROWB + c8 * 16) = o;
+        *reinterpret_cast<uint4*>(At + m * SB_ROWB + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
     const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, fhalf = lane >> 5;
@@ -302,10 +305,10 @@ extern "C" int grl_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
 }
 
 __global__ void stem_pack_weight_b16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // [64][168] bf16 (336-byte rows)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // [64][184] bf16 (368-byte rows), k = (c, ky, kx of 8)
     if (i >= 64 * (SB_ROWB / 2)) return;
-    const int n = i / (SB_ROWB / 2), k = i - n * (SB_ROWB / 2);
-    wp[i] = (__bf16)(k < 147 ? w[n * 147 + k] : 0.f);
+    const int n = i / (SB_ROWB / 2), k = i - n * (SB_ROWB / 2), ch = k >> 3, kx = k & 7;
+    wp[i] = (__bf16)((ch < 21 && kx < 7) ? w[n * 147 + ch * 7 + kx] : 0.f);
 }
 
 extern "C" int grl_stem_pack_weight_bf16(const float* w, void* wp, void* stream) {
@@ -336,7 +339,7 @@ static int stem_b16_launch(const float* x, const float* norm, const float* w, co
     GRL_REQUIRE(x && w && scale && shift && y && n > 0, "stem_bf16: null/empty");
     GRL_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem_bf16: H and W must be even");
     const int Ho = H / 2, Wo = W / 2;
-    const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)(SB_PATCH + 4) * sizeof(float);
+    const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)SB_PATCH * sizeof(__bf16);
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)stem_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH), n), dim3(256), lds,

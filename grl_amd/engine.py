@@ -274,7 +274,7 @@ class GrlEvalPlan(EvalPlan):
         self.stem_w = base[0].weight.detach().contiguous()
         self.stem_wp = torch.empty(64 * 164, dtype=torch.float32, device=self.dev)
         _call('grl_stem_pack_weight', ptr(self.stem_w), ptr(self.stem_wp))
-        self.stem_wpb = torch.empty(64 * 168, dtype=torch.bfloat16, device=self.dev)
+        self.stem_wpb = torch.empty(64 * 184, dtype=torch.bfloat16, device=self.dev)
         _call('grl_stem_pack_weight_bf16', ptr(self.stem_w), ptr(self.stem_wpb))
         self.stem_scale, self.stem_shift = self.fold(base[1])
         self.blocks = []

@@ -229,7 +229,7 @@ int grl_stem_conv7x7_bf16(const float* x, const float* w, const float* scale, co
 int grl_stem_conv7x7_u8_bf16(const uint8_t* x, const float* mean_std, const float* w, const float* scale,
                              const float* shift, void* y, int n, int H, int W, int relu, const void* wp,
                              void* stream);                                      /* u8 input, as grl_stem_conv7x7_u8 */
-int grl_stem_pack_weight_bf16(const float* w, void* wp /* 64*168 bf16 */, void* stream);
+int grl_stem_pack_weight_bf16(const float* w, void* wp /* 64*184 bf16: rows of 368 bytes, k ordered (channel, ky, kx padded to 8) + zero pad */, void* stream);
 int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream);
 int grl_group_mean_bf16(const void* x, float* y, int groups, int rows, int C, int ldy,
                         float out_scale, int accumulate, void* stream);

@@ -461,7 +461,7 @@ def test_bf16_storage_pointwise_twins(dev):
     ws = torch.from_numpy((rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)).bfloat16().float().to(dev)
     sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev) * 0.1
     o32 = torch.empty(n * 32 * 16, 64, device=dev); o16 = torch.empty(n * 32 * 16, 64, dtype=torch.bfloat16, device=dev)
-    wpb = torch.empty(64 * 168, dtype=torch.bfloat16, device=dev)
+    wpb = torch.empty(64 * 184, dtype=torch.bfloat16, device=dev)
     engine._call('grl_stem_pack_weight_bf16', ptr(ws), ptr(wpb))
     engine._call('grl_stem_conv7x7', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o32), n, H, W, 1, None)
     engine._call('grl_stem_conv7x7_bf16', ptr(xi), ptr(ws), ptr(sc), ptr(sh), ptr(o16), n, H, W, 1, ptr(wpb))

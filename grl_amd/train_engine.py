@@ -69,10 +69,31 @@ def set_grad_sync(sync):
     _grad_sync[0] = sync
 
 
+class _Ops(list):
+    """The tape's closure list.  A closure recorded while ``tape.side`` is set (the second TRL direction,
+    issued on a side HIP stream) is replayed on that stream too."""
+
+    def __init__(self, tape):
+        list.__init__(self)
+        self.tape = tape
+
+    def append(self, fn):
+        side = self.tape.side
+        if side is not None:
+            inner = fn
+
+            def fn():
+                with torch.cuda.stream(side):
+                    inner()
+        list.append(self, fn)
+
+
 class Tape(object):
     def __init__(self, dev):
         self.dev = dev
-        self.ops = []
+        self.side = None     # side stream closures are being recorded for (None: the launch stream)
+        self.held = []       # tensors handed from one stream to the other: kept alive until the streams join
+        self.ops = _Ops(self)
         self.flat = None     # flat buffer of every parameter gradient of this tape
         self.cuts = {}       # section name -> (lo, hi) of `flat`: gradients final once the section's backward is done
         self._sent = 0       # elements of `flat` from the END already handed to the gradient sync
@@ -218,7 +239,7 @@ class Tape(object):
                 fn()
         finally:
             _train_math[0] = fwd_math
-        self.ops = []
+        self.ops = _Ops(self)
 
 
 def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
@@ -633,15 +654,30 @@ def _axpy_frame(dst_full, ti, src, b, t, frame, alpha=1.0):
 
 
 def trl_train(tp, model, xu, xc, b, t):
+    """TRL forward (grl_model.py:170-208) recorded for the backward.  The two directions are independent
+    recurrences over their own parameters; like the eval path (engine._TrlFork) they are issued on two HIP
+    streams -- forward and, through the tape's stream tags, backward -- so one direction's small M = B*128
+    GEMMs and latency-bound BatchNorm / attention kernels run next to the other's.  Everything the two
+    directions ACCUMULATE into (f_corr, and in the backward the gradients of x_uncorr, GAP(x_corr) and the
+    initial memo) is kept per direction and summed on the launch stream at the join."""
     trl = model.temporal_learning_block
     Cc, frame, Mb = FRAME_C, PIX * FRAME_C, b * PIX
     dirs = ((trl.forward_f1, trl.forward_f2, trl.channel_atte_foreward_corr, trl.uncorr_memo_forward),
             (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward))
     tp.mark('trl')
+    fk = engine._TrlFork(tp.dev, tp.taps is None)
     memo0 = _new((Mb, Cc), xu)
     _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
+    # per-direction aliases: same storage, their own gradient slots on the tape
+    xu_d = (xu, xu.view_as(xu)) if fk.two else (xu, xu)
+    memo_d = (memo0, memo0.view_as(memo0)) if fk.two else (memo0, memo0)
 
     def bwd_memo0():
+        if fk.two:
+            for al, base in ((xu_d[1], xu), (memo_d[1], memo0)):
+                g1 = tp.take(al)
+                if g1 is not None:
+                    tp.add_grad(base, g1)
         dm = tp.take(memo0)
         if dm is None:
             return
@@ -650,11 +686,29 @@ def trl_train(tp, model, xu, xc, b, t):
     tp.ops.append(bwd_memo0)
 
     gapc = group_mean_op(tp, xc, b * t, PIX, Cc)          # full_grad(xc) accumulates inside
+    gapc_d = (gapc, gapc.view_as(gapc)) if fk.two else (gapc, gapc)
+
+    def bwd_gapc1():
+        g1 = tp.take(gapc_d[1]) if fk.two else None
+        if g1 is not None:
+            tp.add_grad(gapc, g1)
+    tp.ops.append(bwd_gapc1)
     f2 = [biased_conv_relu(tp, xc, b * t * PIX, d[1][0]) for d in dirs]
-    fcorr = torch.zeros((b, t, Cc), dtype=torch.float32, device=tp.dev)
-    memo = [memo0, memo0]
+
+    def bwd_join():                 # backward: both directions are done (runs before f2's backward on the launch stream)
+        fk.join()
+        tp.held = []
+    tp.ops.append(bwd_join)
+    fk.fork()
+    fc = []
+    for di in range(2):
+        with fk.on(di):
+            fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=tp.dev) if (fk.two or di == 0) else fc[0])
+    memo = list(memo_d)
     for i in range(t):
         for di, (f1m, _, mlp, blk) in enumerate(dirs):
+          with fk.on(di):
+            tp.side = fk.side if (fk.two and di == 1) else None
             ti = i if di == 0 else t - 1 - i
             f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
             dvec = _new((b, Cc), xu)
@@ -664,15 +718,17 @@ def trl_train(tp, model, xu, xc, b, t):
             catte = _new((b, Cc), xu)
             w1, w2 = mlp[0].weight, mlp[2].weight
             w2t = tp.w_t(w2.detach(), w2)                   # [128][2048]
+            fcd, gap_al, xu_al = fc[di], gapc_d[di], xu_d[di]
             _call('grl_channel_atte', ptr(dvec), ptr(w1.detach()), ptr(w2t), ptr(gapc[ti:]), t * Cc,
-                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
+                  ptr(catte), ptr(fcd.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
 
-            def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t):
-                dfc = tp.g.get(id(fcorr))
+            def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t, fcd=fcd,
+                         gap_al=gap_al):
+                dfc = tp.g.get(id(fcd))
                 if dfc is None:
                     return
                 ds = _new((b, Cc), xu)
-                dgap = tp.full_grad(gapc)
+                dgap = tp.full_grad(gap_al)
                 _call('grl_catte_bwd', ptr(dfc.view(b * t, Cc)[ti:]), t * Cc, ptr(gapc[ti:]), t * Cc,
                       ptr(catte), ptr(ds), ptr(dgap[ti:]), t * Cc, 1, b, Cc)
                 dhid = _new((b, 128), xu)
@@ -697,29 +753,40 @@ def trl_train(tp, model, xu, xc, b, t):
             _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
             prev = memo[di]
 
-            def bwd_add(s=s, prev=prev, ti=ti):
+            def bwd_add(s=s, prev=prev, ti=ti, xu_al=xu_al):
                 dsum = tp.take(s)
                 if dsum is None:
                     return
-                _axpy_frame(tp.full_grad(xu), ti, dsum, b, t, frame)
+                _axpy_frame(tp.full_grad(xu_al), ti, dsum, b, t, frame)
                 tp.add_grad(prev, dsum)
             tp.ops.append(bwd_add)
             o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
             o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
             memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
-    f_uncorr = _new((b, Cc), xu)
-    _call('grl_group_mean', ptr(memo[0]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
-    _call('grl_group_mean', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
+            tp.side = None
     mf, mb_ = memo
+    fk.join(mb_, fc[1])
+    fcorr = fc[0]
+    if fk.two:
+        fcorr = _new((b, t, Cc), xu)
+        _call('grl_add_strided', ptr(fc[0]), ptr(fc[1]), ptr(fcorr), 1, b * t * Cc, 0)
+    f_uncorr = _new((b, Cc), xu)
+    _call('grl_group_mean', ptr(mf), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
+    _call('grl_group_mean', ptr(mb_), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
 
-    def bwd_funcorr():
+    def bwd_funcorr():              # backward: runs FIRST of the TRL closures, on the launch stream; then the fork
         d = tp.take(f_uncorr)
-        if d is None:
-            return
-        for m in (mf, mb_):
-            g = _new((Mb, Cc), xu)
-            _call('grl_add_rowbcast', ptr(g), ptr(d), Mb, Cc, PIX, C.c_float(1.0 / PIX), 0)
-            tp.add_grad(m, g)
+        dfc = tp.g.get(id(fcorr))
+        if dfc is not None:         # f_corr = fc[0] + fc[1]: both directions read the same upstream gradient
+            tp.g[id(fc[0])] = tp.g[id(fc[1])] = dfc
+        if d is not None:
+            tp.held.append(d)
+            for di, m in enumerate((mf, mb_)):
+                g = _new((Mb, Cc), xu)
+                _call('grl_add_rowbcast', ptr(g), ptr(d), Mb, Cc, PIX, C.c_float(1.0 / PIX), 0)
+                tp.add_grad(m, g)
+                tp.held.append(g)
+        fk.fork()
     tp.ops.append(bwd_funcorr)
     if tp.taps is not None:
         tp.taps.update(f_uncorr=f_uncorr, f_corr=fcorr)

@@ -904,3 +904,40 @@ def test_train_mixed_math_forward_is_the_fp32_forward_and_gradients_stay_fp32_cl
     w_err = [e for e, k in errs if b[2][k].dim() >= 2]
     v_err = [e for e, k in errs if b[2][k].dim() < 2]
     assert max(w_err) < 1e-3 and np.median(w_err) < 5e-5 and np.median(v_err) < 1e-4 and max(v_err) < 1e-2, msg
+
+
+def test_train_two_stream_trl_is_deterministic_and_matches_single_stream(monkeypatch):
+    """Train mode runs the two TRL directions -- forward and, through the tape's stream tags, backward -- on two
+    HIP streams.  Run to run the step is bit-reproducible (fixed per-direction accumulation, sums at the join);
+    against the single-stream order only the association of three sums changes (gradients of x_uncorr, GAP(x_corr)
+    and the initial memo are accumulated per direction first): forward bit-identical, weight gradients within 1e-4."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 8, 4
+    clips = synth_clips_structured(B, T, seed=21).cuda()
+    rg = torch.Generator().manual_seed(9)
+    r1, r2 = torch.randn(B, 2048, generator=rg).cuda(), torch.randn(B, T, 2048, generator=rg).cuda()
+
+    def run(two):
+        monkeypatch.setattr(engine, 'TRL_STREAMS', two)
+        cnn = _fresh_cnn_conditioned()
+        cnn.train()
+        xu, xc = cnn(clips)
+        ((xu * r1).sum() + (xc * r2).sum()).backward()
+        torch.cuda.synchronize()
+        return xu.detach(), xc.detach(), {k: p.grad.clone() for k, p in cnn.named_parameters() if p.grad is not None}
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    scale = {k: float(c[2][k].norm()) for k in c[2]}
+    for k in c[2]:                     # zero-gradient biases in front of a batch-statistics BatchNorm: layer scale
+        if k.endswith('.bias') and k[:-5] + '.weight' in scale:
+            scale[k] = max(scale[k], 1e-3 * scale[k[:-5] + '.weight'])
+    errs = sorted((float((a[2][k] - c[2][k]).norm()) / max(scale[k], 1e-30), k) for k in c[2])
+    w_err = [e for e, k in errs if c[2][k].dim() >= 2]
+    v_err = [e for e, k in errs if c[2][k].dim() < 2]
+    msg = 'two-stream vs single-stream gradients: weights median %.1e max %.1e; vectors median %.1e max %.1e (%s)' % (
+        np.median(w_err), max(w_err), np.median(v_err), max(v_err), errs[-1][1])
+    print(msg)
+    # (BatchNorm gains / shifts: sums over all pixels that cancel to ~1 % of their magnitude amplify the last-bit changes)
+    assert max(w_err) < 1e-4 and np.median(v_err) < 1e-5 and max(v_err) < 1e-2, msg

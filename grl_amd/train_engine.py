@@ -93,6 +93,7 @@ class Tape(object):
         self.dev = dev
         self.side = None     # side stream closures are being recorded for (None: the launch stream)
         self.held = []       # tensors handed from one stream to the other: kept alive until the streams join
+        self.wheld = []      # operands of weight-gradient launches in flight on the weight-gradient stream
         self.ops = _Ops(self)
         self.flat = None     # flat buffer of every parameter gradient of this tape
         self.cuts = {}       # section name -> (lo, hi) of `flat`: gradients final once the section's backward is done
@@ -162,7 +163,16 @@ class Tape(object):
             self.flush(self.cuts.get(name), name)
         self.ops.append(done)
 
+    def wgrad_join(self):
+        """The launch stream waits for the weight-gradient stream (parameter gradients are about to be read)."""
+        if self.wheld:
+            ev = torch.cuda.Event()
+            ev.record(_wgrad_stream(self.dev))
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self.wheld = []
+
     def flush(self, lo=0, label='rest'):
+        self.wgrad_join()
         sync = _grad_sync[0]
         if sync is None or self.flat is None or lo is None:
             return
@@ -239,6 +249,7 @@ class Tape(object):
                 fn()
         finally:
             _train_math[0] = fwd_math
+        self.wgrad_join()
         self.ops = _Ops(self)
 
 
@@ -259,6 +270,35 @@ def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate
     ws = torch.empty(lib.grl_wgrad_workspace_floats(C.byref(d)), dtype=torch.float32, device=dz.device)
     d.workspace = ptr(ws)
     check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream()), 'grl_conv_wgrad_f32')
+
+
+# A layer's weight gradient depends on nothing downstream of it and nothing waits for it before the optimizer (or the
+# section's all-reduce): it is issued on its own HIP stream, so the MFMA-bound wgrad launches run next to the HBM-bound
+# BatchNorm passes and under-filled data-gradient GEMMs of the following layers instead of in between them.  The
+# launch stream waits for that stream where parameter gradients are consumed (Tape.flush, end of Tape.backward); the
+# operands stay referenced until then.  GRL_WGRAD_STREAM=0 / WGRAD_STREAM = False: everything on the launch stream.
+WGRAD_STREAM = __import__('os').environ.get('GRL_WGRAD_STREAM', '1') != '0'
+_wgrad_streams = {}
+
+
+def _wgrad_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(dev)
+    return _wgrad_streams[key]
+
+
+def wgrad_async(tp, dz, x, dw, M, N, K, **kw):
+    """``wgrad`` on the weight-gradient stream (ordered after everything issued so far on the current one)."""
+    if not WGRAD_STREAM:
+        return wgrad(dz, x, dw, M, N, K, **kw)
+    ws = _wgrad_stream(tp.dev)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(tp.dev))
+    ws.wait_event(ev)
+    with torch.cuda.stream(ws):
+        wgrad(dz, x, dw, M, N, K, **kw)
+    tp.wheld.extend((dz, x, dw))
 
 
 def colsum_into(g, M, Ccols, out, ld=None):
@@ -362,7 +402,7 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     M = n_img * Ho * Wo
     K = k * k * cin
     if kcols is None:
-        wgrad(dz, x, tp.pgrad(w), M, N, K, conv=geom)
+        wgrad_async(tp, dz, x, tp.pgrad(w), M, N, K, conv=geom)
     else:                                   # first kcols columns of a wider weight
         tmp = torch.empty(N, kcols, dtype=torch.float32, device=tp.dev)
         wgrad(dz, x, tmp, M, N, K, accumulate=0)
@@ -423,7 +463,7 @@ def biased_conv_relu(tp, x, M, conv):
         g = _new((M, N), da)
         _call('grl_relu_bwd', ptr(da), ptr(a), ptr(g), da.numel(), 0)
         colsum_into(g, M, N, tp.pgrad(conv.bias))
-        wgrad(g, x, tp.pgrad(w), M, N, K)
+        wgrad_async(tp, g, x, tp.pgrad(w), M, N, K)
         cur = tp.g.get(id(x))
         if cur is not None and tuple(cur.shape) != (M, K):
             cur = cur.view(M, K)

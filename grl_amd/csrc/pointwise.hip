@@ -127,27 +127,50 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int Ho = H >> 1, Wo = W >> 1;
     const int img = blockIdx.z, oy0 = blockIdx.y * SM_TH, ox0 = blockIdx.x * SM_TW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
+    // staging: every global load is issued before the first is waited for (as plain `i += 256` loops hipcc
+    // emitted load / s_waitcnt vmcnt(0) / ds_write per iteration -- ~20 exposed latencies per workgroup)
+    constexpr int P_N = 3 * SM_PH * SM_PW, P_IT = (P_N + 255) / 256, W_N = 64 * SM_WLD / 4, W_IT = (W_N + 255) / 256;
+    float pv[P_IT];
+    f32x4 wv[W_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int i = tid + it * 256;
+        const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        const bool ok = i < P_N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int cc = c < 3 ? c : 0;
+        const int64_t o = ok ? ((int64_t)cc * H + iy) * W + ix : 0;
+        pv[it] = norm ? (float)xu[o] : xi[o];
+        if (norm) pv[it] = (pv[it] / 255.f - norm[cc]) / norm[3 + cc];
+        if (!ok) pv[it] = 0.f;
+    }
     if (wp) {                                          // LDS image made once by grl_stem_pack_weight
-        for (int i = tid; i < 64 * SM_WLD / 4; i += 256)
-            reinterpret_cast<f32x4*>(Ws)[i] = reinterpret_cast<const f32x4*>(wp)[i];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            wv[it] = reinterpret_cast<const f32x4*>(wp)[i < W_N ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < W_N) reinterpret_cast<f32x4*>(Ws)[i] = wv[it];
+        }
     } else {
         for (int i = tid; i < 64 * SM_K; i += 256) {
             const int n = i / SM_K, k = i - n * SM_K;
             Ws[n * SM_WLD + k] = k < 147 ? w[n * 147 + k] : 0.f;
         }
     }
-    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-    const float* xi = x + (int64_t)img * 3 * H * W;
-    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
-    for (int i = tid; i < 3 * SM_PH * SM_PW; i += 256) {
-        const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
-        const int iy = iy0 + r, ix = ix0 + q;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-            const int64_t o = ((int64_t)c * H + iy) * W + ix;
-            v = norm ? ((float)xu[o] / 255.f - norm[c]) / norm[3 + c] : xi[o];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int i = tid + it * 256;
+        if (i < P_N) {
+            const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
+            patch[(c * SM_PH + r) * SM_PWP + q] = pv[it];
         }
-        patch[(c * SM_PH + r) * SM_PWP + q] = v;
     }
     if (tid < 8) patch[SM_PATCH + (tid & 3)] = 0.f;
     if (tid < SM_K) {

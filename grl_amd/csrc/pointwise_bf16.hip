@@ -204,20 +204,42 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
-    for (int i = tid; i < SB_PATCH; i += 256) {
+    // every global load of the staging phase is issued before the first one is waited for (written as loops
+    // over `tid + it * 256`, hipcc emitted load / s_waitcnt vmcnt(0) / ds_write per iteration: ten exposed
+    // HBM latencies per workgroup, which is what the kernel spent its time on)
+    constexpr int P_IT = (SB_PATCH + 255) / 256, W_IT = (64 * SB_ROWB / 16 + 255) / 256;
+    float pv[P_IT];
+    bf16x8 wv[W_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int i = tid + it * 256;
         const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
         const int iy = iy0 + r, ix = ix0 + q;
-        float v = 0.f;
-        if (q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-            const int64_t o = ((int64_t)c * H + iy) * W + ix;
-            v = norm ? ((float)xu[o] / 255.f - norm[c]) / norm[3 + c] : xi[o];
+        const bool ok = i < SB_PATCH && q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
+        pv[it] = norm ? (float)xu[o] : xi[o];
+        if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
+        if (!ok) pv[it] = 0.f;
+    }
+    if (wp) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            wv[it] = reinterpret_cast<const bf16x8*>(wp)[i < 64 * SB_ROWB / 16 ? i : 0];
         }
-        patch[i] = (__bf16)v;
+    }
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int i = tid + it * 256;
+        if (i < SB_PATCH) patch[i] = (__bf16)pv[it];
     }
     // weights: the LDS image [64][368 B] made once by grl_stem_pack_weight_bf16, or converted here
     if (wp) {
-        for (int i = tid; i < 64 * SB_ROWB / 16; i += 256)
-            reinterpret_cast<bf16x8*>(Wt)[i] = reinterpret_cast<const bf16x8*>(wp)[i];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < 64 * SB_ROWB / 16) reinterpret_cast<bf16x8*>(Wt)[i] = wv[it];
+        }
     } else {
         for (int i = tid; i < 64 * SB_CH; i += 256) {
             const int n = i / SB_CH, ch = i - n * SB_CH;

@@ -908,7 +908,8 @@ def test_train_mixed_math_forward_is_the_fp32_forward_and_gradients_stay_fp32_cl
 
 def test_train_two_stream_trl_is_deterministic_and_matches_single_stream(monkeypatch):
     """Train mode runs the two TRL directions -- forward and, through the tape's stream tags, backward -- on two
-    HIP streams.  Run to run the step is bit-reproducible (fixed per-direction accumulation, sums at the join);
+    HIP streams, and weight gradients on a third (train_engine.WGRAD_STREAM: same launches, bit-identical gradients
+    with or without it).  Run to run the step is bit-reproducible (fixed per-direction accumulation, sums at the join);
     against the single-stream order only the association of three sums changes (gradients of x_uncorr, GAP(x_corr)
     and the initial memo are accumulated per direction first): forward bit-identical, weight gradients within 1e-4."""
     from grl_amd import engine
@@ -918,8 +919,11 @@ def test_train_two_stream_trl_is_deterministic_and_matches_single_stream(monkeyp
     rg = torch.Generator().manual_seed(9)
     r1, r2 = torch.randn(B, 2048, generator=rg).cuda(), torch.randn(B, T, 2048, generator=rg).cuda()
 
-    def run(two):
+    from grl_amd import train_engine as TE
+
+    def run(two, wstream=True):
         monkeypatch.setattr(engine, 'TRL_STREAMS', two)
+        monkeypatch.setattr(TE, 'WGRAD_STREAM', wstream)
         cnn = _fresh_cnn_conditioned()
         cnn.train()
         xu, xc = cnn(clips)
@@ -928,6 +932,8 @@ def test_train_two_stream_trl_is_deterministic_and_matches_single_stream(monkeyp
         return xu.detach(), xc.detach(), {k: p.grad.clone() for k, p in cnn.named_parameters() if p.grad is not None}
     a, b, c = run(True), run(True), run(False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    d = run(True, wstream=False)       # weight gradients on the launch stream: the same launches, the same bits
+    assert all(torch.equal(a[2][k], d[2][k]) for k in a[2])
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
     scale = {k: float(c[2][k].norm()) for k in c[2]}
     for k in c[2]:                     # zero-gradient biases in front of a batch-statistics BatchNorm: layer scale

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                 return;
             }
         }
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};       // train-mode BN: column sums of the raw output
         if (n < p.N) {
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, cn = sh;
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                         if (p.gbias)
                             v += *reinterpret_cast<const f32x4*>(
                                 p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n);
+                        if (p.stats) { ssum += v; ssq += v * v; }
                         v = v * sc + sh;
                         if (p.res) {
                             if constexpr (MATH == 2) {
@@ -543,6 +545,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                         }
                     } else {
                         *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                    }
+                }
+            }
+        }
+        if constexpr (MATH != 2) {
+            if (p.stats) {
+                // per-channel sum / sum of squares over this tile's rows, fixed order: a lane over its rows (above),
+                // the lanes of a wave that own the same 4 channels (xor-shuffles over the row groups), the two wave
+                // rows through LDS; one deterministic partial per (tile_m, n): stats[tile_m][0|1][n]
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+                }
+                __syncthreads();                               // every wave has read its C slab: LDS is free
+                float* red = smem;                             // [2 wm][2][BN]
+                if (lrow == 0) {
+                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + wn * WTN + lcol) = ssum;
+                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + wn * WTN + lcol) = ssq;
+                }
+                __syncthreads();
+                for (int c = tid; c < BN; c += 256) {
+                    const int nn = n0 + c;
+                    if (nn < p.N) {
+                        p.stats[((int64_t)tile_m * 2 + 0) * p.N + nn] = red[0 * BN + c] + red[2 * BN + c];
+                        p.stats[((int64_t)tile_m * 2 + 1) * p.N + nn] = red[1 * BN + c] + red[3 * BN + c];
                     }
                 }
             }
@@ -649,7 +677,9 @@ TileChoice choose_tile(const GrlGemm& d) {
     if (d.K <= 128) return {64, 64};
     if (d.K <= 512) return tiles(128, 64) >= 448 ? TileChoice{128, 64} : TileChoice{64, 64};
     if (tiles(128, 128) >= 448) return {128, 128};
-    if (tiles(128, 64) >= 448) return {128, 64};
+    // (128-row tiles of a dense operand stage by LDS-DMA: from one tile per CU on they beat four times as many 64 x 64
+    // tiles -- 4096 x 512 x 2048: 84.8 vs 95.7 us)
+    if (tiles(128, 64) >= (d.conv ? 448 : 256)) return {128, 64};
     return {64, 64};
 }
 
@@ -697,7 +727,7 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const int vec_epi = (!d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
+    const int vec_epi = ((!d.stats || MATH != 2) && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (MATH == 2 && !vec_epi)
@@ -711,9 +741,10 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
         // dense fp32 with a long K loop: LDS-DMA staging (GRL_GEMM_DMA=0 switches it off: tuning only)
         static const bool dma_on = [] { const char* e = getenv("GRL_GEMM_DMA"); return !e || atoi(e) != 0; }();
         constexpr bool CAN_DMA = MATH == 0 && BM == 128;
-        if (CAN_DMA && dma_on && !seg && d.K >= 256)
-            launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
-        else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        if (CAN_DMA && dma_on && d.K >= 256) {
+            if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+            else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     }
     return grl_check_launch("grl_conv_gemm_f32");

@@ -45,6 +45,11 @@ class ATTEvaluator(object):
         # its GPU; clip features are independent (eval BN is folded), so any chunking gives the
         # same rows -- 32 keeps the MI355X busy (1900 vs 1400 clip-features/s at 8).
         self.chunk = 32
+        # dense mode: tracklets are collected until this many clips are pending, then extracted together in
+        # `chunk`-sized forwards -- a MARS tracklet has ~15 clips, one forward per tracklet would leave every
+        # forward half empty.  Rows do not depend on what else is in the batch (tested), so the per-tracklet means
+        # are the ones a tracklet-by-tracklet run gives, bit for bit.
+        self.group = 128
 
     def _device(self):
         return next(self.cnn_model.parameters()).device
@@ -60,20 +65,33 @@ class ATTEvaluator(object):
         own = [i for i in range(len(data_loader)) if i % world == rank]
         batches = (b for i, b in enumerate(data_loader) if i % world == rank)
         mine = []
+        pending, n_pending = [], 0          # dense mode: (batch index, clips [n,s,c,h,w], pids, camids)
+
+        def flush():
+            clips = torch.cat([p[1] for p in pending], 0) if len(pending) > 1 else pending[0][1]
+            rows = torch.cat([engine.extract_features(self.cnn_model, self.siamese_model, clips[y:y + self.chunk])
+                              for y in range(0, clips.size(0), self.chunk)], 0)
+            off = 0
+            for i, c, pids, camids in pending:
+                mine.append((i, engine.rows_mean(rows[off:off + c.size(0)]), pids, camids))
+                off += c.size(0)
+            del pending[:]
         # the next batch's host->device copy overlaps this batch's kernels (side HIP stream)
         for i, (imgs, pids, camids) in zip(own, engine.DevicePrefetcher(batches, dev)):
+            pids, camids = [int(x) for x in pids], [int(x) for x in camids]
             if self.only_eval:
                 # dense mode: one tracklet per item, all its clips; features are averaged
                 # over clips (attevaluator.py:68-98)
                 b, n, s, c, h, w = imgs.size()
-                clips = imgs.view(b * n, s, c, h, w)
-                parts = [engine.extract_features(self.cnn_model, self.siamese_model,
-                                                 clips[y * self.chunk:(y + 1) * self.chunk])
-                         for y in range(int(math.ceil(b * n / float(self.chunk))))]
-                feat = engine.rows_mean(torch.cat(parts, 0))
+                pending.append((i, imgs.view(b * n, s, c, h, w), pids, camids))
+                n_pending += b * n
+                if n_pending >= self.group:
+                    flush()
+                    n_pending = 0
             else:
-                feat = engine.extract_features(self.cnn_model, self.siamese_model, imgs)
-            mine.append((i, feat, [int(x) for x in pids], [int(x) for x in camids]))
+                mine.append((i, engine.extract_features(self.cnn_model, self.siamese_model, imgs), pids, camids))
+        if pending:
+            flush()
         feat, pids_all, cams_all = grl_dist.gather_feature_batches(mine, len(data_loader))
         return feat, np.asarray(pids_all), np.asarray(cams_all)
 

@@ -381,6 +381,15 @@ def test_attevaluator_end_to_end_both_modes(gpu_models, capsys):
     df, dp, _ = evd.extract_feature([(dense, torch.tensor([7]), torch.tensor([1]))])
     ref = O.extract_features(sd, ssd, dense[0]).mean(dim=0, keepdim=True)
     assert df.shape == (1, 6144) and _rel(df.cpu().numpy(), ref.numpy()) < TOL and int(dp[0]) == 7
+    # several tracklets of different lengths: clips are batched ACROSS tracklets (evd.group pending clips, chunks of
+    # evd.chunk) -- the per-tracklet means must be the ones a tracklet-by-tracklet run gives, bit for bit
+    tracks = [(synth_clips(n, T, seed=40 + n).unsqueeze(0), torch.tensor([n]), torch.tensor([n % 2])) for n in (3, 7, 1, 9, 5)]
+    evd.group, evd.chunk = 12, 8
+    grouped, gp, gc = evd.extract_feature(tracks)
+    evd.group = 1
+    single, sp, sc = evd.extract_feature(tracks)
+    assert grouped.shape == (5, 6144) and torch.equal(grouped, single)
+    assert list(gp) == [3, 7, 1, 9, 5] == list(sp) and list(gc) == list(sc)
 
 
 @pytest.mark.parametrize('b,t', [(1, 1), (1, 16), (5, 3)])

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Soak test of the multi-stream paths: many repetitions of (a) the two-stream eval extraction against the
+single-stream result, fp32 and bf16-storage, several batch shapes, (b) the training step (TRL directions + weight
+gradients on side streams) against its own first run.  Any mismatch is a race.   python tools/stream_soak.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from grl_amd import engine
+from grl_amd.synthetic import synth_clips, synth_clips_structured
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+dev = torch.device('cuda:0')
+cnn, siam, _, _ = bench.build_models(dev)
+bad = 0
+for mode in ('f32', 'bf16s'):
+    for (b, t) in ((32, 4), (8, 4), (1, 4), (5, 3), (64, 8) if mode == 'bf16s' else (16, 2)):
+        c = synth_clips(b, t, seed=b + t).to(dev)
+        with engine.math_mode(mode):
+            engine.TRL_STREAMS = False
+            want = engine.extract_features(cnn, siam, c)
+            engine.TRL_STREAMS = True
+            n = sum(0 if torch.equal(engine.extract_features(cnn, siam, c), want) else 1 for _ in range(reps))
+        print('eval %-5s B=%2d T=%d: %d/%d mismatches' % (mode, b, t, n, reps), flush=True)
+        bad += n
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import test_gpu_parity as TP
+clips = synth_clips_structured(8, 4, seed=21).to(dev)
+rg = torch.Generator().manual_seed(9)
+r1, r2 = torch.randn(8, 2048, generator=rg).to(dev), torch.randn(8, 4, 2048, generator=rg).to(dev)
+first = None
+n = 0
+for it in range(max(10, reps // 5)):
+    m = TP._fresh_cnn_conditioned(); m.train()
+    xu, xc = m(clips)
+    ((xu * r1).sum() + (xc * r2).sum()).backward()
+    torch.cuda.synchronize()
+    g = [p.grad.clone() for p in m.parameters() if p.grad is not None] + [xu.detach(), xc.detach()]
+    if first is None:
+        first = g
+    elif not all(torch.equal(a, b) for a, b in zip(g, first)):
+        n += 1
+print('train step: %d/%d runs differ from the first' % (n, max(10, reps // 5) - 1))
+bad += n
+print('SOAK', 'FAILED' if bad else 'ok')
+sys.exit(1 if bad else 0)

@@ -60,8 +60,10 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         recs.append((2.0 * M * N * K, e0, e1, (M, N, K, kw.get('conv'))))
         return out
 
-    engine.gemm = timed
     streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
+    engine.extract_features(cnn, siam, clips)                   # untimed: the caching allocator re-settles on one stream
+    torch.cuda.synchronize()                                    # (a hipMalloc between two events would count as GEMM time)
+    engine.gemm = timed
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)

@@ -740,7 +740,7 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
     } else {
         // dense fp32 with a long K loop: LDS-DMA staging (GRL_GEMM_DMA=0 switches it off: tuning only)
         static const bool dma_on = [] { const char* e = getenv("GRL_GEMM_DMA"); return !e || atoi(e) != 0; }();
-        constexpr bool CAN_DMA = MATH == 0 && BM == 128;
+        constexpr bool CAN_DMA = (MATH == 0 || MATH == 2) && BM == 128;     // 128-byte operand rows (fp32 x 32 / bf16 x 64)
         if (CAN_DMA && dma_on && d.K >= 256) {
             if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
             else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);

@@ -43,6 +43,8 @@ namespace {
 constexpr int BK = 32;
 constexpr int SEG_STAGES = 16;     // fp32 path: accumulator segment = 16 stages = 512 k
 
+__device__ uint4 g_zero_chunks[8];        // 128 zero bytes: LDS-DMA source of out-of-image conv taps
+
 struct RowInfo {          // per staged A row: where it comes from
     int64_t base;         // dense: m*lda ; conv: image base offset (img*H*W*C)
     int iy0, ix0;         // conv: top-left input coordinate of the window
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     int64_t bofs[B_ITEMS];
     const char* dma_a[DMA ? BM / 32 : 1];
     const char* dma_b[DMA ? BN / 32 : 1];
+    int dma_iy0[DMA && CONV ? BM / 32 : 1], dma_ix0[DMA && CONV ? BM / 32 : 1];      // conv: window origin of the row
     int m0, n0, tile_m;
     auto setup_tile = [&](int t) {
         int bid = t;
@@ -139,7 +142,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                 const int r = (wave + 4 * i) * 8 + d_row;
                 int m = m0 + r;
                 m = m < p.M ? m : p.M - 1;
-                dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)m * p.lda) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
+                if constexpr (CONV) {                          // image base; the stage adds the tap's pixel and channel
+                    const int hw = p.Ho * p.Wo;
+                    const int img = m / hw, rem = m - img * hw;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)img * p.H * p.W * p.C) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
+                    dma_iy0[i] = oy * p.stride - p.pad;
+                    dma_ix0[i] = ox * p.stride - p.pad;
+                } else {
+                    dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)m * p.lda) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
+                }
             }
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
@@ -160,11 +172,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             char* const Asb = reinterpret_cast<char*>(As + buf * BM * BK);
             char* const Bsb = reinterpret_cast<char*>(Bs + buf * BN * BK);
             const int64_t kb = (int64_t)ks * KST * ESZ;
+            if constexpr (CONV) {
+                // implicit GEMM: the per-lane DMA source IS the gather -- the tap (ky, kx) and channel offset of the
+                // stage are wave-uniform, out-of-image taps read a zero page
+                const int k0 = ks * KST;
+                const int tap = k0 / p.C, c0 = k0 - tap * p.C;
+                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                const char* const zsrc = reinterpret_cast<const char*>(g_zero_chunks) + (d_chunk << 4);
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i) {
+                    const int rb = wave + 4 * i;
+                    const int iy = dma_iy0[i] + ky, ix = dma_ix0[i] + kx;
+                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const char* src = ok ? dma_a[i] + ((int64_t)(iy * p.W + ix) * p.C + c0) * ESZ : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(Asb + rb * 1024), 16, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) {
                 const int rb = wave + 4 * i;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_a[i] + kb),
                                                  (__attribute__((address_space(3))) void*)(Asb + rb * 1024), 16, 0, 0);
+            }
             }
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
@@ -734,8 +764,13 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
         return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
     constexpr bool CAN_SEG = MATH == 0;
     const bool seg = CAN_SEG && d.kblock && d.K > SEG_STAGES * BK;
+    static const bool dma_conv_on = [] { const char* e = getenv("GRL_GEMM_DMA_CONV"); return !e || atoi(e) != 0; }();
     if (d.conv) {
-        if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        constexpr bool CAN_DMA_CONV = (MATH == 0 || MATH == 2) && BM == 128;
+        if (CAN_DMA_CONV && dma_conv_on) {
+            if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+            else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
+        } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false>>(d, s, lds, tiles_n, num_tiles, vec_epi);
     } else {
         // dense fp32 with a long K loop: LDS-DMA staging (GRL_GEMM_DMA=0 switches it off: tuning only)

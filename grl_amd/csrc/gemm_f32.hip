@@ -430,6 +430,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         // row: float4 scale/shift/residual loads and 256-B contiguous row segments per
         // 16 lanes on the store, instead of 64 dword-wide store instructions.
         float* Cs = smem;                                   // [BM][BN]
+        // fp32 residual rows of this lane, requested BEFORE the accumulators take their round trip through LDS:
+        // the epilogue of a short-K layer is a read-modify-write of the output at HBM speed, and a residual load
+        // issued per row inside the store loop serialises its latency with the stores
+        constexpr int EPI_ROWS = WTM / (64 / (WTN / 4));
+        constexpr bool RES_PREFETCH = MATH != 2 && !SEG && !(BM == 128 && BN == 128);     // (16 rows x 4 VGPRs would spill there)
+        constexpr int EPI_UNROLL = RES_PREFETCH ? EPI_ROWS : 4;
+        f32x4 rpre[RES_PREFETCH ? EPI_ROWS : 1];
+        if constexpr (RES_PREFETCH) {
+            if (p.res && p.epilogue == GRL_EPI_AFFINE) {
+                constexpr int LPRp = WTN / 4, RPIp = 64 / LPRp;
+                const int np = n0 + wn * WTN + (lane % LPRp) * 4;
+#pragma unroll
+                for (int it = 0; it < EPI_ROWS; ++it) {
+                    const int m = m0 + wm * WTM + it * RPIp + lane / LPRp;
+                    if (m < p.M && np < p.N) rpre[it] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + np);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
             if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
             if (p.epilogue == GRL_EPI_EUCLID) cn = *reinterpret_cast<const f32x4*>(p.cnorm + n);
-#pragma unroll 4
+#pragma unroll EPI_UNROLL
             for (int it = 0; it < WTM / RPI; ++it) {
                 const int row = wm * WTM + it * RPI + lrow;
                 const int m = m0 + row;
@@ -549,6 +567,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                                     reinterpret_cast<const __bf16*>(p.res) + (int64_t)m * p.ldres + n);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                            } else if constexpr (RES_PREFETCH) {
+                                v += rpre[it];
                             } else {
                                 v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
                             }

@@ -602,18 +602,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
         if constexpr (MATH == 0) {
         const float* Ab = As + buf * 32 * BM + wm * WTM;
         const float* Bb = Bs + buf * 32 * BN + wn * WTN;
+        // fragments double-buffered in registers: the reads of k-step s+1 are issued BEFORE the MFMAs of step s and
+        // fenced there (left to itself hipcc issues read, s_waitcnt lgkmcnt(0), 4 MFMAs per step: the LDS latency of
+        // every step in front of 256 cycles of matrix work -- 66 % MFMA busy)
+        float af[2][MT], bf[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = Ab[fhalf * BM + i * 32 + frow];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = Bb[fhalf * BN + j * 32 + frow];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            float af[MT], bf[NT];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < 16) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = Ab[(2 * s + fhalf) * BM + i * 32 + frow];
+                for (int i = 0; i < MT; ++i) af[nxt][i] = Ab[(2 * s + 2 + fhalf) * BM + i * 32 + frow];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = Bb[(2 * s + fhalf) * BN + j * 32 + frow];
+                for (int j = 0; j < NT; ++j) bf[nxt][j] = Bb[(2 * s + 2 + fhalf) * BN + j * 32 + frow];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         } else {
             // transpose reads: 16-lane group g = lane >> 4 reads the 4-row x 16-column block

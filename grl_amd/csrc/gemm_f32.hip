@@ -329,6 +329,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
         } else if constexpr (MATH == 0) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
+            if constexpr (SEG && DMA) {
+            // (K-blocked train kernels only -- the LDS-DMA forms, which have the registers for it: +1.5 % on the train step; the eval kernels LOSE 3 % to it -- their compiler
+            // schedule already overlaps the next chunk's reads with the last two MFMAs and the extra registers cost more)
+            // fragments double-buffered in registers: the reads of chunk q+1 are issued, and fenced, in front of
+            // the 4 * MT * NT MFMAs of chunk q (see wgrad_kernel in train.hip)
+            f32x4 af[2][MT], bf[2][NT];
+            auto rd = [&](int set, int q) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = i * 32 + frow;
+                    af[set][i] = *reinterpret_cast<const f32x4*>(Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = j * 32 + frow;
+                    bf[set][j] = *reinterpret_cast<const f32x4*>(Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q + 1 < 4) rd((q + 1) & 1, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i][s], bf[q & 1][j][s],
+                                                                             acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 af[MT], bf[NT];
@@ -353,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
                                                                              acc[i][j], 0, 0, 0);
+            }
             }
         } else {
             const char* Ab = Ah + buf * PL * BM * 64 + (wm * WTM) * 64;

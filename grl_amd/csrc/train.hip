@@ -176,7 +176,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
-    int M, int C) {
+    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta) {
     constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
     __shared__ f32x4 red[2][4][LPR];
     const int chunk = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -186,17 +186,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     if (c < C) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        f32x4 ms = {0.f, 0.f, 0.f, 0.f}, mb = ms;
+        if (mscale) ms = *reinterpret_cast<const f32x4*>(mscale + c);
+        if (mbeta) mb = *reinterpret_cast<const f32x4*>(mbeta + c);
         const int r1 = min(M, (chunk + 1) * CHUNK);
         const int rend = min(r1, chunk * CHUNK + (wave + 1) * (CHUNK / 4));
 #pragma unroll 4
         for (int r = chunk * CHUNK + wave * (CHUNK / 4) + sub; r < rend; r += RPW) {       // 12 loads in flight
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)r * C + c);
+            const f32x4 zc = *reinterpret_cast<const f32x4*>(z + (int64_t)r * C + c) - mu;
             if (act) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(act + (int64_t)r * C + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            } else if (mscale) {                      // the forward's (z - mean) * scale + beta, term for term
+                f32x4 t = zc * ms;
+                if (mbeta) t += mb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = t[e] > 0.f ? g[e] : 0.f;
             }
-            const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + (int64_t)r * C + c) - mu) * is;
+            const f32x4 xh = zc * is;
             s += g; q += g * xh;
         }
     }
@@ -237,16 +246,23 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ act, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ coef, float* __restrict__ dz, int C,
-                                    int64_t total4, float* __restrict__ gres, int gres_accumulate) {
+                                    int64_t total4, float* __restrict__ gres, int gres_accumulate,
+                                    const float* __restrict__ mscale, const float* __restrict__ mbeta) {
     const int C4 = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 zc = reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c);
         if (act) {
             const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        } else if (mscale) {
+            f32x4 t = zc * *reinterpret_cast<const f32x4*>(mscale + c);
+            if (mbeta) t += *reinterpret_cast<const f32x4*>(mbeta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = t[e] > 0.f ? g[e] : 0.f;
         }
         if (gres) {        // the residual branch receives the same masked gradient (y = relu(bn(z) + res))
             f32x4 r = g;
@@ -254,7 +270,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             reinterpret_cast<f32x4*>(gres)[i] = r;
         }
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
-        const f32x4 xh = (reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c)) * is;
+        const f32x4 xh = zc * is;
         f32x4 gm = is;
         if (gamma) gm = gm * *reinterpret_cast<const f32x4*>(gamma + c);
         reinterpret_cast<f32x4*>(dz)[i] =
@@ -802,24 +818,24 @@ extern "C" int grl_bn_apply_centered(const float* z, const float* mean, const fl
 extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                           const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                           float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
-                          void* stream) {
+                          const float* mask_scale, const float* mask_beta, void* stream) {
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
     if (C <= 64)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<16>, dim3(grl_ceil_div(C, 64), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta);
     else if (C <= 128)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(grl_ceil_div(C, 128), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, s, slab_ws, rows, C,
                        (double)M, dgamma, dbeta, coef_ws);
     const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
-                       coef_ws, dz, C, total4, gres, gres_accumulate);
+                       coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta);
     return grl_check_launch("grl_bn_bwd");
 }
 

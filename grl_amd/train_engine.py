@@ -335,15 +335,17 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
-def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0):
+def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False):
     """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
-    same pass that writes dz)."""
+    same pass that writes dz).  ``mask_from_z``: y = relu(bn(z)) without a residual -- the ReLU mask is recomputed
+    from z with the forward's own operations (st.scale, st.beta) instead of reading the activation."""
     dz = _new((M, Cc), dy)
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Cc), dy)
     coef = _new((2, Cc), dy)
-    _call('grl_bn_bwd', ptr(dy), ptr(z), ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma), ptr(dz),
-          ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc)
+    _call('grl_bn_bwd', ptr(dy), ptr(z), None if mask_from_z else ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+          ptr(dz), ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc,
+          ptr(st.scale) if mask_from_z else None, ptr(st.beta) if mask_from_z else None)
     return dz
 
 
@@ -386,7 +388,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             if gres is None:
                 gres = tp.g[id(res)] = _new((M, N), da)
         dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
-                         gres=gres, gres_acc=gacc)
+                         gres=gres, gres_acc=gacc, mask_from_z=relu and res is None)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
                                    kcols=kcols, ldw=ldw)
         if gbias is not None:

@@ -274,7 +274,9 @@ int grl_bn_apply(const float* z, const float* scale, const float* shift, const f
 int grl_bn_apply_centered(const float* z, const float* mean, const float* scale, const float* beta,
                           const float* res, float* y, int64_t M, int C, int relu, void* stream);
 
-/* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask);
+/* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask -- unless mask_scale is given: then the ReLU
+ * mask of y = relu((z - mean)*mask_scale + mask_beta) is RECOMPUTED from z with the forward's own three fp32
+ * operations (grl_bn_apply_centered without a residual), so the activation is not read at all);
  * dgamma += sum g*xhat; dbeta += sum g; dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
  * slab_ws: grl_col_stats_rows(M)*2*C floats, coef_ws: 2*C floats. gamma/dgamma/dbeta may be NULL.
  * gres (may be NULL): gradient of the residual input of y = relu(bn(z) + res), which is the same
@@ -282,7 +284,7 @@ int grl_bn_apply_centered(const float* z, const float* mean, const float* scale,
 int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
-               void* stream);
+               const float* mask_scale, const float* mask_beta, void* stream);
 
 /* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
 int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);

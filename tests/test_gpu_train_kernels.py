@@ -369,3 +369,31 @@ def test_wgrad_bf16_datapaths(M, N, K, conv):
             got = run(dzd, xd, math).cpu().double()
             err = float((got - ref32).abs().max() / ref32.abs().max())
             assert err < tol, (representable, math, err)
+
+
+@pytest.mark.parametrize('M,Cc', [(4096, 64), (1024, 128), (777 * 4, 512)])
+def test_bn_backward_mask_recomputed_from_z_is_the_activation_mask(M, Cc):
+    """y = relu(bn(z)) without a residual: grl_bn_bwd recomputes the ReLU mask from z with the forward's own
+    (z - mean) * scale + beta instead of reading the activation -- dz, dgamma, dbeta must be the ones the activation
+    mask gives, bit for bit (values straddling zero included: beta shifts half of them negative)."""
+    from grl_amd import train_engine as TE
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(M + Cc)
+    bn = nn.BatchNorm1d(Cc).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5); bn.bias.copy_(torch.randn(Cc, generator=g) * 0.3)
+    z = (torch.randn(M, Cc, generator=g) * 2 + 0.7).to(dev)
+    dy = torch.randn(M, Cc, generator=g).to(dev)
+    rows = TE._lib.load().grl_col_stats_rows(M)
+    slab = torch.empty(rows, 2, Cc, device=dev)
+    TE._call('grl_col_stats', TE.ptr(z), TE.ptr(slab), M, Cc, Cc, TE.ptr(z))
+    st = TE.bn_finalize(slab, rows, Cc, M, bn, dev, pivot=z)
+    a = torch.empty_like(z)
+    TE.bn_apply(z, st, None, a, M, Cc, True)
+    assert 0.2 < float((a > 0).float().mean()) < 0.8
+    out = []
+    for from_z in (False, True):
+        dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+        dz = TE.bn_backward(dy, z, a, st, bn.weight, dg, db, M, Cc, mask_from_z=from_z)
+        out.append((dz, dg, db))
+    assert all(torch.equal(x, y) for x, y in zip(*out))

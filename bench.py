@@ -19,6 +19,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC); set before HIP initialises
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

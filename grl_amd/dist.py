@@ -27,6 +27,10 @@ trainer.py:137-162).  Here every rank builds them from its LOCAL pairs and the g
 averaged: cross-rank negatives are not mined.  That is what north_star prescribes ("all-reduce
 on the gradient step only"); it is not bit-equivalent to a 2-GPU DataParallel run.
 """
+import os
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL across processes needs dmabuf IPC on this driver
+
 import torch
 import torch.distributed as dist
 

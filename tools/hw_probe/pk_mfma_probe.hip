@@ -96,7 +96,7 @@ int main() {
     CK(hipMemset(ga, 0x3c, (size_t)GM * GK * 2)); CK(hipMemset(gw, 0x3c, (size_t)GN * GK * 2));
     GrlGemm gd; memset(&gd, 0, sizeof gd); gd.a = (const float*)ga; gd.w = (const float*)gw; gd.y = (float*)gy;
     gd.M = GM; gd.N = GN; gd.K = GK; gd.lda = GK; gd.ldw = GK; gd.ldy = GN; gd.ldres = GN; gd.relu = 1; gd.math = GRL_MATH_BF16S;
-    for (int var = 3; var < 5; ++var) {
+    for (int var = 0; var < 5; ++var) {
         auto run_v = [&](float* out, hipStream_t s) {
             dim3 g((C + 1023) / 1024, B);
             if (var == 0) hipLaunchKernelGGL(victim<0>, g, dim3(256), Hd * 4, s, hid, w, out, C, Hd);
@@ -116,7 +116,7 @@ int main() {
                 if (ag == 1) hipLaunchKernelGGL(spinner<1>, dim3(512), dim3(256), 0, s1, sp, 5000);
                 if (ag == 2) hipLaunchKernelGGL(spinner<2>, dim3(1024), dim3(256), 0, s1, sp, 20000);
                 if (ag == 4) { if (grl_conv_gemm_f32(&gd, s1) != 0) { printf("gemm failed\n"); return 1; } }
-                for (int rep = 0; rep < 12; ++rep) run_v(y, s2);
+                for (int rep = 0; rep < 60; ++rep) run_v(y, s2);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(got.data(), y, got.size() * 4, hipMemcpyDeviceToHost));
                 int cnt = 0;

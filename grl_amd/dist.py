@@ -36,7 +36,11 @@ import torch.distributed as dist
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """More than one rank -- or GRL_SYNC_FORCE=1 with an initialised group of one (tests: the only way to run the
+    RCCL call sequence on a single-GPU box; every collective is then an identity)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('GRL_SYNC_FORCE') == '1'
 
 
 # ----------------------------------------------------------------------------
@@ -233,6 +237,9 @@ class GradSync(object):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if is_distributed() else 1
+        # GRL_SYNC_FORCE=1 (tests): issue the collectives even in a world of one rank -- the only way to run the
+        # RCCL call sequence (async all-reduce of flat-buffer slices under the backward) on a single-GPU box
+        self.force = os.environ.get('GRL_SYNC_FORCE') == '1' and dist.is_available() and dist.is_initialized()
         self._works = []          # (work, flat slice)
         self._owned = []          # (param, flat, offset) of every tape-owned gradient of this step
         self._checked = False
@@ -251,7 +258,7 @@ class GradSync(object):
         """Average ``piece`` (a contiguous slice of a flat gradient buffer) over the ranks; returns
         at once, the result is valid after ``finish()``."""
         self.launched.append((label, piece.numel()))
-        if self.world == 1 or piece.numel() == 0:
+        if (self.world == 1 and not self.force) or piece.numel() == 0:
             return
         if _host_staged(piece, self.group):
             self._works.append((_HostWork(piece, self.group), piece))
@@ -280,7 +287,7 @@ class GradSync(object):
             for p in stray:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
                 p.grad.mul_(inv)
-        if not self._checked and self.world > 1:
+        if not self._checked and (self.world > 1 or self.force):
             mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32)
             if dist.get_backend(self.group) != 'gloo':              # RCCL reduces device tensors only
                 mask = mask.to(self.params[0].device)

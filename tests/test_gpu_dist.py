@@ -1,6 +1,7 @@
 """Data-parallel training on ONE MI355X: two processes share cuda:0 and talk over gloo (device
 tensors are staged through the host by grl_amd.dist) -- the same GradSync / tape code path the
-8-GPU RCCL run takes, minus the transport.  RCCL itself cannot be exercised on a 1-GPU box."""
+8-GPU RCCL run takes, minus the transport.  RCCL itself runs here only in a world of ONE rank
+(test_rccl_backend_in_a_world_of_one_rank: the real call sequence on the `nccl` backend, every collective an identity)."""
 import os
 import sys
 
@@ -58,12 +59,17 @@ def _snapshot(mods, crits):
     return sd
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend='gloo'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':
+        os.environ['GRL_SYNC_FORCE'] = '1'
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda:0')
     tr, opt, mods, crits = _trainer(dev)
     assert tr.device.type == 'cuda'
@@ -180,12 +186,17 @@ def test_two_rank_training_on_one_device_matches_averaged_gradients():
     assert worst < 1e-6
 
 
-def _eval_worker(rank, world, port, out):
+def _eval_worker(rank, world, port, out, backend='gloo'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':
+        os.environ['GRL_SYNC_FORCE'] = '1'
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     out[rank] = _run_eval()
     torch.cuda.synchronize()
     dist.barrier()
@@ -222,3 +233,29 @@ def test_two_rank_evaluation_equals_single_process():
     for r in range(world):
         assert torch.equal(out[r][0], ref[0]) and out[r][1] == ref[1] and out[r][2] == ref[2]
         assert out[r][3] == ref[3] and out[r][4] == ref[4] and len(ref[4]) == 5
+
+
+def test_rccl_backend_in_a_world_of_one_rank():
+    """The `nccl` (= RCCL) backend on this 1-GPU box: a process group of ONE rank, collectives forced
+    (GRL_SYNC_FORCE=1) -- the exact call sequence of the 8-GPU run (async all-reduce of flat gradient slices
+    released by the tape while the backward -- TRL side stream, weight-gradient stream -- is still running; device
+    all-gathers in the evaluator and the OIM replay), minus the peers.  With one rank every collective is an identity,
+    so two trainer steps must leave bit-identical parameters / LUTs to a plain single-process run, and the evaluator
+    the same features and metrics."""
+    world, port = 1, 32900 + os.getpid() % 1500
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out, 'nccl'), nprocs=1, join=True)
+    snaps, launched, _ = out[0]
+    assert [l for l, _ in launched[0]] == ['trl', 'layer4', 'layer3', 'stem', 'rest'][:len(launched[0])] or len(launched[0]) >= 4
+    dev = torch.device('cuda:0')
+    tr, opt, mods, crits = _trainer(dev)
+    for step, batch in enumerate(_batches()):
+        tr.train(step, [batch], opt)
+        ref = _snapshot(mods, crits)
+        for k in ref:
+            assert torch.equal(ref[k], snaps[step][k]), (step, k)
+    out2 = ctx.Manager().dict()
+    mp.spawn(_eval_worker, args=(world, port + 1, out2, 'nccl'), nprocs=1, join=True)
+    ref = _run_eval()
+    assert torch.equal(out2[0][0], ref[0]) and out2[0][1:] == ref[1:]

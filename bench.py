@@ -226,7 +226,7 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
         raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16')
     clips = synth_clips(B, T, seed=rank).to(dev)
     pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
-    sync = grl_dist.GradSync(params) if world > 1 else None      # bucketed all-reduce under the backward
+    sync = grl_dist.GradSync(params) if grl_dist.is_distributed() else None      # bucketed all-reduce under the backward (GRL_SYNC_FORCE=1: also in a world of one)
 
     def step():
         loss, _, _, _ = trainer._forward([clips], pids, 0, 0)

@@ -496,34 +496,34 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     catte = _new((b, Cc), xu) if taps is not None else None
     for i in range(t):
         for di, d in enumerate(plan.dirs):
-          with fk.on(di):
-            ti = i if di == 0 else t - 1 - i
-            dvec, dpart, hid = scr[di]
-            fcorr = fc[di]
-            # d = GAP((ReLU(conv_f1(memo)) - f2_t)^2): the squared difference is reduced in the GEMM
-            # epilogue (32-row partial sums), conv_f1's output never reaches HBM (grl_model.py:146-149)
-            if FUSE_TRL_SQDIFF:
-                gemm(memo[di], d['f1'].w, dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
-                     res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX)
-                _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
-            else:
-                f1 = _new((Mb, Cc), xu)
-                gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
-                _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
-            _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                  ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
-            if taps is not None:
-                taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
-            s = _new((Mb, Cc), xu)
-            _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
-            o = _new((Mb, 512), xu)
-            c1, c2, c3 = d['c1'], d['c2'], d['c3']
-            gemm(s, c1.w, o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True)
-            o2 = _new((Mb, 512), xu)
-            gemm(o, c2.w, o2, Mb, 512, 512, scale=c2.scale, shift=c2.shift, relu=True)
-            nm = _new((Mb, Cc), xu)
-            gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True)
-            memo[di] = nm
+            with fk.on(di):
+                ti = i if di == 0 else t - 1 - i
+                dvec, dpart, hid = scr[di]
+                fcorr = fc[di]
+                # d = GAP((ReLU(conv_f1(memo)) - f2_t)^2): the squared difference is reduced in the GEMM
+                # epilogue (32-row partial sums), conv_f1's output never reaches HBM (grl_model.py:146-149)
+                if FUSE_TRL_SQDIFF:
+                    gemm(memo[di], d['f1'].w, dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
+                         res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX)
+                    _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
+                else:
+                    f1 = _new((Mb, Cc), xu)
+                    gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
+                    _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+                _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
+                      ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+                if taps is not None:
+                    taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
+                s = _new((Mb, Cc), xu)
+                _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
+                o = _new((Mb, 512), xu)
+                c1, c2, c3 = d['c1'], d['c2'], d['c3']
+                gemm(s, c1.w, o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True)
+                o2 = _new((Mb, 512), xu)
+                gemm(o, c2.w, o2, Mb, 512, 512, scale=c2.scale, shift=c2.shift, relu=True)
+                nm = _new((Mb, Cc), xu)
+                gemm(o2, c3.w, nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s, relu=True)
+                memo[di] = nm
     fk.join(memo[1], fc[1])
     fcorr = fc[0]
     if fk.two:
@@ -653,24 +653,24 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     memo = [memo0, memo0]
     for i in range(t):
         for di, d in enumerate(plan.dirs):
-          with fk.on(di):
-            ti = i if di == 0 else t - 1 - i
-            dvec, hid = scr[di]
-            f1 = _newb((Mb, Cc), x)
-            gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
-            _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
-            _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                  None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
-            s_ = _newb((Mb, Cc), x)
-            _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
-            c1, c2_, c3 = d['c1'], d['c2'], d['c3']
-            o = _newb((Mb, 512), x)
-            gemm(s_, c1.wb(), o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True, math=MATH_BF16S)
-            o2 = _newb((Mb, 512), x)
-            gemm(o, c2_.wb(), o2, Mb, 512, 512, scale=c2_.scale, shift=c2_.shift, relu=True, math=MATH_BF16S)
-            nm = _newb((Mb, Cc), x)
-            gemm(o2, c3.wb(), nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s_, relu=True, math=MATH_BF16S)
-            memo[di] = nm
+            with fk.on(di):
+                ti = i if di == 0 else t - 1 - i
+                dvec, hid = scr[di]
+                f1 = _newb((Mb, Cc), x)
+                gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
+                _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+                _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
+                      None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+                s_ = _newb((Mb, Cc), x)
+                _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
+                c1, c2_, c3 = d['c1'], d['c2'], d['c3']
+                o = _newb((Mb, 512), x)
+                gemm(s_, c1.wb(), o, Mb, 512, Cc, scale=c1.scale, shift=c1.shift, relu=True, math=MATH_BF16S)
+                o2 = _newb((Mb, 512), x)
+                gemm(o, c2_.wb(), o2, Mb, 512, 512, scale=c2_.scale, shift=c2_.shift, relu=True, math=MATH_BF16S)
+                nm = _newb((Mb, Cc), x)
+                gemm(o2, c3.wb(), nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=s_, relu=True, math=MATH_BF16S)
+                memo[di] = nm
     fk.join(memo[1], fc[1])
     fcorr = fc[0]
     if fk.two:

@@ -749,63 +749,63 @@ def trl_train(tp, model, xu, xc, b, t):
     memo = list(memo_d)
     for i in range(t):
         for di, (f1m, _, mlp, blk) in enumerate(dirs):
-          with fk.on(di):
-            tp.side = fk.side if (fk.two and di == 1) else None
-            ti = i if di == 0 else t - 1 - i
-            f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
-            dvec = _new((b, Cc), xu)
-            f2t = f2[di]
-            _call('grl_sqdiff_mean', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
-            hid = _new((b, 128), xu)
-            catte = _new((b, Cc), xu)
-            w1, w2 = mlp[0].weight, mlp[2].weight
-            w2t = tp.w_t(w2.detach(), w2)                   # [128][2048]
-            fcd, gap_al, xu_al = fc[di], gapc_d[di], xu_d[di]
-            _call('grl_channel_atte', ptr(dvec), ptr(w1.detach()), ptr(w2t), ptr(gapc[ti:]), t * Cc,
-                  ptr(catte), ptr(fcd.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
+            with fk.on(di):
+                tp.side = fk.side if (fk.two and di == 1) else None
+                ti = i if di == 0 else t - 1 - i
+                f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
+                dvec = _new((b, Cc), xu)
+                f2t = f2[di]
+                _call('grl_sqdiff_mean', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+                hid = _new((b, 128), xu)
+                catte = _new((b, Cc), xu)
+                w1, w2 = mlp[0].weight, mlp[2].weight
+                w2t = tp.w_t(w2.detach(), w2)                   # [128][2048]
+                fcd, gap_al, xu_al = fc[di], gapc_d[di], xu_d[di]
+                _call('grl_channel_atte', ptr(dvec), ptr(w1.detach()), ptr(w2t), ptr(gapc[ti:]), t * Cc,
+                      ptr(catte), ptr(fcd.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
 
-            def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t, fcd=fcd,
-                         gap_al=gap_al):
-                dfc = tp.g.get(id(fcd))
-                if dfc is None:
-                    return
-                ds = _new((b, Cc), xu)
-                dgap = tp.full_grad(gap_al)
-                _call('grl_catte_bwd', ptr(dfc.view(b * t, Cc)[ti:]), t * Cc, ptr(gapc[ti:]), t * Cc,
-                      ptr(catte), ptr(ds), ptr(dgap[ti:]), t * Cc, 1, b, Cc)
-                dhid = _new((b, 128), xu)
-                gemm(ds, w2t, dhid, b, 128, Cc)
-                wgrad(ds, hid, tp.pgrad(w2), b, Cc, 128)
-                dhp = _new((b, 128), xu)
-                _call('grl_relu_bwd', ptr(dhid), ptr(hid), ptr(dhp), dhid.numel(), 0)
-                wgrad(dhp, dvec, tp.pgrad(w1), b, 128, Cc)
-                dd = _new((b, Cc), xu)
-                gemm(dhp, tp.w_t(w1.detach(), w1), dd, b, Cc, 128)
-                # through d = mean (f1 - f2)^2
-                df1 = _new((Mb, Cc), xu)
-                df2 = tp.full_grad(f2t)
-                _call('grl_sqdiff_bwd', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dd), ptr(df1),
-                      ptr(df2[ti * PIX:]), b, PIX, Cc, t * frame, 1)
-                tp.add_grad(f1, df1)
-            tp.ops.append(bwd_atte)
-            if tp.taps is not None:
-                tp.taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte)
+                def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t, fcd=fcd,
+                             gap_al=gap_al):
+                    dfc = tp.g.get(id(fcd))
+                    if dfc is None:
+                        return
+                    ds = _new((b, Cc), xu)
+                    dgap = tp.full_grad(gap_al)
+                    _call('grl_catte_bwd', ptr(dfc.view(b * t, Cc)[ti:]), t * Cc, ptr(gapc[ti:]), t * Cc,
+                          ptr(catte), ptr(ds), ptr(dgap[ti:]), t * Cc, 1, b, Cc)
+                    dhid = _new((b, 128), xu)
+                    gemm(ds, w2t, dhid, b, 128, Cc)
+                    wgrad(ds, hid, tp.pgrad(w2), b, Cc, 128)
+                    dhp = _new((b, 128), xu)
+                    _call('grl_relu_bwd', ptr(dhid), ptr(hid), ptr(dhp), dhid.numel(), 0)
+                    wgrad(dhp, dvec, tp.pgrad(w1), b, 128, Cc)
+                    dd = _new((b, Cc), xu)
+                    gemm(dhp, tp.w_t(w1.detach(), w1), dd, b, Cc, 128)
+                    # through d = mean (f1 - f2)^2
+                    df1 = _new((Mb, Cc), xu)
+                    df2 = tp.full_grad(f2t)
+                    _call('grl_sqdiff_bwd', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dd), ptr(df1),
+                          ptr(df2[ti * PIX:]), b, PIX, Cc, t * frame, 1)
+                    tp.add_grad(f1, df1)
+                tp.ops.append(bwd_atte)
+                if tp.taps is not None:
+                    tp.taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte)
 
-            s = _new((Mb, Cc), xu)
-            _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
-            prev = memo[di]
+                s = _new((Mb, Cc), xu)
+                _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
+                prev = memo[di]
 
-            def bwd_add(s=s, prev=prev, ti=ti, xu_al=xu_al):
-                dsum = tp.take(s)
-                if dsum is None:
-                    return
-                _axpy_frame(tp.full_grad(xu_al), ti, dsum, b, t, frame)
-                tp.add_grad(prev, dsum)
-            tp.ops.append(bwd_add)
-            o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
-            o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
-            memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
-            tp.side = None
+                def bwd_add(s=s, prev=prev, ti=ti, xu_al=xu_al):
+                    dsum = tp.take(s)
+                    if dsum is None:
+                        return
+                    _axpy_frame(tp.full_grad(xu_al), ti, dsum, b, t, frame)
+                    tp.add_grad(prev, dsum)
+                tp.ops.append(bwd_add)
+                o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
+                o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
+                memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
+                tp.side = None
     mf, mb_ = memo
     fk.join(mb_, fc[1])
     fcorr = fc[0]

@@ -29,6 +29,9 @@ from utils.serialization import load_checkpoint, save_cnn_checkpoint, save_siame
 
 
 def main(args):
+    if args.train_math:
+        from grl_amd import train_engine
+        train_engine.set_math(args.train_math)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -109,6 +112,9 @@ if __name__ == '__main__':
     ap.add_argument('--iters', type=int, default=4)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--augment', action='store_true', help='raw uint8 clips + on-device flip / erase / normalise')
+    ap.add_argument('--train-math', default=None, choices=['f32', 'mixed', 'bf16x3', 'bf16'],
+                    help="training GEMM datapath (grl_amd.train_engine.set_math; default exact fp32; 'mixed' = fp32 forward, "
+                         "split-bf16 backward GEMMs)")
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--logs-dir', type=str, default='/tmp/grl_logs')
     main(ap.parse_args())

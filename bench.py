@@ -5,9 +5,15 @@ A "step" is one pass of the hot path over one batch of synthetic MARS-shaped cli
 (BASELINE.json configs[1]: B x T = 32 x 4, 256 x 128, fp32): ResNet-50 trunk + GCE +
 TRL + Siamese temporal attention + concat -> one 6144-d feature row per clip
 (reference: reid/evaluator/attevaluator.py:100-112).  Inputs are resident in HBM
-before the timed region.  With --gpus N (launched by torch.distributed.run, one rank
-per GPU) every rank processes its own batch: clips are independent, there is no
-data-path collective (weak scaling); the barrier only brackets the timed region.
+before the timed region.  With --gpus N every rank processes its own batch: clips are
+independent, there is no data-path collective (weak scaling); the barrier only brackets the
+timed region.  `python bench.py --gpus N` by itself (no WORLD_SIZE in the environment) STARTS the
+N ranks -- `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process,
+before anything in this process touches the GPU -- and forwards the child's line; launched by
+torch.distributed.run it is one of the ranks.  The N > 1 line carries `rccl_ranks` /
+`dist_backend` from the initialised process group, and every line carries a `train` block: the
+SEQTrainer step of BASELINE configs[3] (64 clips x 4 frames per GPU, GradSync over RCCL) -- the
+series in which the ranks actually exchange data.
 
 Prints ONE JSON line (rank 0).
 """
@@ -30,6 +36,15 @@ sys.path.insert(0, ROOT)
 B, T = 32, 4
 GFLOP_PER_FRAME = 14.485                # conv+linear forward, per frame (57.94 per clip at T=4)
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def max_over_ranks(dist, dev, seconds):
+    """MAX of a per-rank wall time (RCCL reduces device tensors, gloo host tensors)."""
+    if dist is None:
+        return seconds
+    tt = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def build_models(dev):
@@ -107,52 +122,103 @@ def cpu_baseline(sd, ssd):
         O.extract_features(sd, ssd, clips)
     dt = time.time() - t0
     return {"value": round(nb * passes / dt, 3), "unit": "clip-features/sec", "cores": cores,
-            "kind": "port",
-            "sample": "oracle.extract_features (torch CPU fp32, %d threads) on the %d clips of one "
-                      "step, T=%d, %d timed passes (%.1f s)" % (cores, nb, T, passes, dt)}
+            "node_cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle.extract_features (torch CPU fp32, %d threads of the node's %d cores: the fastest "
+                      "setting measured, PyTorch-CPU convs regress beyond it) on the %d clips of one "
+                      "step, T=%d, %d timed passes (%.1f s)" % (cores, os.cpu_count() or 0, nb, T, passes, dt)}
 
 
-def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4):
-    """One SEQTrainer step (forward + 5-term loss + HIP backward + SGD) timed in this process;
-    used by the default run's `secondary` block.  Returns ms per step."""
+def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default'):
+    """One SEQTrainer step (forward + 5-term loss + HIP backward + bucketed gradient all-reduce when a process
+    group is up + SGD) on b x t synthetic pair-interleaved clips per rank.  Timed with a barrier + device sync on
+    both sides, MAX over ranks.  Returns a dict (ms_per_step, and the gradient-sync bookkeeping)."""
     from grl_amd.reid import models
     from grl_amd.reid.train import SEQTrainer
     from grl_amd.reid.loss import OIMLoss, PairLoss
     from grl_amd.synthetic import synth_clips, synth_state_dict
     from grl_amd import train_engine
+    from grl_amd import dist as grl_dist
     with contextlib.redirect_stdout(io.StringIO()):
         cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
     siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
     siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
-    cnn.load_state_dict(synth_state_dict(cnn, seed=0))
+    cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile=profile))
     siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'))
     siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
     cnn, siam, siamv = cnn.to(dev).train(), siam.to(dev).train(), siamv.to(dev).train()
     tr = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev),
                     OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), None)
-    opt = torch.optim.SGD(tr._all_params(), lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
-    clips = synth_clips(b, t, seed=0).to(dev)
-    pids = (torch.arange(b, device=dev) // 2 * 7) % 625
+    params = tr._all_params()
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    clips = synth_clips(b, t, seed=rank).to(dev)
+    pids = (torch.arange(b, device=dev) // 2 * 7 + rank * 131) % 625
+    sync = grl_dist.GradSync(params) if grl_dist.is_distributed() else None   # (GRL_SYNC_FORCE=1: also in a world of one)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    exposed = []
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        loss, _, _, _ = tr._forward([clips], pids, 0, 0)
+        opt.zero_grad()
+        if sync is not None:
+            sync.begin()
+        loss.backward()
+        if sync is not None:
+            e0.record()
+            sync.finish()              # the launch stream waits here for whatever the backward did not cover
+            e1.record()
+            exposed.append((e0, e1))
+        opt.step()
+        return loss
+
     old = train_engine.set_math(math)
     try:
-        def step():
-            loss, _, _, _ = tr._forward([clips], pids, 0, 0)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            return loss
         for _ in range(warmup):
             loss = step()
-        torch.cuda.synchronize()
+        barrier()
+        del exposed[:]
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+            if exposed:                # (events are re-used: read them before the next step re-records)
+                torch.cuda.current_stream().synchronize()
+                exposed[-1] = exposed[-1][0].elapsed_time(exposed[-1][1])
+        barrier()
+        dt = time.perf_counter() - t0
         assert bool(torch.isfinite(loss).all())
     finally:
         train_engine.set_math(old)
-    return ms
+    dt = max_over_ranks(dist, dev, dt)
+    ms = dt / steps * 1e3
+    out = {"ms_per_step": round(ms, 2), "clips_per_sec": round(max(world, 1) * b / ms * 1e3, 1)}
+    if sync is not None:
+        out.update({"allreduce_bytes_per_step": 4 * sum(n for _, n in sync.launched),
+                    "allreduce_buckets": [[lab, 4 * n] for lab, n in sync.launched],
+                    "gradsync_collectives_per_step": sync.collectives, "stray_reductions": sync.stray,
+                    "allreduce_exposed_ms": round(sum(exposed) / max(len(exposed), 1), 3),
+                    "reduce_op": "AVG in the collective" if sync.avg_op else "SUM + scale pass"})
+    return out
+
+
+def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4):
+    return train_series(dev, math, steps, warmup, b, t)["ms_per_step"]
+
+
+def train_block(dev, rank, world, dist, backend):
+    """BASELINE configs[3] per GPU: 64 clips x 4 frames (global P x K = 128 x 4 over 8 GPUs), SEQTrainer step with
+    the gradient buckets all-reduced under the backward.  Reported on every line (N = 1: no exchange), so that one
+    driver run at N = 1, 2, 4, 8 records the training series next to the eval headline."""
+    out = {"workload": "BASELINE configs[3] per GPU: SEQTrainer step (fwd + 5-term loss + HIP bwd + bucketed "
+                       "gradient all-reduce + SGD), 64 clips x 4 frames per GPU, global batch %d clips" % (64 * max(world, 1)),
+           "n_gpus": max(world, 1), "dist_backend": backend if dist is not None else None,
+           "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None}
+    for m in ('f32', 'mixed'):
+        out[m] = train_series(dev, m, steps=5, warmup=2, b=64, t=4, rank=rank, world=world, dist=dist)
+    return out
 
 
 def secondary_block(dev, cnn, siam, steps):
@@ -200,64 +266,19 @@ def secondary_block(dev, cnn, siam, steps):
     return out
 
 
-def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
+def train_bench(args, dev, dist, rank, world, backend):
     """Secondary series: train clips/sec.  One step = SEQTrainer's
-    forward (train-mode BN) + reference loss composition + HIP backward + the flat
-    gradient all-reduce when world > 1 + SGD(nesterov) step, on B x T = 32 x 4 synthetic
+    forward (train-mode BN) + reference loss composition + HIP backward + the bucketed
+    gradient all-reduce when world > 1 + SGD(nesterov) step, on B x T synthetic
     pair-interleaved clips per rank (mars_train.py -b 32 --seq_len 4)."""
-    from grl_amd.reid import models
-    from grl_amd.reid.train import SEQTrainer
-    from grl_amd.reid.loss import OIMLoss, PairLoss
-    from grl_amd.synthetic import synth_clips, synth_state_dict
-    from grl_amd import dist as grl_dist
-    siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
-    siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
-    siamv.to(dev)
-    crit_c = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
-    crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
-    trainer = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
-    params = trainer._all_params()
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
-    cnn.train(); siam.train(); siamv.train()
-    from grl_amd import train_engine
-    if args.math in ('mixed', 'bf16x3', 'bf16'):     # opt-in training datapaths (fp32 is the parity mode)
-        train_engine.set_math(args.math)
-    elif args.math != 'f32':
+    if args.math not in ('f32', 'mixed', 'bf16x3', 'bf16'):
         raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16')
-    clips = synth_clips(B, T, seed=rank).to(dev)
-    pids = (torch.arange(B, device=dev) // 2 * 7 + rank * 131) % 625
-    sync = grl_dist.GradSync(params) if grl_dist.is_distributed() else None      # bucketed all-reduce under the backward (GRL_SYNC_FORCE=1: also in a world of one)
-
-    def step():
-        loss, _, _, _ = trainer._forward([clips], pids, 0, 0)
-        opt.zero_grad()
-        if sync is not None:
-            sync.begin()
-        loss.backward()
-        if sync is not None:
-            sync.finish()
-        opt.step()
-        return loss
-
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert bool(torch.isfinite(loss).all())
+    r = train_series(dev, args.math, steps=args.steps, warmup=args.warmup, b=B, t=T, rank=rank, world=world, dist=dist)
     if rank == 0:
         n = max(world, 1)
-        value = n * B * args.steps / dt
-        print(json.dumps({
-            "metric": "train clips/sec", "value": round(value, 2), "unit": "clips/sec", "n_gpus": n,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        line = {
+            "metric": "train clips/sec", "value": r["clips_per_sec"], "unit": "clips/sec", "n_gpus": n,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "mixed": "f32 forward (exact), split-bf16 products in the backward GEMMs (dgrad + wgrad), f32 accumulate / storage",
                       "bf16x3": "bf16x3 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
@@ -266,7 +287,11 @@ def train_bench(args, cnn, siam, dev, dist, rank, world, barrier):
             "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = %d x %d per GPU" % (B, T),
                        "clips_per_gpu": B, "seq_len": T, "math": args.math,
                        "parallelism": "dp%d (4 gradient buckets all-reduced over RCCL under the backward)" % n},
-            "end_to_end_tflops": round(value / n * 173.8 / 1e3, 2)}))
+            "dist_backend": backend if dist is not None else None,
+            "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None,
+            "gradsync": {k: v for k, v in r.items() if k not in ("ms_per_step", "clips_per_sec")},
+            "end_to_end_tflops": round(r["clips_per_sec"] / n * 173.8 / 1e3, 2)}
+        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -336,6 +361,24 @@ def distmat_bench(args, dev, rank):
                                        "frac": round(flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}}))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process group
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and return its exit code.  This
+    parent has not touched the GPU and never does (no HIP call, no exec of a GPU-initialised process); the child's
+    rank 0 prints the JSON line to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -352,19 +395,37 @@ def main():
     ap.add_argument('--mode', default='eval', choices=['eval', 'train', 'distmat'],
                     help="eval (default): the headline clip-features/sec; train: secondary series, one "
                          "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
+    ap.add_argument('--no-train-block', action='store_true', help='skip the configs[3] `train` block of the eval line')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher check (CPU tests): every rank joins a gloo group, the ranks are counted with an '
+                         'all-reduce, rank 0 prints {"dry_run": true, "world_size": N}; no GPU is touched')
     args = ap.parse_args()
     globals()['B'], globals()['T'] = args.clips, args.seq_len
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(args.gpus, 1):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.dry_run:
+        import torch.distributed as dist
+        n = torch.ones(1)
+        if world > 1:
+            dist.init_process_group('gloo')
+            dist.all_reduce(n)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "world_size": int(n.item()), "n_gpus": args.gpus}))
+        return
     dist = None
     # GRL_DIST_BACKEND=gloo + GRL_SINGLE_DEVICE=1: functional test of the N>1 path on a box with
     # one GPU (every rank on cuda:0, collectives through gloo); the real runs use nccl = RCCL.
     backend = os.environ.get('GRL_DIST_BACKEND', 'nccl')
     if os.environ.get('GRL_SINGLE_DEVICE'):
         local = 0
-    if world > 1:
+    if world > 1 or (os.environ.get('GRL_SYNC_FORCE') == '1' and 'RANK' in os.environ):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
@@ -373,8 +434,9 @@ def main():
         else:
             dist.init_process_group(backend)
     else:
+        local = 0
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local if world > 1 else 0)
+    dev = torch.device('cuda', local)
 
     from grl_amd import engine, _lib
     from grl_amd.synthetic import synth_clips
@@ -389,7 +451,8 @@ def main():
         torch.cuda.synchronize()
 
     if args.mode == 'train':
-        return train_bench(args, cnn, siam, dev, dist, rank, world, barrier)
+        del cnn, siam
+        return train_bench(args, dev, dist, rank, world, backend)
     if args.mode == 'distmat':
         return distmat_bench(args, dev, rank)
 
@@ -400,12 +463,11 @@ def main():
     for _ in range(args.steps):
         feat = engine.extract_features(cnn, siam, clips)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dist, dev, time.perf_counter() - t0)
     assert bool(torch.isfinite(feat).all())
+    train = None
+    if not args.no_train_block and (B, T, args.math) == (32, 4, 'f32'):
+        train = train_block(dev, rank, world, dist, backend)          # every rank: the step has collectives
 
     if rank == 0:
         n = max(world, 1)
@@ -415,10 +477,12 @@ def main():
         # dense MFMA peak of the datapath (MI355X_MICROARCH.md): fp32 157.3, bf16 2500; bf16x3
         # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
         peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r02_gemm_pmc.json')
-        if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
+        traffic, pmc_name = None, None
+        for pmc_name in ('r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
+            pmc = os.path.join(ROOT, 'profiles', pmc_name)
+            if os.path.isfile(pmc):
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
+                break
         out = {
             "metric": "clip-features/sec", "value": round(value, 2), "unit": "clip-features/sec",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -437,15 +501,23 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic if args.math == 'f32' else None,
-                         "traffic_note": "HBM bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) summed "
-                                         "over the kernel's launches of ONE step, like the GFLOP figure; "
-                                         "profiles/r02_gemm_pmc.json",
+                         "traffic_note": "NOT measured by this run: read from profiles/%s (rocprofv3 FETCH_SIZE x2 + "
+                                         "WRITE_SIZE, separate passes, summed over the kernel's launches of ONE "
+                                         "step like the GFLOP figure)" % pmc_name,
                          "kernel": "gemm_f32_kernel (%s MFMA implicit-GEMM conv), %d launches/step, "
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
                                        'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
             "end_to_end_tflops": round(value / n * GFLOP_PER_FRAME * T / 1e3, 2),
         }
         out["config"]["math"] = args.math
+        if dist is not None:
+            # what the process group itself reports (the eval data path has no collective; the timed region is
+            # bracketed by dist.barrier and the per-rank times are MAX-reduced through it)
+            out["dist_backend"] = dist.get_backend()
+            out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == 'nccl' else None
+            out["world_size"] = dist.get_world_size()
+        if train is not None:
+            out["train"] = train
         if n == 1 and not args.no_alt:
             # secondary, informational: the opt-in bf16 multiplier datapaths on the SAME
             # workload, with their deviation from the exact-fp32 features measured live

@@ -12,6 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
 
+ABI_VERSION = 3       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
 _fp = C.c_void_p      # device float*
@@ -145,6 +147,10 @@ def load():
         fn = getattr(lib, name)            # AttributeError = header/library mismatch
         fn.argtypes = args
         fn.restype = res
+    got = lib.grl_abi_version()
+    if got != ABI_VERSION:                 # a stale .so would read a pointer as the stream / overrun a pack buffer
+        raise GrlHipError('libgrl_hip.so at %s has ABI version %d, this grl_amd expects %d: rebuild it '
+                          '(make -C grl_amd/csrc)' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

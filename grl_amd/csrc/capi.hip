@@ -22,4 +22,4 @@ int grl_check_launch(const char* what) {
 }
 
 extern "C" const char* grl_last_error(void) { return g_err; }
-extern "C" int grl_abi_version(void) { return 1; }
+extern "C" int grl_abi_version(void) { return GRL_ABI_VERSION; }

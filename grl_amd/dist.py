@@ -109,6 +109,40 @@ class PairShardedBatches(object):
             yield (imgs[lo:hi], pids[lo:hi], cams[lo:hi]) + tuple(e[lo:hi] for e in extra)
 
 
+class _RankBatchSampler(object):
+    """Every world-th batch of a batch sampler, starting at ``rank``: the rank's DataLoader workers then decode
+    only this rank's clips (filtering a loader's OUTPUT would still decode every batch on every rank)."""
+
+    def __init__(self, batch_sampler, rank, world):
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+
+    def __iter__(self):
+        for i, idx in enumerate(self.batch_sampler):
+            if i % self.world == self.rank:
+                yield idx
+
+    def __len__(self):
+        n = len(self.batch_sampler)
+        return (n - self.rank + self.world - 1) // self.world if n > self.rank else 0
+
+
+def shard_loader_batches(loader, rank=None, world=None):
+    """Iterable over batches ``rank, rank + world, ...`` of ``loader`` (evaluation: batch i belongs to rank
+    i % world).  A torch DataLoader is re-built around a rank-filtered batch sampler -- same dataset, workers,
+    collate function -- so a rank's host side loads 1/world of the data; any other iterable is filtered."""
+    rank, world = _rank_world(rank, world)
+    if world == 1:
+        return loader
+    bs = getattr(loader, 'batch_sampler', None)
+    if isinstance(loader, torch.utils.data.DataLoader) and bs is not None:
+        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                  timeout=loader.timeout, worker_init_fn=loader.worker_init_fn)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
+        return torch.utils.data.DataLoader(loader.dataset, batch_sampler=_RankBatchSampler(bs, rank, world), **kw)
+    return (b for i, b in enumerate(loader) if i % world == rank)
+
+
 def gather_rank_order(x, y, group=None):
     """(features, labels) of every rank concatenated in rank order -- the OIM look-up tables
     replay all ranks' updates in that order so they stay identical without a broadcast
@@ -220,18 +254,24 @@ class _HostWork(object):
 class GradSync(object):
     """Bucketed, backward-overlapped gradient averaging.
 
-    ``begin()`` (before ``loss.backward()``) registers the object with train_engine; while the
-    backward runs, every tape hands over contiguous slices of its flat gradient buffer as soon as
-    all gradients inside are final (``reduce``): an asynchronous all-reduce is launched on each --
-    torch's NCCL/RCCL work stream first waits for the kernels already queued on the compute stream,
-    i.e. the producers of that slice, and the backward kernels that follow overlap the transfer.
-    ``finish()`` (before ``optimizer.step()``) waits for the collectives, divides by the world size
-    and makes sure every ``p.grad`` holds the averaged values (autograd normally adopts the tape's
-    views as ``p.grad``, in which case nothing is copied).
+    ``begin()`` (any time before ``loss.backward()`` -- before or after the forward) registers the object with
+    train_engine; while the backward runs, every tape first declares the parameters whose gradients live in its
+    flat buffer (``own``, from Tape.backward) and then hands over contiguous slices of that buffer as soon as all
+    gradients inside are final (``reduce``): an asynchronous all-reduce is launched on each -- torch's NCCL/RCCL
+    work stream first waits for the kernels already queued on the compute stream, i.e. the producers of that
+    slice, and the backward kernels that follow overlap the transfer.  ``finish()`` (before
+    ``optimizer.step()``) waits for the collectives and makes sure every ``p.grad`` holds the averaged values
+    (autograd normally adopts the tape's views as ``p.grad``, in which case nothing is copied).  On RCCL the
+    average is taken by the collective itself (ReduceOp.AVG: no scaling pass over the 219 MB afterwards); gloo
+    (tests) sums and scales.  ``abort()`` drops the step's state without issuing a collective (error path).
 
     Parameters that never receive a gradient (Siamese.featV*, the unused uncorr verification
     head) sit in the flat buffers as zeros on every rank; their ``p.grad`` stays None everywhere --
-    ``finish`` asserts once that the None-pattern is identical across ranks."""
+    ``finish`` asserts once that the None-pattern is identical across ranks.
+
+    Bookkeeping of the last step for tests / the bench line: ``launched`` [(label, numel)] per bucket,
+    ``stray`` = number of per-parameter fall-back reductions (gradients no tape declared: none on this path),
+    ``collectives`` = every collective issued (buckets + strays + the one-off mask check)."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -240,16 +280,20 @@ class GradSync(object):
         # GRL_SYNC_FORCE=1 (tests): issue the collectives even in a world of one rank -- the only way to run the
         # RCCL call sequence (async all-reduce of flat-buffer slices under the backward) on a single-GPU box
         self.force = os.environ.get('GRL_SYNC_FORCE') == '1' and dist.is_available() and dist.is_initialized()
+        self.avg_op = (self.world > 1 or self.force) and dist.get_backend(group) == 'nccl'
         self._works = []          # (work, flat slice)
         self._owned = []          # (param, flat, offset) of every tape-owned gradient of this step
         self._checked = False
         self.launched = []        # (label, numel) per collective of the last step (tests / logging)
+        self.stray = 0
+        self.collectives = 0
 
     # -- protocol with train_engine.Tape -------------------------------------------------------
     def begin(self):
         from . import train_engine
         train_engine.set_grad_sync(self)
         self._works, self._owned, self.launched = [], [], []
+        self.stray = self.collectives = 0
 
     def own(self, param, flat, offset):
         self._owned.append((param, flat, offset))
@@ -260,10 +304,19 @@ class GradSync(object):
         self.launched.append((label, piece.numel()))
         if (self.world == 1 and not self.force) or piece.numel() == 0:
             return
+        self.collectives += 1
         if _host_staged(piece, self.group):
             self._works.append((_HostWork(piece, self.group), piece))
         else:
-            self._works.append((dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True), piece))
+            op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
+            self._works.append((dist.all_reduce(piece, op=op, group=self.group, async_op=True), piece))
+
+    def abort(self):
+        """Error path (the backward raised on this rank): forget the step WITHOUT issuing any collective -- the
+        peers are at an unknown point of the sequence, a blocking all-reduce here would hang and mask the error."""
+        from . import train_engine
+        train_engine.set_grad_sync(None)
+        self._works, self._owned = [], []
 
     def finish(self):
         from . import train_engine
@@ -271,7 +324,8 @@ class GradSync(object):
         inv = 1.0 / self.world
         for work, piece in self._works:
             work.wait()
-            piece.mul_(inv)
+            if not self.avg_op:
+                piece.mul_(inv)
         self._works = []
         stray = []
         for p, flat, off in self._owned:
@@ -283,10 +337,12 @@ class GradSync(object):
         for p in self.params:                                       # gradients no tape owns (none on this path)
             if id(p) not in owned and p.grad is not None:
                 stray.append(p)
+        self.stray = len(stray)
         if stray and self.world > 1:
             for p in stray:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
                 p.grad.mul_(inv)
+                self.collectives += 1
         if not self._checked and (self.world > 1 or self.force):
             mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32)
             if dist.get_backend(self.group) != 'gloo':              # RCCL reduces device tensors only
@@ -294,6 +350,7 @@ class GradSync(object):
             lo, hi = mask.clone(), mask.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            self.collectives += 2
             if not torch.equal(lo, hi):
                 raise RuntimeError('GradSync: the set of parameters that receive gradients differs across ranks')
             self._checked = True
@@ -301,9 +358,8 @@ class GradSync(object):
 
 
 class GradBucket(object):
-    """Non-overlapped fallback: copies every ``p.grad`` into one flat buffer, ONE blocking
-    all-reduce, copies back.  Kept for optimisers / modules whose gradients are not produced by
-    the GRL tapes; the trainer uses ``GradSync``.  Parameters whose ``p.grad`` is None contribute
+    """NOT on the GRL path (SEQTrainer and bench.py use ``GradSync``).  Utility for modules whose gradients are not
+    produced by the GRL tapes: copies every ``p.grad`` into one flat buffer, ONE blocking all-reduce, copies back.  Parameters whose ``p.grad`` is None contribute
     zeros (the layout is rank-invariant) and stay None."""
 
     def __init__(self, params):

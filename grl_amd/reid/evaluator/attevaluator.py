@@ -62,8 +62,9 @@ class ATTEvaluator(object):
         rank, world = grl_dist._rank_world(None, None)
         # data parallel (one process per GPU): batch i is extracted by rank i % world -- clips are
         # independent, there is no collective on the data path -- and the rows are all-gathered once
+        # (sharded at the batch SAMPLER: a rank's loader workers decode only its own clips)
         own = [i for i in range(len(data_loader)) if i % world == rank]
-        batches = (b for i, b in enumerate(data_loader) if i % world == rank)
+        batches = grl_dist.shard_loader_batches(data_loader, rank, world)
         mine = []
         pending, n_pending = [], 0          # dense mode: (batch index, clips [n,s,c,h,w], pids, camids)
 

@@ -73,9 +73,12 @@ class BaseTrainer(object):
                 sync.begin()
             try:
                 loss.backward()
-            finally:
+            except BaseException:
                 if sync is not None:
-                    sync.finish()
+                    sync.abort()          # no collective on the error path: the peers are somewhere else in the sequence
+                raise
+            if sync is not None:
+                sync.finish()
             optimizer1.step()
 
             batch_time.update(time.time() - end)

@@ -104,6 +104,7 @@ class Tape(object):
         self.no_grad = set() # ids of tensors that need no gradient (network input)
         self.taps = None     # optional dict of intermediates (tests)
         self._pview = {}     # id(param) -> view into the flat gradient buffer
+        self._owns = []      # (param, offset into `flat`)
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
@@ -142,16 +143,14 @@ class Tape(object):
         section's backward has run (``mark``)."""
         total = sum((p.numel() + 3) // 4 * 4 for p in params)
         flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-        sync = _grad_sync[0]
         off, offs = 0, []
         for p in params:
             n = p.numel()
             self._pview[id(p)] = flat[off:off + n].view_as(p)
-            if sync is not None:
-                sync.own(p, flat, off)
             offs.append(off)
             off += (n + 3) // 4 * 4
         self.flat = flat
+        self._owns = list(zip(params, offs))     # declared to the gradient sync when the backward starts
         self.cuts = {name: offs[i] for name, i in (cuts or {}).items()}
 
     def mark(self, name):
@@ -242,6 +241,12 @@ class Tape(object):
         return self.wc[key]
 
     def backward(self):
+        sync = _grad_sync[0]
+        if sync is not None and self.flat is not None:
+            # ownership is declared HERE, from the tape's own offset table: the sync object only has to be
+            # registered (GradSync.begin) before loss.backward(), not before the forward that built the tape
+            for p, off in self._owns:
+                sync.own(p, self.flat, off)
         fwd_math = _train_math[0]
         _train_math[0] = _TRAIN_MATH[_train_mode[0]][1]          # 'mixed': the backward GEMMs' datapath
         try:

@@ -32,6 +32,10 @@ extern "C" {
 #define GRL_ELAUNCH    -2   /* hipLaunch failed; message has the HIP error string */
 
 const char* grl_last_error(void);
+/* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
+ * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
+ * grew, grl_bn_bwd gained two pointers -- round 3: 3). */
+#define GRL_ABI_VERSION 3
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */

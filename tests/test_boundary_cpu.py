@@ -27,7 +27,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), 'libgrl_hip.so does not export %s' % n
     assert set(names) == set(_lib.exported_symbols()), \
         set(names) ^ set(_lib.exported_symbols())
-    assert lib.grl_abi_version() == 1
+    hdr = int(re.search(r'#define\s+GRL_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'grl_hip.h')).read()).group(1))
+    assert lib.grl_abi_version() == hdr == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A .so built from another round's header (struct layouts / argument lists differ) must not load."""
+    from grl_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.GrlHipError, match='ABI version'):
+        _lib.load()
+    monkeypatch.setattr(_lib, '_lib', None)
 
 
 def test_ctypes_signatures_match_the_header():

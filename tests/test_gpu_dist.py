@@ -85,6 +85,9 @@ def _worker(rank, world, port, out, backend='gloo'):
     for step, batch in enumerate(_batches()):
         tr.train(step, [batch], opt)              # the trainer keeps this rank's pair shard of the global batch
         launched.append(list(tr._bucket.launched))
+        # every gradient is tape-owned: no per-parameter fall-back reduction; 6 buckets (+ the one-off check)
+        assert tr._bucket.stray == 0, tr._bucket.stray
+        assert tr._bucket.collectives == len(tr._bucket.launched) + (2 if step == 0 else 0), tr._bucket.collectives
         snaps.append(_snapshot(mods, crits))
     out[rank] = (snaps, launched, g0)
     torch.cuda.synchronize()
@@ -259,3 +262,32 @@ def test_rccl_backend_in_a_world_of_one_rank():
     mp.spawn(_eval_worker, args=(world, port + 1, out2, 'nccl'), nprocs=1, join=True)
     ref = _run_eval()
     assert torch.equal(out2[0][0], ref[0]) and out2[0][1:] == ref[1:]
+
+
+def test_bench_gpus_2_prints_one_line_with_a_train_block():
+    """The driver's form `python bench.py --gpus N`: the parent starts N fresh ranks (before any GPU call) and
+    rank 0 prints ONE line.  On this 1-GPU box both ranks share cuda:0 and talk over gloo
+    (GRL_SINGLE_DEVICE=1 GRL_DIST_BACKEND=gloo); the line must say n_gpus 2, carry the process group's world
+    size, and a `train` block (configs[3] per GPU) whose gradient buckets were reduced with no stray
+    per-parameter collectives."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GRL_SINGLE_DEVICE='1', GRL_DIST_BACKEND='gloo')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['world_size'] == 2 and line['dist_backend'] == 'gloo'
+    assert line['metric'] == 'clip-features/sec' and line['value'] > 0 and line['scaling'] == 'weak'
+    tr = line['train']
+    assert tr['n_gpus'] == 2 and tr['dist_backend'] == 'gloo'
+    for m in ('f32', 'mixed'):
+        blk = tr[m]
+        assert blk['stray_reductions'] == 0
+        assert [lab for lab, _ in blk['allreduce_buckets']][:4] == ['trl', 'layer4', 'layer3', 'stem']
+        assert blk['allreduce_bytes_per_step'] >= 4 * 54758726
+        assert blk['gradsync_collectives_per_step'] == len(blk['allreduce_buckets'])
+        assert blk['clips_per_sec'] > 0

@@ -89,11 +89,26 @@ def _worker(rank, world, port, out):
     q_.grad = flat[4:10].view_as(q_).clone()       # autograd copied (pre-reduction values)
     sync.finish()
     sync_out = (p_.grad.clone(), q_.grad.clone(), r_.grad, list(sync.launched))
+    # the trainer's order: the forward builds the tape BEFORE GradSync.begin(); ownership is declared by
+    # Tape.backward from the tape's own offset table, so no gradient is "stray" 
+    from grl_amd import train_engine
+    tp_params = [torch.nn.Parameter(torch.zeros(6)), torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(5))]
+    tape = train_engine.Tape(torch.device('cpu'))
+    tape.reserve_param_grads(tp_params, cuts={'early': 0, 'late': 1})        # "forward"
+    tape.mark('early'); tape.mark('late')
+    sync2 = GradSync(tp_params)
+    sync2.begin()                                                          # after the forward, as SEQTrainer does
+    tape.pgrad(tp_params[1]).fill_(float(rank + 1))
+    tape.pgrad(tp_params[0]).fill_(float(10 * (rank + 1)))
+    tape.backward(); tape.flush()
+    tp_params[0].grad, tp_params[1].grad = tape.pgrad(tp_params[0]), tape.pgrad(tp_params[1])
+    sync2.finish()
+    tape_out = (tp_params[0].grad.clone(), tp_params[1].grad.clone(), sync2.stray, sync2.collectives, list(sync2.launched))
     # evaluation features sharded by batch: rank r owns batches r, r + world, ...
     feats = [(i, torch.full((2 + i, 3), float(i)), [i] * (2 + i), [7] * (2 + i)) for i in range(5) if i % world == rank]
     gf, gp, gc = gather_feature_batches(feats, 5)
     out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone(), sync_out,
-                 (gf.clone(), gp, gc))
+                 (gf.clone(), gp, gc), tape_out)
     dist.destroy_process_group()
 
 
@@ -117,6 +132,10 @@ def test_gradient_allreduce_gloo_world2():
         pg, qg, rg, launched = out[r][5]
         assert torch.equal(pg, torch.full((4,), 1.5)) and torch.equal(qg, torch.full((2, 3), 15.0)) and rg is None
         assert launched == [('late layers', 12), ('early layers', 4)]
+        g0, g1, stray, ncoll, launched = out[r][7]
+        assert torch.equal(g0, torch.full((6,), 15.0)) and torch.equal(g1, torch.full((3, 3), 1.5))
+        assert stray == 0 and launched == [('late', 20), ('early', 8)]      # 4-float aligned slots: 8 | 12 + 8
+        assert ncoll == 2 + 2                       # two buckets + the one-off None-pattern check (MIN, MAX)
         gf, gp, gc = out[r][6]
         assert gf.shape == (2 + 3 + 4 + 5 + 6, 3) and gp == [i for i in range(5) for _ in range(2 + i)]
         assert torch.equal(gf[:, 0], torch.tensor([float(i) for i in range(5) for _ in range(2 + i)])) and set(gc) == {7}
@@ -139,3 +158,65 @@ def test_sharded_pair_sampler_and_batches():
     loader = [(torch.arange(8).view(8, 1), torch.arange(8), torch.zeros(8))]
     parts = [list(PairShardedBatches(loader, rank=r, world=2))[0] for r in range(2)]
     assert parts[0][1].tolist() == [0, 1, 2, 3] and parts[1][1].tolist() == [4, 5, 6, 7]
+
+
+def test_rank_batch_sampler_shards_the_loader_not_its_output():
+    """Evaluation under world > 1: the rank's DataLoader is rebuilt around a rank-filtered batch sampler, so a
+    rank's __getitem__ calls cover only its own batches (the host decode must scale)."""
+    from torch.utils.data import DataLoader, Dataset
+    from grl_amd.dist import shard_loader_batches
+
+    class Counting(Dataset):
+        def __init__(self):
+            self.seen = []
+
+        def __len__(self):
+            return 26
+
+        def __getitem__(self, i):
+            self.seen.append(i)
+            return torch.tensor([i]), i % 7, i % 2
+
+    for world in (2, 3):
+        got = {}
+        for rank in range(world):
+            ds = Counting()
+            dl = shard_loader_batches(DataLoader(ds, batch_size=4), rank, world)
+            assert len(dl) == len([i for i in range(7) if i % world == rank])
+            got[rank] = [b[0].view(-1).tolist() for b in dl]
+            assert sorted(ds.seen) == sorted(x for b in got[rank] for x in b)        # nothing else was loaded
+        full = [list(range(i, min(i + 4, 26))) for i in range(0, 26, 4)]
+        assert [got[i % world][i // world] for i in range(7)] == full
+    assert shard_loader_batches('abc', 0, 1) == 'abc'
+    assert list(shard_loader_batches(iter(range(7)), 1, 3)) == [1, 4]
+
+
+def test_bench_launcher_starts_n_fresh_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a child (it never touches the GPU
+    itself), the two ranks rendezvous on 127.0.0.1 and rank 0 prints ONE line (--dry-run: gloo, no GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"dry_run": True, "world_size": 2, "n_gpus": 2}
+    # the command the launcher builds
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('grl_bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    real = subprocess.call
+    subprocess.call = lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0
+    try:
+        assert bench.launch_ranks(8, ['--gpus', '8', '--steps', '3']) == 0
+    finally:
+        subprocess.call = real
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '8', '--steps', '3']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

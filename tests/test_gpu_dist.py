@@ -287,7 +287,8 @@ def test_bench_gpus_2_prints_one_line_with_a_train_block():
     for m in ('f32', 'mixed'):
         blk = tr[m]
         assert blk['stray_reductions'] == 0
-        assert [lab for lab, _ in blk['allreduce_buckets']][:4] == ['trl', 'layer4', 'layer3', 'stem']
+        labs = [lab for lab, _ in blk['allreduce_buckets']]      # the two Siamese tapes ('rest') run first in the backward
+        assert [l for l in labs if l != 'rest'] == ['trl', 'layer4', 'layer3', 'stem'] and labs.count('rest') == 2
         assert blk['allreduce_bytes_per_step'] >= 4 * 54758726
         assert blk['gradsync_collectives_per_step'] == len(blk['allreduce_buckets'])
         assert blk['clips_per_sec'] > 0

@@ -149,7 +149,12 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
     tr = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev),
                     OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), None)
     params = tr._all_params()
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    # mars_train.py's optimizer (torch.optim.SGD, nesterov) in its single-kernel `fused` form: the update is one pass
+    # over parameters / gradients / momentum buffers instead of torch's four foreach passes (0.77 -> ~0.3 ms per step)
+    try:
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True, fused=True)
+    except (TypeError, RuntimeError):
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
     clips = synth_clips(b, t, seed=rank).to(dev)
     pids = (torch.arange(b, device=dev) // 2 * 7 + rank * 131) % 625
     sync = grl_dist.GradSync(params) if grl_dist.is_distributed() else None   # (GRL_SYNC_FORCE=1: also in a world of one)

@@ -26,7 +26,8 @@ class GrlGemm(C.Structure):
                                    'rnorm', 'cnorm', 'stats')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
-                                    'kw', 'stride', 'pad', 'math', 'out_f32', 'res_rows', 'res_gstride', 'kblock')]
+                                    'kw', 'stride', 'pad', 'math', 'out_f32', 'res_rows', 'res_gstride', 'kblock')] + \
+               [('splitk_ws', _fp), ('splitk_ws_floats', _i64)]
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
@@ -42,6 +43,7 @@ _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
+    'grl_conv_gemm_f32_workspace_floats': ([C.POINTER(GrlGemm)], _i64),
     'grl_gemm_bf16_tile_mode': ([C.c_int], C.c_int),
     'grl_pack_conv_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_fold': ([_fp, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp], C.c_int),

@@ -65,9 +65,25 @@ struct RowInfo {          // per staged A row: where it comes from
 // rows hold 32 bf16 (64 B) with the 16-byte chunk XOR-swizzled by (row >> 2) & 3.
 // SEG: cut the fp32 accumulation chain every SEG_STAGES stages (launched when K > 512; K <= 512
 // layers run the instantiation without the second accumulator set).
-template <int BM, int BN, bool CONV, int MATH, bool SEG, bool DMA = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const int tiles_n,
+// SPLITK (skinny K-blocked GEMMs, GrlGemm.splitk_ws): blockIdx.y is a 512-k segment of the K-blocked chain; the
+// workgroup runs that segment as a plain chain from zero and stores the raw accumulator to ws[segment][M][N].
+template <int BM, int BN, bool CONV, int MATH, bool SEG, bool DMA = false, bool SPLITK = false>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, const int tiles_n,
                                                            const int num_tiles, const int vec_epi) {
+    GrlGemm p_seg;
+    if constexpr (SPLITK) {
+        p_seg = p_in;
+        const int seg = blockIdx.y, kseg = SEG_STAGES * BK;
+        p_seg.a = p_in.a + (int64_t)seg * kseg;
+        p_seg.w = p_in.w + (int64_t)seg * kseg;
+        p_seg.K = min(kseg, p_in.K - seg * kseg);
+        p_seg.y = p_in.splitk_ws + (int64_t)seg * p_in.M * p_in.N;
+        p_seg.ldy = p_in.N;
+        p_seg.scale = p_seg.shift = p_seg.res = p_seg.gbias = p_seg.rowscale = nullptr;
+        p_seg.stats = nullptr;
+        p_seg.relu = 0;
+    }
+    const GrlGemm& p = SPLITK ? p_seg : p_in;
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;   // MFMA tiles per wave
     constexpr int ESZ = MATH == 2 ? 2 : 4;        // bytes per operand element in HBM
@@ -734,6 +750,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p, const
     }
 }
 
+// split-K finish: y = epilogue( seg[last] + (((seg[0] + seg[1]) + ...) + seg[last - 1]) ) -- the K-blocked chain's own
+// association (the kernel above adds the running total to the LAST segment's accumulator), so the result is the
+// one-workgroup K-blocked result bit for bit.  Epilogue arithmetic = the affine epilogue's: v*scale + shift (+res), ReLU.
+__global__ void splitk_finish_kernel(const GrlGemm p, const int nseg) {
+    const int64_t total = (int64_t)p.M * p.N, plane = total;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
+        float tot = 0.f;
+        for (int sgm = 0; sgm + 1 < nseg; ++sgm) tot += p.splitk_ws[(int64_t)sgm * plane + i];
+        float v = p.splitk_ws[(int64_t)(nseg - 1) * plane + i];
+        v += tot;
+        const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+        v = v * sc + sh;
+        if (p.res) v += p.res[(int64_t)m * p.ldres + n];
+        if (p.relu) v = v > 0.f ? v : 0.f;
+        p.y[(int64_t)m * p.ldy + n] = v;
+    }
+}
+
+// Which launches split K (and how much scratch that takes): fp32 K-blocked, dense, plain affine epilogue, at most 256
+// rows and so few 64 x 64 tiles that one workgroup per tile leaves the chip empty.
+int64_t splitk_floats(const GrlGemm& d) {
+    if (d.math != GRL_MATH_F32 || !d.kblock || d.conv || d.stats || d.gbias || d.rowscale || d.epilogue != GRL_EPI_AFFINE)
+        return 0;
+    if (d.M > 256 || d.K <= SEG_STAGES * BK) return 0;
+    const int64_t tiles = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    if (tiles > 128) return 0;
+    const int nseg = (d.K + SEG_STAGES * BK - 1) / (SEG_STAGES * BK);
+    return (int64_t)nseg * d.M * d.N;
+}
+
 struct TileChoice { int bm, bn; };
 
 TileChoice choose_tile(const GrlGemm& d) {
@@ -893,11 +940,26 @@ extern "C" int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc) {
     return (desc->M + t.bm - 1) / t.bm;
 }
 
+extern "C" int64_t grl_conv_gemm_f32_workspace_floats(const GrlGemm* desc) {
+    return desc ? splitk_floats(*desc) : 0;
+}
+
 extern "C" int grl_conv_gemm_f32(const GrlGemm* desc, void* stream) {
     if (!desc) return grl_fail(GRL_EINVAL, "null desc");
     const GrlGemm& d = *desc;
     if (int e = validate(d)) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (const int64_t need = splitk_floats(d); need > 0 && d.splitk_ws && d.splitk_ws_floats >= need &&
+        ((uintptr_t)d.splitk_ws & 15) == 0) {
+        const int tiles_m = (d.M + 63) / 64, tiles_n = (d.N + 63) / 64, nseg = (int)(need / ((int64_t)d.M * d.N));
+        constexpr size_t lds = (size_t)2 * (64 + 64) * BK * sizeof(float);          // (>= the 64 x 64 C staging)
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, false, 0, false, false, true>), dim3(tiles_m * tiles_n, nseg), dim3(256),
+                           lds, s, d, tiles_n, tiles_m * tiles_n, d.N % 4 == 0 ? 1 : 0);
+        const int64_t total = (int64_t)d.M * d.N;
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+                           dim3(256), 0, s, d, nseg);
+        return grl_check_launch("grl_conv_gemm_f32 (split-K)");
+    }
     if (d.math == GRL_MATH_BF16S) {
         const int r = grl_gemm_bf16_256(d, s);       // large-tile LDS-DMA kernel where it can fill the chip
         if (r != 0) return r < 0 ? r : GRL_OK;

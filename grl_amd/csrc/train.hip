@@ -72,25 +72,29 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict_
     }
 }
 
-// Sum the [rows][2][C] partial slab for 64 channels with 16 row groups (1024 threads),
-// fp64 accumulation; returns the two totals to the threads of row group 0.
+// Sum the [rows][2][C] partial slab for FCH channels with FRG row groups (1024 threads), fp64 accumulation in a
+// fixed order (a thread over its rows r = ry, ry + FRG, ..., then the row groups in index order); returns the two
+// totals to the threads of row group 0.  16 channels x 64 row groups (round 3; it was 64 x 16): the 64-channel layers
+// have up to 2048 slab rows (the stem 8192) and with 64 channels per workgroup ONE workgroup walked them, 128 dependent
+// fp64 adds per thread -- ~9 us per launch, 176 launches per training step.
+constexpr int FCH = 16, FRG = 64;
 __device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int rows, int C, int c,
-                                            double* sh /*[2][16][64]*/, double& s, double& q) {
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+                                            double* sh /*[2][FRG][FCH]*/, double& s, double& q) {
+    const int cx = threadIdx.x % FCH, ry = threadIdx.x / FCH;
     s = 0.0; q = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int r = ry; r < rows; r += 16) {
+        for (int r = ry; r < rows; r += FRG) {
             s += slab[((int64_t)r * 2 + 0) * C + c];
             q += slab[((int64_t)r * 2 + 1) * C + c];
         }
     }
-    sh[ry * 64 + cx] = s;
-    sh[1024 + ry * 64 + cx] = q;
+    sh[ry * FCH + cx] = s;
+    sh[FRG * FCH + ry * FCH + cx] = q;
     __syncthreads();
     if (ry == 0) {
         s = 0.0; q = 0.0;
-        for (int g = 0; g < 16; ++g) { s += sh[g * 64 + cx]; q += sh[1024 + g * 64 + cx]; }
+        for (int g = 0; g < FRG; ++g) { s += sh[g * FCH + cx]; q += sh[FRG * FCH + g * FCH + cx]; }
     }
 }
 
@@ -102,12 +106,12 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
     const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
     const float* __restrict__ pivot) {
-    __shared__ double sh[2 * 16 * 64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double sh[2 * FRG * FCH];
+    const int c = blockIdx.x * FCH + (threadIdx.x % FCH);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     double s, q;
     slab_totals(slab, rows, C, c, sh, s, q);
-    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    if (threadIdx.x >= FCH || c >= C) return;
     const double md = s / count;                       // mean of (x - pivot)
     double var = q / count - md * md;
     var = var > 0.0 ? var : 0.0;
@@ -230,11 +234,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                int rows, int C, double count,
                                                                float* dgamma, float* dbeta,
                                                                float* __restrict__ coef) {
-    __shared__ double sh[2 * 16 * 64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double sh[2 * FRG * FCH];
+    const int c = blockIdx.x * FCH + (threadIdx.x % FCH);
     double s, q;
     slab_totals(slab, rows, C, c, sh, s, q);
-    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    if (threadIdx.x >= FCH || c >= C) return;
     if (dbeta) dbeta[c] += (float)s;
     if (dgamma) dgamma[c] += (float)q;
     coef[c] = (float)(s / count);
@@ -729,32 +733,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 }
 
 // dW (torch layout [N][C][taps], or [N][K] when taps == 1) (+)= sum_z slab[z][n][t*C + c]
+// A lane owns FOUR consecutive slab columns (same tap: C % 4 == 0) and keeps four slabs' loads in flight; the sum
+// runs over z = 0, 1, 2, ... in that order whatever the unrolling (round 3: the scalar one-load-at-a-time form ran at
+// 1.9 TB/s, 2.1 ms per step over 112 launches).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t stride,
                                     int N, int C, int taps, int Kslab, float* __restrict__ dw,
                                     int Kout, int accumulate) {
-    if (taps > 1) {
-        // walk the slabs in THEIR order (tap-major, channel-minor: coalesced reads of `splits` slabs)
-        // and scatter into torch's [N][C][taps] -- the reads are `splits` times the writes
-        const int64_t total = (int64_t)N * Kslab;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-             i += (int64_t)gridDim.x * blockDim.x) {
-            const int n = i / Kslab, kk = i - (int64_t)n * Kslab;   // kk = t*C + c
-            const int t = kk / C, c = kk - t * C;
-            float s = 0.f;
-            for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * stride + i];
-            const int64_t dst = (int64_t)n * Kout + (int64_t)c * taps + t;
-            dw[dst] = (accumulate ? dw[dst] : 0.f) + s;
-        }
-        return;
-    }
-    const int64_t total = (int64_t)N * Kout;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+    const int K4 = Kslab >> 2;
+    const int64_t total4 = (int64_t)N * K4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int n = i / Kout, ko = i - (int64_t)n * Kout;        // taps == 1: ko = c (Kout <= Kslab: stem padding)
-        const int64_t src = (int64_t)n * Kslab + ko;
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * stride + src];
-        dw[i] = (accumulate ? dw[i] : 0.f) + s;
+        const int n = (int)(i / K4), kk = (int)(i - (int64_t)n * K4) * 4;      // slab column kk = t*C + c
+        const float* src = slab + (int64_t)n * Kslab + kk;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 0) * stride);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * stride);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(src + (int64_t)z * stride);
+        if (taps > 1) {                               // scatter into torch's [N][C][taps]
+            const int t = kk / C, c = kk - t * C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t dst = (int64_t)n * Kout + (int64_t)(c + e) * taps + t;
+                dw[dst] = (accumulate ? dw[dst] : 0.f) + s[e];
+            }
+        } else if (Kout == Kslab) {
+            f32x4* d = reinterpret_cast<f32x4*>(dw + (int64_t)n * Kout + kk);
+            if (accumulate) s = *d + s;
+            *d = s;
+        } else {                                      // stem: K padded to 160, 147 real columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kk + e < Kout) {
+                    const int64_t dst = (int64_t)n * Kout + kk + e;
+                    dw[dst] = (accumulate ? dw[dst] : 0.f) + s[e];
+                }
+        }
     }
 }
 
@@ -791,7 +810,7 @@ extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t
                                      void* stream) {
     GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
     GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, slab,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, (hipStream_t)stream, slab,
                        rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
                        eps, mean, invstd, scale, shift, pivot);
     return grl_check_launch("grl_bn_stats_finalize");
@@ -831,7 +850,7 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
                            invstd, slab_ws, M, C, mask_scale, mask_beta);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, 64)), dim3(1024), 0, s, slab_ws, rows, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, s, slab_ws, rows, C,
                        (double)M, dgamma, dbeta, coef_ws);
     const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
@@ -993,7 +1012,10 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     const int taps = d.conv ? d.kh * d.kw : 1;
     const int Cc = d.conv ? d.C : d.K;
     const int kout = d.k_out > 0 ? d.k_out : d.K;      // stem: K padded to 160, 147 real
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)d.N * (taps > 1 ? d.K : kout))), dim3(256), 0, s, d.workspace,
+    GRL_REQUIRE(taps == 1 || kout == d.K, "wgrad conv: k_out is a dense-only option");
+    GRL_REQUIRE(kout == d.K || ((uintptr_t)d.dw & 3) == 0, "wgrad: dw alignment");
+    GRL_REQUIRE(kout != d.K || taps > 1 || ((uintptr_t)d.dw & 15) == 0, "wgrad: dw must be 16-byte aligned");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)d.N * (d.K / 4))), dim3(256), 0, s, d.workspace,
                        real_splits, a.slab_stride, d.N, Cc, taps, d.K, d.dw, kout, d.accumulate);
     return grl_check_launch("grl_conv_wgrad_f32");
 }

@@ -140,6 +140,9 @@ def augment_normalize_u8(clips, params):
     return y
 
 
+SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
+
+
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False,
@@ -172,6 +175,11 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
     lib = _lib.load()
+    if SPLITK and kblock and conv is None and M <= 256 and K > 512:      # skinny K-blocked GEMM: split-K scratch (include/grl_hip.h)
+        need = lib.grl_conv_gemm_f32_workspace_floats(C.byref(d))
+        if need > 0:
+            ws = torch.empty(need, dtype=torch.float32, device=y.device)
+            d.splitk_ws, d.splitk_ws_floats = ptr(ws), need
     if want_stats:
         rows = lib.grl_conv_gemm_f32_stat_rows(C.byref(d))
         slab = torch.empty((rows, 2, N), dtype=torch.float32, device=y.device)

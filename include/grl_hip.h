@@ -97,9 +97,19 @@ typedef struct GrlGemm {
                               sgemm; ~4 % slower on K >= 1024).  The train-mode forward sets it -- ReLU
                               masks, hence parameter gradients, agree with the reference's only as well
                               as the forward does; 0 = ONE k-ordered fmaf chain (eval path, evaluator). */
+    /* Optional split-K scratch (round 3).  A skinny K-blocked GEMM (M <= 256, a handful of tiles: the per-clip
+     * linears of GCE / TRL / the Siamese heads in train mode) walks K = 1024..2048 in ONE workgroup per tile --
+     * latency-bound, ~60 us at 1 % MFMA busy.  With scratch the 512-k segments of the K-blocked chain run as
+     * separate workgroups (grid.y = segments) writing raw partials [segment][M][N], and a second kernel adds them
+     * in segment order and applies the epilogue: bit-identical to the one-workgroup K-blocked result.  NULL or
+     * fewer floats than grl_conv_gemm_f32_workspace_floats() asks for: the one-workgroup form runs. */
+    float*  splitk_ws;
+    int64_t splitk_ws_floats;
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
+/* floats of split-K scratch the call above can use for this shape (0: it would not split) */
+int64_t grl_conv_gemm_f32_workspace_floats(const GrlGemm* desc);
 /* Kernel-tuning / test hook of the GRL_MATH_BF16S datapath: which launches take the 256 x 256
  * LDS-DMA tile (gemm_bf16.hip): -1 = automatic (enough tiles to fill the chip; the default),
  * 0 = never, 1 = whenever the shape is legal.  Returns the previous mode; results do not depend

@@ -345,6 +345,28 @@ def pair_loss(score, tar_probe, tar_gallery):
     return loss, prec
 
 
+def trainer_forward(state, sstate, vstate, clips, pids, lut_c, lut_u, scalar=30.0, momentum=0.5):
+    """SEQTrainer._forward (reid/train/trainer.py:107-170): frame-level id loss on x_corr and clip-level id loss on
+    the Siamese-pooled rows (ONE criterion, one LUT: :126,:138), 20 x pair verification (:143-149), batch-hard soft
+    triplet (:141), id loss of the uncorrelated branch through Siamese_video (:151-152); the uncorrelated
+    verification loss is evaluated upstream (:157-162) but never added (:165-168).  Returns
+    (all_loss, (x_uncorr, x_corr), (siamese_out, siamese_video_out)).  The LUTs are updated in place by the backward
+    in autograd order (oim.py:24-26)."""
+    b, t = clips.shape[:2]
+    xu, xc = grl_forward(state, clips, train=True)
+    l_frame, _ = oim_loss(xc.reshape(b * t, -1), pids.repeat_interleave(t), lut_c, scalar, momentum)
+    tp, tg = pids[0::2], pids[1::2]
+    target = torch.cat((tp, tg))
+    cls, sout = siamese_forward(sstate, xc, train=True)
+    l_vid, _ = oim_loss(sout, target, lut_c, scalar, momentum)
+    l_tri = triplet_soft_batch_hard(sout, target).mean()
+    prob = F.softmax(cls.view(-1, 2), dim=-1).view(cls.shape[0], cls.shape[1], 2)[:, :, 1]
+    l_ver, _ = pair_loss(prob, tp, tg)
+    _, vout = siamese_video_forward(vstate, xu, train=True)
+    l_unc, _ = oim_loss(vout, target, lut_u, scalar, momentum)
+    return l_unc + (l_frame + l_vid + l_ver * 20 + l_tri), (xu, xc), (sout, vout)
+
+
 # ----------------------------------------------------------------------------
 # training input transforms (flip / erase / ToTensor / Normalize)
 # ----------------------------------------------------------------------------

@@ -226,6 +226,110 @@ def oim_golden(ref_models, path):
     np.savez_compressed(path, **out)
 
 
+def install_oim_bridge():
+    """Points ``reid.loss.oim.oim`` at a static autograd.Function that runs the reference's OIM.forward /
+    OIM.backward BODIES (oim.py:14-27) on a stub ``self`` -- see oim_golden above.  Returns (module, order)."""
+    import importlib
+    ref_oim = importlib.import_module('reid.loss.oim')
+    order = []
+
+    class Bridge(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, inputs, targets, lut, momentum):
+            stub = types.SimpleNamespace(lut=lut, momentum=momentum, needs_input_grad=(True, False))
+            stub.save_for_backward = lambda *t: setattr(stub, 'saved_tensors', t)
+            ctx.stub = stub
+            return ref_oim.OIM.forward(stub, inputs, targets)
+
+        @staticmethod
+        def backward(ctx, grad_outputs):
+            order.append(int(ctx.stub.saved_tensors[0].size(0)))
+            gi, _ = ref_oim.OIM.backward(ctx.stub, grad_outputs)
+            return gi, None, None, None
+
+    ref_oim.oim = lambda inputs, targets, lut, momentum=0.5: Bridge.apply(inputs, targets, lut, momentum)
+    return ref_oim, order
+
+
+def grad_record(prefix, named_grads, out, n=256):
+    keys = []
+    for k, gten in named_grads:
+        if gten is None:
+            continue
+        ga = gten.detach().reshape(-1).double()
+        if float(ga.abs().max()) < 1e-12:
+            continue
+        idx = torch.linspace(0, ga.numel() - 1, min(n, ga.numel())).long()
+        out['%s.%s.val' % (prefix, k)] = ga[idx].float().numpy()
+        out['%s.%s.norm' % (prefix, k)] = np.array(ga.norm().item())
+        out['%s.%s.proj' % (prefix, k)] = np.array([float((ga * sign_pattern(ga.numel(), sd)).sum()) for sd in range(4)])
+        keys.append(k)
+    out[prefix + '.keys'] = np.array(keys)
+
+
+def trainer_step_golden(ref_models, path, B=8, T=4):
+    """(I) ONE training step of the reference's own SEQTrainer (reid/train/trainer.py:107-170 `_forward` as
+    shipped + `loss.backward()`, :53-55) on CPU: conditioned CNN weights, structured clips, B x T = 8 x 4 (four
+    (anchor, positive) pairs), unit-norm LUTs.  OIMLoss goes through the bridge above (the reference's
+    forward / backward bodies; its legacy Function cannot be applied on this torch); TripletLoss, PairLoss,
+    the Siamese heads and the 5-term composition run unmodified.  Stored: the loss, the three precisions, the
+    model outputs handed to the heads, every parameter gradient of the two Siamese heads (samples, norm,
+    projections) and of the CNN (same packing), the LUT rows of the batch identities after the step and the
+    heads' BatchNorm running statistics."""
+    sys.path.insert(0, REPO)
+    from grl_amd.synthetic import synth_state_dict, synth_clips_structured
+    from reid.train import trainer as ref_trainer
+    from reid.loss import pairloss
+    ref_oim, order = install_oim_bridge()
+    cnn = ref_models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625)
+    cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'), strict=True)
+    siam = ref_models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'), strict=True)
+    siamv = ref_models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'), strict=True)
+    g = np.random.Generator(np.random.PCG64(23))
+    NC = 625
+
+    def unit(a):
+        return (a / np.linalg.norm(a, axis=-1, keepdims=True)).astype(np.float32)
+    lut_c, lut_u = unit(g.standard_normal((NC, 2048))), unit(g.standard_normal((NC, 2048)))
+    crit_c = ref_oim.OIMLoss(2048, NC, scalar=30, momentum=0.5)
+    crit_u = ref_oim.OIMLoss(2048, NC, scalar=30, momentum=0.5)
+    crit_c.lut.copy_(torch.from_numpy(lut_c)); crit_u.lut.copy_(torch.from_numpy(lut_u))
+    tr = ref_trainer.SEQTrainer(cnn, siam, siamv, pairloss.PairLoss(), crit_c, crit_u, None)
+    cnn.train(); siam.train(); siamv.train()
+    pids = torch.tensor([5, 5, 9, 9, 300, 300, 77, 77][:B])
+    clips = synth_clips_structured(B, T, seed=3)
+    taps = {}
+    h = cnn.register_forward_hook(lambda m, i, o: taps.update(xu=o[0], xc=o[1]))
+    loss, p_u, p_v, p_f = tr._forward([clips], pids, 0, 0)
+    h.remove()
+    taps['xu'].retain_grad(); taps['xc'].retain_grad()
+    loss.backward()
+    out = {'meta.B': np.array(B), 'meta.T': np.array(T), 'pids': pids.numpy(),
+           'lut_seed': np.array(23), 'loss': np.array(loss.item(), np.float64),
+           'prec': np.array([float(p_u), float(p_v), float(p_f)]),
+           'x_uncorr': taps['xu'].detach().numpy(), 'x_corr_s4': taps['xc'].detach()[..., ::4].numpy(),
+           'grad.x_uncorr': taps['xu'].grad.numpy(), 'grad.x_corr_s4': taps['xc'].grad[..., ::4].numpy(),
+           'oim_backward_rows': np.array(order)}
+    grad_record('gs', [(k, p.grad) for k, p in siam.named_parameters()], out)
+    grad_record('gv', [(k, p.grad) for k, p in siamv.named_parameters()], out)
+    # (parameters whose gradient is analytically zero -- a bias in front of a train-mode BatchNorm -- hold fp32 noise:
+    # the conditioned fixture identified them with its float64 run; the same 194 tensors are recorded here)
+    live = set(str(k) for k in np.load(os.path.join(HERE, 'grl_train_cond_b8t4.npz'))['meta.keys'])
+    grad_record('gc', [(k, p.grad) for k, p in cnn.named_parameters() if k in live], out)
+    rows = sorted(set(pids.tolist()))
+    out['lut_rows'] = np.array(rows)
+    out['lut_c1'], out['lut_u1'] = crit_c.lut[rows].numpy().copy(), crit_u.lut[rows].numpy().copy()
+    for name, m in (('siamese', siam), ('siamese_video', siamv)):
+        for k, v in m.state_dict().items():
+            if 'running' in k:
+                out['stat.%s.%s' % (name, k)] = v.numpy().copy()
+    np.savez_compressed(path, **out)
+    print('trainer step golden: loss %.6f prec %s, OIM backward order (rows) %s, %d + %d + %d gradient tensors, %d bytes' % (
+        loss.item(), out['prec'], order, len(out['gs.keys']), len(out['gv.keys']), len(out['gc.keys']), os.path.getsize(path)))
+
+
 def cmc_golden(attev, evaf, path):
     """(G) eva_functions.cmc / mean_ap (eva_functions.py:18-115) with the reference's defaults and
     with first_match_break=True, on the same synthetic features as the evaluator fixture."""
@@ -250,7 +354,7 @@ def sign_pattern(n, salt):
     return (((h >> 13) & 1) * 2 - 1).double()
 
 
-def train_golden_conditioned(ref_models, path, B=8, T=4):
+def train_golden_conditioned(ref_models, path, B=8, T=4, clip_seed=3, xu_stride=1, xc_stride=4):
     """(B') the tight train-parity fixture: 'conditioned' synthetic weights (near-identity residual
     blocks, ReLU inputs shifted positive -- grl_amd/synthetic.py) on structured clips, B x T = 8 x 4.
     Two fp32 runs of a ReLU network differ mostly by ReLU-mask flips of pre-activations within
@@ -263,7 +367,7 @@ def train_golden_conditioned(ref_models, path, B=8, T=4):
     from grl_amd.synthetic import synth_state_dict, synth_clips_structured
     cnn = ref_models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625)
     sd = synth_state_dict(cnn, seed=0, profile='conditioned')
-    clips = synth_clips_structured(B, T, seed=3)
+    clips = synth_clips_structured(B, T, seed=clip_seed)
     g = np.random.Generator(np.random.PCG64(7))
     r1 = torch.from_numpy(g.standard_normal((B, 2048)).astype(np.float32))
     r2 = torch.from_numpy(g.standard_normal((B, T, 2048)).astype(np.float32))
@@ -278,9 +382,11 @@ def train_golden_conditioned(ref_models, path, B=8, T=4):
                     {k: p.grad.detach().double() for k, p in cnn.named_parameters() if p.grad is not None},
                     {k: v.detach().double().clone() for k, v in cnn.state_dict().items() if 'running' in k or 'tracked' in k})
     a, b = runs[torch.float32], runs[torch.float64]
-    out = {'meta.B': np.array(B), 'meta.T': np.array(T),
-           'x_uncorr': a[0].float().numpy(), 'x_corr_s4': a[1][..., ::4].float().numpy(),   # every 4th column
-           'f64.x_uncorr': b[0].float().numpy(), 'f64.x_corr_s4': b[1][..., ::4].float().numpy()}
+    # (outputs: every xu_stride-th / xc_stride-th column -- the big-batch fixtures keep a strided sample)
+    out = {'meta.B': np.array(B), 'meta.T': np.array(T), 'meta.clip_seed': np.array(clip_seed),
+           'meta.xu_stride': np.array(xu_stride), 'meta.xc_stride': np.array(xc_stride),
+           'x_uncorr': a[0][..., ::xu_stride].float().numpy(), 'x_corr_s4': a[1][..., ::xc_stride].float().numpy(),
+           'f64.x_uncorr': b[0][..., ::xu_stride].float().numpy(), 'f64.x_corr_s4': b[1][..., ::xc_stride].float().numpy()}
     keys, worst = [], 0.0
     for k in a[2]:
         ga, gb = a[2][k].reshape(-1), b[2][k].reshape(-1)
@@ -301,9 +407,9 @@ def train_golden_conditioned(ref_models, path, B=8, T=4):
     out['meta.keys'] = np.array(keys)
     np.savez_compressed(path, **out)
     errs = sorted(float(out['g.%s.ref_l2err' % k]) for k in keys)
-    print('conditioned train golden: %d gradient tensors; reference fp32 vs its float64: outputs %.1e / %.1e, '
+    print('conditioned train golden B x T = %d x %d: %d gradient tensors; reference fp32 vs its float64: outputs %.1e / %.1e, '
           'gradient L2 median %.1e p90 %.1e max %.1e; %d bytes' % (
-              len(keys), float((a[0] - b[0]).abs().max() / b[0].abs().max()),
+              B, T, len(keys), float((a[0] - b[0]).abs().max() / b[0].abs().max()),
               float((a[1] - b[1]).abs().max() / b[1].abs().max()),
               errs[len(errs) // 2], errs[int(0.9 * len(errs))], errs[-1], os.path.getsize(path)))
 
@@ -514,12 +620,22 @@ def main():
                         triplet=tri.numpy(), score=score.numpy(), tp=tp.numpy(), tg=tg.numpy(),
                         pair_loss=np.array(pl.item()), pair_prec=np.array(float(prec)))
     train_golden_conditioned(ref_models, os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
+    round3_goldens(ref_models)
     oim_golden(ref_models, os.path.join(HERE, 'oim.npz'))
     cmc_golden(attev, evaf, os.path.join(HERE, 'cmc_q40_g400.npz'))
     augment_golden(os.path.join(HERE, 'augment.npz'))
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+def round3_goldens(ref_models):
+    """BASELINE configs[1] at full size (32 x 4: a strided sample of the outputs), the TRL recurrence length of
+    configs[2] (T = 8) in train mode, and one step of the reference's trainer."""
+    train_golden_conditioned(ref_models, os.path.join(HERE, 'grl_train_cond_b4t8.npz'), B=4, T=8, clip_seed=5)
+    train_golden_conditioned(ref_models, os.path.join(HERE, 'grl_train_cond_b32t4.npz'), B=32, T=4, clip_seed=9,
+                             xu_stride=8, xc_stride=32)
+    trainer_step_golden(ref_models, os.path.join(HERE, 'trainer_step_cond_b8t4.npz'))
 
 
 def main_train_only():
@@ -541,6 +657,12 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'cond':
         torch.manual_seed(0); torch.set_num_threads(8)
         train_golden_conditioned(import_reference()[0], os.path.join(HERE, 'grl_train_cond_b8t4.npz'))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round3':
+        torch.manual_seed(0); torch.set_num_threads(8)
+        round3_goldens(import_reference()[0])
+    elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
+        torch.manual_seed(0); torch.set_num_threads(8)
+        trainer_step_golden(import_reference()[0], os.path.join(HERE, 'trainer_step_cond_b8t4.npz'))
     elif len(sys.argv) > 1 and sys.argv[1] == 'augment':
         import_reference()
         augment_golden(os.path.join(HERE, 'augment.npz'))

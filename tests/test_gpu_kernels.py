@@ -42,9 +42,41 @@ def test_gemm_bit_exact_vs_fma_chain(dev, M, N, K):
     assert np.array_equal(got, ref), 'max diff %g' % np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize('M,N,K', [(32, 1024, 2048), (64, 2048, 1024), (256, 32, 2048), (5, 128, 2048), (33, 68, 1568)])
+def test_gemm_splitk_equals_one_workgroup_kblock(dev, M, N, K):
+    """Skinny K-blocked GEMMs (per-clip linears of GCE / TRL / the Siamese heads in train mode) run their 512-k
+    segments as separate workgroups when the caller hands scratch (GrlGemm.splitk_ws); the finish kernel adds the
+    segments in the chain's own association, so the result -- epilogue included -- is the one-workgroup result bit
+    for bit."""
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) + 0.5).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    sc, sh = (torch.rand(N, generator=g) + 0.5).to(dev), torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    lib = engine._lib.load()
+    for kw in (dict(), dict(scale=sc, shift=sh, relu=True), dict(shift=sh, res=res), dict(scale=sc, res=res, relu=True)):
+        outs = []
+        for split in (True, False):
+            engine.SPLITK = split
+            try:
+                y = torch.full((M, N), float('nan'), device=dev)
+                engine.gemm(a, w, y, M, N, K, kblock=True, **kw)
+                outs.append(y)
+            finally:
+                engine.SPLITK = True
+        assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all()), kw.keys()
+    d = engine.GrlGemm()
+    d.M, d.N, d.K, d.kblock, d.math = M, N, K, 1, 0
+    assert lib.grl_conv_gemm_f32_workspace_floats(C.byref(d)) == -(-K // 512) * M * N
+    d.M = 4096
+    assert lib.grl_conv_gemm_f32_workspace_floats(C.byref(d)) == 0
+
+
 @pytest.mark.parametrize('M,N,K,conv', [(300, 200, 2048, None), (64, 130, 4608, None), (4096, 512, 1024, None),
                                         (2 * 16 * 8, 96, 9 * 128, (16, 8, 128, 16, 8, 3, 3, 1, 1)),
-                                        (128, 64, 512, None)])
+                                        (128, 64, 512, None), (32, 1024, 2048, None), (256, 32, 2048, None),
+                                        (7, 100, 1024, None)])
 def test_gemm_kblock_bit_exact_and_more_accurate(dev, M, N, K, conv):
     """GrlGemm.kblock (the train-mode forward's K-blocked accumulation: the chain cut every 512 k,
     segments summed in order) equals the C oracle's blocked chain bit for bit on every tile shape,

@@ -180,8 +180,10 @@ def _fresh_cnn_conditioned():
     return cnn.cuda()
 
 
-@pytest.mark.parametrize('math', ['f32', 'mixed'])
-def test_train_forward_backward_matches_reference_golden_1e3(golden, math):
+@pytest.mark.parametrize('fname,math', [('grl_train_cond_b8t4.npz', 'f32'), ('grl_train_cond_b8t4.npz', 'mixed'),
+                                        ('grl_train_cond_b4t8.npz', 'f32'), ('grl_train_cond_b32t4.npz', 'f32'),
+                                        ('grl_train_cond_b32t4.npz', 'mixed')])
+def test_train_forward_backward_matches_reference_golden_1e3(golden, fname, math):
     """(``math``: the default exact-fp32 step, and 'mixed' = the same forward with split-bf16 backward GEMMs.)
     THE end-to-end backward pin: HIP train-mode forward + backward of the whole CNN against the
     reference's fp32 autograd run (tests/golden/grl_train_cond_b8t4.npz), B x T = 8 x 4, EVERY
@@ -190,23 +192,26 @@ def test_train_forward_backward_matches_reference_golden_1e3(golden, math):
     'conditioned' weights / structured clips keep the ReLU-flip floor (what ANY two fp32 runs
     differ by) at ~2e-4 -- measured in the fixture as the reference fp32 vs its own float64 -- so
     a 1 % gradient bug in any layer fails here (tolerance model: tests/train_cond_check.py).
-    The chaotic default-weight fixtures below stay as stress tests."""
+    The chaotic default-weight fixtures below stay as stress tests.  Round 3: the same pin at B x T = 4 x 8 (the
+    T = 8 recurrence of BASELINE configs[2]: the memo-block BatchNorms run 8 times per forward) and at configs[1]'s
+    FULL size 32 x 4 (grl_train_cond_b32t4.npz: the reference's fp32 + float64 runs at that size)."""
     import train_cond_check as TC
     from grl_amd.synthetic import synth_clips_structured
-    g = golden('grl_train_cond_b8t4.npz')
+    g = golden(fname)
     B, T = int(g['meta.B']), int(g['meta.T'])
+    clip_seed = int(g['meta.clip_seed']) if 'meta.clip_seed' in g.files else 3
     cnn = _fresh_cnn_conditioned()
     cnn.train()
     r1, r2 = TC.upstream(B, T)
     from grl_amd import train_engine as TE
     old = TE.set_math(math)
     try:
-        xu, xc = cnn(synth_clips_structured(B, T, seed=3).cuda())
+        xu, xc = cnn(synth_clips_structured(B, T, seed=clip_seed).cuda())
         ((xu * r1.cuda()).sum() + (xc * r2.cuda()).sum()).backward()
     finally:
         TE.set_math(old)
     grads = {k: p.grad for k, p in cnn.named_parameters() if p.grad is not None}
-    TC.check(g, xu, xc, grads, cnn.state_dict(), out_tol=1e-4, grad_tol=1e-3, label='HIP ' + math)
+    TC.check(g, xu, xc, grads, cnn.state_dict(), out_tol=1e-4, grad_tol=1e-3, label='HIP %s %dx%d' % (math, B, T))
 
 
 @pytest.mark.parametrize('B,T,seed,fname,tol_xu', [(2, 4, 0, 'grl_train_b2t4.npz', 5e-2),
@@ -636,6 +641,50 @@ def test_reference_script_flow_through_dropin(tmp_path):
         assert 'Mean AP:' in r.stdout and 'Rank-1:' in r.stdout
         seen[tuple(extra)] = [l for l in r.stdout.splitlines() if l.startswith(('Mean AP', 'Rank-'))]
     assert seen[()] == seen[('--uint8',)] and seen[('--dense',)] == seen[('--dense', '--uint8')]
+
+
+def test_trainer_step_matches_reference_trainer_golden_1e3(golden):
+    """grl_amd's SEQTrainer on HIP against ONE step of the reference's own SEQTrainer (trainer.py:107-170 `_forward`
+    as shipped + loss.backward(); tests/golden/trainer_step_cond_b8t4.npz: B x T = 8 x 4, conditioned CNN weights,
+    unit-norm LUTs): the 5-term loss, the model outputs handed to the heads, the gradients that come back into the
+    CNN outputs and EVERY parameter gradient of the Siamese head at <= 1e-3 (north_star's figure), the LUT rows of
+    the batch identities after the three OIM backwards, the heads' BatchNorm running statistics."""
+    import trainer_step_check as TS
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.synthetic import synth_clips_structured
+    g = golden('trainer_step_cond_b8t4.npz')
+    B, T = int(g['meta.B']), int(g['meta.T'])
+    dev = torch.device('cuda:0')
+    cnn = _fresh_cnn_conditioned()
+    _, siam, siamv = _fresh_models()
+    crit_c, crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+    lut_c, lut_u = TS.luts(g)
+    crit_c.lut.copy_(lut_c); crit_u.lut.copy_(lut_u)
+    trainer = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+    cnn.train(); siam.train(); siamv.train()
+    taps = {}
+    h = cnn.register_forward_hook(lambda m, i, o: taps.update(xu=o[0], xc=o[1]))
+    loss, p_u, p_v, p_f = trainer._forward([synth_clips_structured(B, T, seed=3).to(dev)], torch.from_numpy(g['pids']).to(dev), 0, 0)
+    h.remove()
+    taps['xu'].retain_grad(); taps['xc'].retain_grad()
+    loss.backward()
+    print('trainer step: loss hip %.6f reference %.6f' % (loss.item(), float(g['loss'])))
+    assert abs(loss.item() - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    assert [float(p_u), float(p_v), float(p_f)] == list(g['prec'])
+    assert TS.rel(taps['xu'].detach().cpu().numpy(), g['x_uncorr']) < 1e-4
+    assert TS.rel(taps['xc'].detach().cpu().numpy()[..., ::4], g['x_corr_s4']) < 1e-4
+    assert TS.rel(taps['xu'].grad.cpu().numpy(), g['grad.x_uncorr']) < 1e-3
+    assert TS.rel(taps['xc'].grad.cpu().numpy()[..., ::4], g['grad.x_corr_s4']) < 1e-3
+    TS.check_grads(g, 'gs', {k: p.grad for k, p in siam.named_parameters() if p.grad is not None}, 1e-3, 'HIP')
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in siamv.parameters())     # (as upstream: 'gv' is empty)
+    TS.check_grads(g, 'gc', {k: p.grad for k, p in cnn.named_parameters() if p.grad is not None}, 1e-3, 'HIP', cnn_model=True)
+    rows = torch.from_numpy(g['lut_rows']).to(dev)
+    assert TS.rel(crit_c.lut[rows].cpu().numpy(), g['lut_c1']) < 1e-4 and TS.rel(crit_u.lut[rows].cpu().numpy(), g['lut_u1']) < 1e-4
+    for name, m in (('siamese', siam), ('siamese_video', siamv)):
+        sd = m.state_dict()
+        for k in [k for k in g.files if k.startswith('stat.%s.' % name)]:
+            assert TS.rel(sd[k[len('stat.%s.' % name):]].cpu().numpy(), g[k]) < 1e-4, k
 
 
 def test_trainer_loss_composition_matches_cpu_restatement():

@@ -177,15 +177,18 @@ def test_cmc_and_mean_ap_match_reference(golden):
         E.cmc(dist, qp, gp, qc, gc, single_gallery_shot=True)
 
 
-def test_train_conditioned_fixture_pins_oracle(golden):
-    """The tight train fixture (conditioned weights, structured clips, B x T = 8 x 4; every
-    parameter gradient): the oracle's forward + autograd backward against the reference's."""
+@pytest.mark.parametrize('fname', ['grl_train_cond_b8t4.npz', 'grl_train_cond_b4t8.npz', 'grl_train_cond_b32t4.npz'])
+def test_train_conditioned_fixture_pins_oracle(golden, fname):
+    """The tight train fixtures (conditioned weights, structured clips; every parameter gradient) -- B x T = 8 x 4,
+    4 x 8 (the TRL recurrence length of BASELINE configs[2]) and the full 32 x 4 of configs[1]: the oracle's
+    forward + autograd backward against the reference's."""
     import contextlib, io
     import train_cond_check as TC
     from grl_amd.reid import models
     from grl_amd.synthetic import synth_state_dict, synth_clips_structured
-    g = golden('grl_train_cond_b8t4.npz')
+    g = golden(fname)
     B, T = int(g['meta.B']), int(g['meta.T'])
+    clip_seed = int(g['meta.clip_seed']) if 'meta.clip_seed' in g.files else 3
     with contextlib.redirect_stdout(io.StringIO()):
         cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
     sd = synth_state_dict(cnn, seed=0, profile='conditioned')
@@ -193,10 +196,45 @@ def test_train_conditioned_fixture_pins_oracle(golden):
         if v.dtype.is_floating_point and 'running' not in k:
             v.requires_grad_(True)
     r1, r2 = TC.upstream(B, T)
-    xu, xc = O.grl_forward(sd, synth_clips_structured(B, T, seed=3), train=True)
+    xu, xc = O.grl_forward(sd, synth_clips_structured(B, T, seed=clip_seed), train=True)
     ((xu * r1).sum() + (xc * r2).sum()).backward()
     TC.check(g, xu, xc, {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None},
-             {k: v.detach() for k, v in sd.items()}, out_tol=1e-5, grad_tol=1e-3, label='oracle')
+             {k: v.detach() for k, v in sd.items()}, out_tol=1e-5, grad_tol=1e-3, label='oracle %dx%d' % (B, T))
+
+
+def test_trainer_step_fixture_pins_oracle(golden):
+    """ONE step of the reference's own SEQTrainer (`_forward` + backward, B x T = 8 x 4, conditioned CNN weights;
+    tests/golden/trainer_step_cond_b8t4.npz): the oracle's restatement of trainer.py:107-170 gives the same loss,
+    the same gradients into both Siamese heads and the CNN, and the same LUT rows after the three OIM backwards."""
+    import contextlib, io
+    import trainer_step_check as TS
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_state_dict, synth_clips_structured
+    g = golden('trainer_step_cond_b8t4.npz')
+    B, T = int(g['meta.B']), int(g['meta.T'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    sd = synth_state_dict(cnn, seed=0, profile='conditioned')
+    ssd = synth_state_dict(siam, seed=0, prefix='siamese.')
+    svd = synth_state_dict(siamv, seed=0, prefix='siamese_video.')
+    for d in (sd, ssd, svd):
+        for k, v in d.items():
+            if v.dtype.is_floating_point and 'running' not in k:
+                v.requires_grad_(True)
+    lut_c, lut_u = TS.luts(g)
+    loss, (xu, xc), _ = O.trainer_forward(sd, ssd, svd, synth_clips_structured(B, T, seed=3), torch.from_numpy(g['pids']),
+                                          lut_c, lut_u)
+    xu.retain_grad(); xc.retain_grad()
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss'])), (loss.item(), float(g['loss']))
+    assert TS.rel(xu.detach().numpy(), g['x_uncorr']) < 1e-5 and TS.rel(xc.detach().numpy()[..., ::4], g['x_corr_s4']) < 1e-5
+    assert TS.rel(xu.grad.numpy(), g['grad.x_uncorr']) < 1e-4 and TS.rel(xc.grad.numpy()[..., ::4], g['grad.x_corr_s4']) < 1e-4
+    TS.check_grads(g, 'gs', {k: v.grad for k, v in ssd.items() if v.grad is not None}, 1e-4, 'oracle')
+    TS.check_grads(g, 'gc', {k: v.grad for k, v in sd.items() if v.grad is not None}, 1e-3, 'oracle', cnn_model=True)
+    rows = g['lut_rows']
+    assert TS.rel(lut_c[rows].numpy(), g['lut_c1']) < 1e-5 and TS.rel(lut_u[rows].numpy(), g['lut_u1']) < 1e-5
 
 
 def test_augmentation_params_and_oracle_match_reference_transforms(golden):

@@ -1,6 +1,7 @@
-"""Shared checker for the tight train-parity fixture tests/golden/grl_train_cond_b8t4.npz
-(generated from the reference by make_golden.py:train_golden_conditioned): used by the CPU test
-that pins the oracle and by the `-m gpu` test that pins the HIP forward + backward.
+"""Shared checker for the tight train-parity fixtures tests/golden/grl_train_cond_b{8t4,4t8,32t4}.npz
+(generated from the reference by make_golden.py:train_golden_conditioned -- B x T = 8 x 4, the T = 8
+recurrence of BASELINE configs[2], and configs[1]'s full 32 x 4): used by the CPU tests
+that pin the oracle and by the `-m gpu` tests that pin the HIP forward + backward.
 
 Tolerances.  Outputs: 1e-4 relative (max norm).  Every parameter gradient, relative L2 over the
 stored samples: 1e-3 -- north_star's figure -- wherever the reference's own fp32 run is within
@@ -35,7 +36,9 @@ def check(g, xu, xc, grads, stats, out_tol=1e-4, grad_tol=1e-3, label='', max_ou
     def rel(a, b):
         a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
         return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
-    xu = xu.detach().double().cpu().numpy(); xc = xc.detach().double().cpu().numpy()[..., ::4]
+    xs_u = int(g['meta.xu_stride']) if 'meta.xu_stride' in g.files else 1       # (big-batch fixtures keep strided outputs)
+    xs_c = int(g['meta.xc_stride']) if 'meta.xc_stride' in g.files else 4
+    xu = xu.detach().double().cpu().numpy()[..., ::xs_u]; xc = xc.detach().double().cpu().numpy()[..., ::xs_c]
     e_u, e_c = rel(xu, g['x_uncorr']), rel(xc, g['x_corr_s4'])
     print('%s outputs vs reference fp32: x_uncorr %.2e x_corr %.2e; vs its float64 run: %.2e %.2e (reference fp32 '
           'itself: %.2e %.2e)' % (label, e_u, e_c, rel(xu, g['f64.x_uncorr']), rel(xc, g['f64.x_corr_s4']),

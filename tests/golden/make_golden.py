@@ -312,7 +312,8 @@ def trainer_step_golden(ref_models, path, B=8, T=4):
            'x_uncorr': taps['xu'].detach().numpy(), 'x_corr_s4': taps['xc'].detach()[..., ::4].numpy(),
            'grad.x_uncorr': taps['xu'].grad.numpy(), 'grad.x_corr_s4': taps['xc'].grad[..., ::4].numpy(),
            'oim_backward_rows': np.array(order)}
-    grad_record('gs', [(k, p.grad) for k, p in siam.named_parameters()], out)
+    # (featQ.bias / featK.bias sit in front of a train-mode BatchNorm1d, Siamese.py:84-94: analytically zero, fp32 noise)
+    grad_record('gs', [(k, p.grad) for k, p in siam.named_parameters() if k not in ('featQ.bias', 'featK.bias')], out)
     grad_record('gv', [(k, p.grad) for k, p in siamv.named_parameters()], out)
     # (parameters whose gradient is analytically zero -- a bias in front of a train-mode BatchNorm -- hold fp32 noise:
     # the conditioned fixture identified them with its float64 run; the same 194 tensors are recorded here)

@@ -248,7 +248,10 @@ def secondary_block(dev, cnn, siam, steps):
     del c3
     out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
         m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
-        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'mixed', 'bf16x3'))}
+        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'mixed', 'bf16x3', 'bf16s'))}
+    v = train_step_ms(dev, 'bf16s', b=64, t=8)
+    out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = {
+        "ms_per_step": round(v, 2), "clips_per_sec": round(64 / v * 1e3, 1), "frames_per_sec": round(512 / v * 1e3)}
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
     qd, gd = qf.to(dev), gf.to(dev)
     for _ in range(2):
@@ -276,8 +279,8 @@ def train_bench(args, dev, dist, rank, world, backend):
     forward (train-mode BN) + reference loss composition + HIP backward + the bucketed
     gradient all-reduce when world > 1 + SGD(nesterov) step, on B x T synthetic
     pair-interleaved clips per rank (mars_train.py -b 32 --seq_len 4)."""
-    if args.math not in ('f32', 'mixed', 'bf16x3', 'bf16'):
-        raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16')
+    if args.math not in ('f32', 'mixed', 'bf16x3', 'bf16', 'bf16s'):
+        raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16 | bf16s')
     r = train_series(dev, args.math, steps=args.steps, warmup=args.warmup, b=B, t=T, rank=rank, world=world, dist=dist)
     if rank == 0:
         n = max(world, 1)
@@ -287,7 +290,8 @@ def train_bench(args, dev, dist, rank, world, backend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "mixed": "f32 forward (exact), split-bf16 products in the backward GEMMs (dgrad + wgrad), f32 accumulate / storage",
                       "bf16x3": "bf16x3 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
-                      "bf16": "bf16 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad"}[args.math],
+                      "bf16": "bf16 products (fwd + dgrad GEMMs), f32 accumulate / storage / wgrad",
+                      "bf16s": "bf16 storage (activations, saved tensors, activation gradients), bf16 MFMA, f32 accumulate / statistics / parameter gradients"}[args.math],
             "data": "synthetic",
             "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = %d x %d per GPU" % (B, T),
                        "clips_per_gpu": B, "seq_len": T, "math": args.math,

@@ -36,7 +36,7 @@ MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
 class GrlWgrad(C.Structure):
     _fields_ = [(n, _fp) for n in ('dz', 'x', 'dw', 'workspace')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'ldz', 'ldx', 'k_out', 'accumulate', 'conv', 'H', 'W',
-                                    'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math')]
+                                    'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math', 'in_bf16')]
 
 
 _SIGNATURES = {
@@ -122,6 +122,21 @@ _SIGNATURES = {
     'grl_temporal_mean_bf16': ([_fp, _fp, C.c_int, C.c_int, _i64, _fp], C.c_int),
     'grl_add_strided_bf16': ([_fp, _fp, _fp, C.c_int, _i64, _i64, _fp], C.c_int),
     'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    # bf16-storage training twins (train_bf16.hip)
+    'grl_bn_apply_centered_bf16': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_col_stats_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_bn_bwd_bf16': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp], C.c_int),
+    'grl_relu_bwd_bf16': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
+    'grl_axpby_bf16': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
+    'grl_axpy_strided_bf16': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),
+    'grl_dilate2_bf16': ([_fp, _fp] + [C.c_int] * 9 + [_fp], C.c_int),
+    'grl_maxpool3x3s2_bwd_bf16': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_im2col_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_gate_apply_bf16': ([_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_gate_bwd_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_add_rowbcast_bf16': ([_fp, _fp, _i64, _i64, _i64, C.c_float, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_sqdiff_bwd_bf16': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _i64, C.c_int, _fp], C.c_int),
+    'grl_cast_f32': ([_fp, _fp, _i64, _fp], C.c_int),
 }
 
 _lib = None

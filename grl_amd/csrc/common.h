@@ -32,3 +32,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // 128 x 128 family), < 0 = error.
 struct GrlGemm;
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s);
+
+// train.hip: BatchNorm-backward finalize over an fp32 partial slab (shared with the bf16-storage kernels of train_bf16.hip)
+int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,
+                               hipStream_t s);

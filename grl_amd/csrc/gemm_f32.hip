@@ -513,6 +513,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                 constexpr int LPR8 = WTN / 8, RPI8 = 64 / LPR8;
                 const int lrow = lane / LPR8, lcol = (lane % LPR8) * 8;
                 const int n = n0 + wn * WTN + lcol;
+                // train-mode BatchNorm (bf16-storage training): column sums of the RAW fp32 accumulator -- before it is
+                // rounded to bf16 -- per lane over its rows, then lanes / wave rows below, as in the fp32 epilogue
+                f32x4 ssum8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 if (n < p.N) {
                     f32x4 sc[2], sh[2];
 #pragma unroll
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                             if (p.gbias)
                                 v[u] += *reinterpret_cast<const f32x4*>(
                                     p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n + 4 * u);
+                            if (p.stats) { ssum8[u] += v[u]; ssq8[u] += v[u] * v[u]; }
                             v[u] = v[u] * sc[u] + sh[u];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -545,6 +549,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                             }
                         }
                         *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (int64_t)m * p.ldy + n) = o;
+                    }
+                }
+                if (p.stats) {
+#pragma unroll
+                    for (int o2 = LPR8; o2 < 64; o2 <<= 1) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                ssum8[u][e] += __shfl_xor(ssum8[u][e], o2);
+                                ssq8[u][e] += __shfl_xor(ssq8[u][e], o2);
+                            }
+                    }
+                    __syncthreads();                               // every wave has read its C slab: LDS is free
+                    float* red = smem;                             // [2 wm][2][BN]
+                    if (lrow == 0) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + wn * WTN + lcol + 4 * u) = ssum8[u];
+                            *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + wn * WTN + lcol + 4 * u) = ssq8[u];
+                        }
+                    }
+                    __syncthreads();
+                    for (int c = tid; c < BN; c += 256) {
+                        const int nn = n0 + c;
+                        if (nn < p.N) {
+                            p.stats[((int64_t)tile_m * 2 + 0) * p.N + nn] = red[0 * BN + c] + red[2 * BN + c];
+                            p.stats[((int64_t)tile_m * 2 + 1) * p.N + nn] = red[1 * BN + c] + red[3 * BN + c];
+                        }
                     }
                 }
                 return;
@@ -859,7 +892,7 @@ int launch_math(const GrlGemm& d, hipStream_t s) {
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const int vec_epi = ((!d.stats || MATH != 2) && d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
+    const int vec_epi = (d.N % 4 == 0 && d.ldy % 4 == 0 && al16(d.y) &&
                          (!d.res || (d.ldres % 4 == 0 && al16(d.res))) && al16(d.scale) && al16(d.shift) &&
                          al16(d.gbias) && al16(d.cnorm)) ? 1 : 0;
     if (MATH == 2 && !vec_epi)
@@ -913,7 +946,9 @@ int validate(const GrlGemm& d) {
         return grl_fail(GRL_EINVAL, "gemm: unknown math mode");
     if (d.math == GRL_MATH_BF16S) {
         if (d.K % 64 || (d.conv && d.C % 64)) return grl_fail(GRL_EINVAL, "gemm bf16s: K (and C) must be multiples of 64");
-        if (d.epilogue != GRL_EPI_AFFINE || d.stats) return grl_fail(GRL_EINVAL, "gemm bf16s: affine epilogue only");
+        if (d.epilogue != GRL_EPI_AFFINE) return grl_fail(GRL_EINVAL, "gemm bf16s: affine epilogue only");
+        if (d.stats && (d.N % 8 || d.out_f32 || d.rowscale))
+            return grl_fail(GRL_EINVAL, "gemm bf16s: stats need N % 8 == 0, bf16 output, no rowscale");
         if (d.N % 4 || d.ldy % 4 || (d.res && d.ldres % 4) || d.lda % 8 || d.ldw % 8 ||
             ((uintptr_t)d.y & 15) || ((uintptr_t)d.res & 15))
             return grl_fail(GRL_EINVAL, "gemm bf16s: N, ldy, ldres % 4, lda, ldw % 8, aligned pointers");

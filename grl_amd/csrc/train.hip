@@ -732,6 +732,164 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     }
 }
 
+// Weight gradient with bf16 operands IN HBM (train_engine math 'bf16s'): dz [M][ldz] and X are bf16 tensors, the
+// products run on v_mfma_f32_32x32x16_bf16, accumulation / slabs / dW are fp32.  Same LDS planes and transpose reads
+// as wgrad_kernel<128, 128, .., 1> -- [m][out] bf16 rows of 256 bytes, 16-byte chunk XOR-swizzled by
+// ((m & 3) << 2) | ((m >> 2) & 3), fragments by ds_read_b64_tr_b16 -- but the staging pass is a plain 16-byte copy
+// (8 channels per item, two items per thread and operand) instead of a convert-and-split.  One tile shape, 128 x 128,
+// for every layer: columns past N / K are zero-filled, and in the implicit-GEMM form every staged item resolves its
+// OWN tap from its column (tap = k / C), so a tile may straddle taps (C = 64: two taps per tile).
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void wgrad_b16in_kernel(const WgradArgs p, const int tiles_k) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, MT = 2, NT = 2;
+    constexpr int PLANE = 32 * 256;                       // bytes of one bf16 plane: 32 rows x 128 columns
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const sm8 = reinterpret_cast<char*>(smem);      // [2 buf][A plane, B plane]
+    const __bf16* const dzp = reinterpret_cast<const __bf16*>(p.dz);
+    const __bf16* const xp = reinterpret_cast<const __bf16*>(p.x);
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * BM, k0 = tile_k * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_begin = blockIdx.y * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    // staging: item i of a thread is (row = tid / 16 + 16 i, chunk = tid % 16): columns 8 chunk .. 8 chunk + 7
+    const int s_row = tid >> 4, s_chunk = tid & 15;
+    const bool a_ok = n0 + 8 * s_chunk < p.N;
+    const int kcol = k0 + 8 * s_chunk;
+    const bool b_ok = kcol < p.K;
+    int ky = 0, kx = 0, cc = kcol;
+    if (CONV && b_ok) { const int tap = kcol / p.C; cc = kcol - tap * p.C; ky = tap / p.kw; kx = tap - ky * p.kw; }
+    int pimg[2], poy[2], pox[2];
+    const int adv_y = 32 / p.Wo, adv_x = 32 - adv_y * p.Wo;
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m_begin + s_row + 16 * i, hw = p.Ho * p.Wo;
+            pimg[i] = m / hw;
+            const int rem = m - pimg[i] * hw;
+            poy[i] = rem / p.Wo;
+            pox[i] = rem - poy[i] * p.Wo;
+        }
+    }
+    uint4 areg[2], breg[2];
+    auto load_stage = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + s_row + 16 * i;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (m < m_end && a_ok) v = *reinterpret_cast<const uint4*>(dzp + (int64_t)m * p.ldz + n0 + 8 * s_chunk);
+            areg[i] = v;
+            uint4 w = {0u, 0u, 0u, 0u};
+            if (CONV) {
+                const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
+                if (m < m_end && b_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    w = *reinterpret_cast<const uint4*>(xp + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + cc);
+                pox[i] += adv_x;                              // this row's pixel, one stage (32 rows) further on
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
+                poy[i] += adv_y;
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
+            } else if (m < m_end && b_ok) {
+                w = *reinterpret_cast<const uint4*>(xp + (int64_t)m * p.ldx + kcol);
+            }
+            breg[i] = w;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char* const base = sm8 + buf * (2 * PLANE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = s_row + 16 * i;
+            const int off = 256 * row + 16 * (s_chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+            *reinterpret_cast<uint4*>(base + off) = areg[i];
+            *reinterpret_cast<uint4*>(base + PLANE + off) = breg[i];
+        }
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nst = (m_end - m_begin + 31) / 32;
+    const int fhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    if (nst > 0) {
+        load_stage(m_begin);
+        store_stage(0);
+    }
+    __syncthreads();
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(m_begin + (st + 1) * 32);
+        const unsigned sbase = lds_base + buf * (2 * PLANE);
+        unsigned aaddr[MT][2], baddr[NT][2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int row = 8 * (g >> 1) + 4 * rd + q;
+            const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int col = wm * WTM + i * 32 + 16 * (g & 1) + 4 * pp;
+                aaddr[i][rd] = sbase + 256 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wn * WTN + j * 32 + 16 * (g & 1) + 4 * pp;
+                baddr[j][rd] = sbase + PLANE + 256 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+            }
+        }
+#define GRL_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define GRL_FRAG(lo4, hi4) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {               // two k-steps of 16 rows per 32-row stage
+            s16x4 ra[MT][2], rb[NT][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (ks == 0) GRL_TR(ra[i][rd], aaddr[i][rd], 0);
+                    else GRL_TR(ra[i][rd], aaddr[i][rd], 4096);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (ks == 0) GRL_TR(rb[j][rd], baddr[j][rd], 0);
+                    else GRL_TR(rb[j][rd], baddr[j][rd], 4096);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(GRL_FRAG(ra[i][0], ra[i][1]), GRL_FRAG(rb[j][0], rb[j][1]),
+                                                                        acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef GRL_TR
+#undef GRL_FRAG
+        if (st + 1 < nst) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = p.slab + (int64_t)blockIdx.y * p.slab_stride;
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int k = k0 + wn * WTN + j * 32 + col_l;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (n < p.N) out[(int64_t)n * p.K + k] = acc[i][j][r];
+            }
+    }
+}
+
 // dW (torch layout [N][C][taps], or [N][K] when taps == 1) (+)= sum_z slab[z][n][t*C + c]
 // A lane owns FOUR consecutive slab columns (same tap: C % 4 == 0) and keeps four slabs' loads in flight; the sum
 // runs over z = 0, 1, 2, ... in that order whatever the unrolling (round 3: the scalar one-load-at-a-time form ran at
@@ -787,6 +945,13 @@ inline int grid_for(int64_t n, int block = 256) {
 #define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
 
 extern "C" int grl_col_stats_rows(int M) { return (M + CHUNK - 1) / CHUNK; }
+
+int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, s, slab, rows, C, count, dgamma,
+                       dbeta, coef);
+    return grl_check_launch("bn_bwd_finalize");
+}
 
 extern "C" int grl_col_stats(const float* x, float* slab, int M, int C, int ld, const float* pivot, void* stream) {
     GRL_REQUIRE(x && slab && M > 0 && C % 4 == 0 && ld % 4 == 0, "col_stats: bad args");
@@ -850,8 +1015,7 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
                            invstd, slab_ws, M, C, mask_scale, mask_beta);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, s, slab_ws, rows, C,
-                       (double)M, dgamma, dbeta, coef_ws);
+    if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
                        coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta);
@@ -953,6 +1117,7 @@ static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
 }
 
 static void wgrad_tile(const GrlWgrad& d, int* bm, int* bn) {
+    if (d.in_bf16) { *bm = 128; *bn = 128; return; }      // one tile shape: edges are zero-filled, tiles may straddle taps
     *bm = d.N >= 128 ? 128 : 64;
     const int cdiv = d.conv ? d.C : d.K;
     *bn = (cdiv % 128 == 0) ? 128 : 64;
@@ -972,6 +1137,11 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     GRL_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.ldz % 4 == 0, "wgrad: bad shape");
     GRL_REQUIRE(d.N % 4 == 0 && d.K % 4 == 0, "wgrad: N and K must be multiples of 4");
     GRL_REQUIRE(d.math == GRL_MATH_F32 || d.math == GRL_MATH_BF16X3 || d.math == GRL_MATH_BF16, "wgrad: unknown math mode");
+    if (d.in_bf16) {
+        GRL_REQUIRE(d.N % 8 == 0 && d.K % 8 == 0 && d.ldz % 8 == 0 && (d.conv || d.ldx % 8 == 0) &&
+                    ((uintptr_t)d.dz & 15) == 0 && ((uintptr_t)d.x & 15) == 0, "wgrad bf16-in: N, K, ld % 8, 16-byte aligned operands");
+        GRL_REQUIRE(!d.conv || d.C % 8 == 0, "wgrad bf16-in conv: C % 8");
+    }
     if (d.conv) {
         GRL_REQUIRE(d.C % 64 == 0 && d.K == d.kh * d.kw * d.C, "wgrad conv: C % 64, K = kh*kw*C");
         GRL_REQUIRE(d.M % (d.Ho * d.Wo) == 0, "wgrad conv: M must be nimg*Ho*Wo");
@@ -998,7 +1168,10 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
         if (d.conv) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true>), grid, dim3(256), lds, s, a, tiles_k);  \
         else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, false>), grid, dim3(256), lds, s, a, tiles_k);        \
     } while (0)
-    if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16X3) {
+    if (d.in_bf16) {
+        if (d.conv) hipLaunchKernelGGL((wgrad_b16in_kernel<true>), grid, dim3(256), (size_t)4 * 32 * 256, s, a, tiles_k);
+        else hipLaunchKernelGGL((wgrad_b16in_kernel<false>), grid, dim3(256), (size_t)4 * 32 * 256, s, a, tiles_k);
+    } else if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16X3) {
         if (d.conv) hipLaunchKernelGGL((wgrad_kernel<128, 128, true, 3>), grid, dim3(256), lds, s, a, tiles_k);
         else hipLaunchKernelGGL((wgrad_kernel<128, 128, false, 3>), grid, dim3(256), lds, s, a, tiles_k);
     } else if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16) {

@@ -185,13 +185,29 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
         slab = torch.empty((rows, 2, N), dtype=torch.float32, device=y.device)
         d.stats = ptr(slab)
         check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+        if _DEBUG_SYNC:
+            _debug_sync('gemm+stats %s math %d conv %s' % ((M, N, K), d.math, conv))
         return y, slab
     check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+    if _DEBUG_SYNC:
+        _debug_sync('gemm %s math %d conv %s' % ((M, N, K), d.math, conv))
     return y
+
+
+_DEBUG_SYNC = bool(os.environ.get('GRL_DEBUG_SYNC'))      # debugging only: name every launch on stderr and wait for it
+
+
+def _debug_sync(name):
+    import sys
+    sys.stderr.write('[grl] %s\n' % name)
+    sys.stderr.flush()
+    torch.cuda.synchronize()
 
 
 def _call(name, *args):
     check(getattr(_lib.load(), name)(*args, _lib.stream()), name)
+    if _DEBUG_SYNC:
+        _debug_sync(name)
 
 
 # ----------------------------------------------------------------------------

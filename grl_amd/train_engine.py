@@ -32,8 +32,16 @@ from .engine import _call, _new, EvalPlan, PIX
 #            the parameter gradients -- the ReLU masks are those of 'f32', bit for bit), BACKWARD GEMMs (data and
 #            weight gradients) split-bf16: every product carries ~2^-16 relative error instead of 2^-24, no
 #            mask can flip, so the gradients stay within ~1e-5 of the 'f32' ones at ~2/3 of the step time.
+#   'bf16s'  bf16 STORAGE (BASELINE configs[2], "bf16 MFMA", as the training batch it describes): every
+#            [pixels][channels] activation, saved tensor and activation gradient of the CNN is bf16 in HBM, every
+#            GEMM -- forward, data gradient, weight gradient -- runs bf16 products with fp32 accumulation;
+#            BatchNorm statistics (taken from the fp32 accumulators), per-channel vectors, the per-clip heads,
+#            parameter gradients, master weights and the optimizer stay fp32.  Kernels: train_bf16.hip, the
+#            bf16-in weight gradient of train.hip, the bf16-storage GEMM with the statistics epilogue.
 _TRAIN_MATH = {'f32': (MATH_F32, MATH_F32), 'bf16x3': (engine.MATH_BF16X3, engine.MATH_BF16X3),
-               'bf16': (engine.MATH_BF16, engine.MATH_BF16), 'mixed': (MATH_F32, engine.MATH_BF16X3)}
+               'bf16': (engine.MATH_BF16, engine.MATH_BF16), 'mixed': (MATH_F32, engine.MATH_BF16X3),
+               'bf16s': (MATH_F32, MATH_F32)}       # (bf16s: the datapath follows the operand dtype, see gemm below)
+BF16 = torch.bfloat16
 _train_mode = [__import__('os').environ.get('GRL_TRAIN_MATH', 'f32')]
 _train_math = [_TRAIN_MATH[_train_mode[0]][0]]       # datapath of the GEMMs issued NOW (Tape.backward switches it)
 
@@ -50,11 +58,45 @@ def get_math():
     return _train_mode[0]
 
 
-def gemm(*args, **kw):
+def gemm(a, w, *args, **kw):
+    if a.dtype == BF16:                  # bf16-storage operands: the bf16-storage datapath, whatever the mode says
+        kw['math'] = engine.MATH_BF16S
+        if w.dtype != BF16:
+            w = cast16(w)
+        return engine.gemm(a, w, *args, **kw)
     kw.setdefault('math', _train_math[0])
     if kw['math'] == MATH_F32:
         kw.setdefault('kblock', True)    # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock)
-    return engine.gemm(*args, **kw)
+    return engine.gemm(a, w, *args, **kw)
+
+
+def _b16(t):
+    return t is not None and t.dtype == BF16
+
+
+def _k(name, t):
+    """Entry point for tensor ``t``'s storage type: the bf16 twin (train_bf16.hip / pointwise_bf16.hip) or the fp32 one."""
+    return name + '_bf16' if t.dtype == BF16 else name
+
+
+def _newl(shape, like):
+    return torch.empty(shape, dtype=like.dtype, device=like.device)
+
+
+def cast16(t):
+    """fp32 -> bf16 copy (weights: once per step through Tape.w16)."""
+    src = t if t.is_contiguous() else t.contiguous()
+    out = torch.empty(src.shape, dtype=BF16, device=src.device)
+    _call('grl_cast_bf16', ptr(src), ptr(out), src.numel())
+    return out
+
+
+def add_rowbcast(dst, v, M, Cc, rpg, scale, acc):
+    """dst[m][c] (+)= v[m / rpg][c] * scale (grl_add_rowbcast / its bf16-storage twin)."""
+    if dst.dtype == BF16:
+        _call('grl_add_rowbcast_bf16', ptr(dst), ptr(v), M, Cc, rpg, C.c_float(scale), acc, 1 if v.dtype == BF16 else 0)
+    else:
+        _call('grl_add_rowbcast', ptr(dst), ptr(v), M, Cc, rpg, C.c_float(scale), acc)
 
 FRAME_C = 2048
 
@@ -105,6 +147,7 @@ class Tape(object):
         self.taps = None     # optional dict of intermediates (tests)
         self._pview = {}     # id(param) -> view into the flat gradient buffer
         self._owns = []      # (param, offset into `flat`)
+        self.b16 = False     # bf16-storage step: the packed / transposed weights below are handed out as bf16 copies
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
@@ -112,17 +155,17 @@ class Tape(object):
         if cur is None:
             self.g[id(t)] = g
         else:
-            _call('grl_axpby', ptr(cur), ptr(g), ptr(cur), C.c_float(1.0), C.c_float(1.0), cur.numel())
+            _call(_k('grl_axpby', cur), ptr(cur), ptr(g), ptr(cur), C.c_float(1.0), C.c_float(1.0), cur.numel())
 
     def add_masked(self, t, dy, act):
         """grad(t) += dy * (act > 0)"""
         cur = self.g.get(id(t))
         if cur is None:
-            cur = _new(tuple(dy.shape), dy)
+            cur = _newl(tuple(dy.shape), dy)
             self.g[id(t)] = cur
-            _call('grl_relu_bwd', ptr(dy), ptr(act), ptr(cur), dy.numel(), 0)
+            _call(_k('grl_relu_bwd', dy), ptr(dy), ptr(act), ptr(cur), dy.numel(), 0)
         else:
-            _call('grl_relu_bwd', ptr(dy), ptr(act), ptr(cur), dy.numel(), 1)
+            _call(_k('grl_relu_bwd', dy), ptr(dy), ptr(act), ptr(cur), dy.numel(), 1)
 
     def full_grad(self, t):
         cur = self.g.get(id(t))
@@ -203,16 +246,29 @@ class Tape(object):
                 self.wc[key] = out
             else:
                 self.wc[key] = wd.contiguous().view(wd.shape[0], -1)
+            if self.b16:
+                self.wc[key] = cast16(self.wc[key])
         return self.wc[key]
 
-    def w_t(self, w2d, key_obj, ld=None):
-        """Transposed [K][N] of a dense weight [N][K] (row stride ld) for the data gradient."""
-        key = ('t', id(key_obj), w2d.data_ptr())
+    def w16(self, w, key_obj=None):
+        """bf16 copy of a dense fp32 weight for this step (identity when the step is fp32)."""
+        if not self.b16:
+            return w
+        key = ('16', id(key_obj) if key_obj is not None else w.data_ptr(), tuple(w.shape))
+        if key not in self.wc:
+            self.wc[key] = cast16(w)
+        return self.wc[key]
+
+    def w_t(self, w2d, key_obj, ld=None, like=None):
+        """Transposed [K][N] of a dense weight [N][K] (row stride ld) for the data gradient; ``like``: the gradient
+        tensor it will multiply -- a bf16 one gets a bf16 copy (the per-clip heads stay fp32 in every mode)."""
+        b16 = like is not None and like.dtype == BF16
+        key = ('t', id(key_obj), w2d.data_ptr(), b16)
         if key not in self.wc:
             n, k = w2d.shape
             out = torch.empty(k, n, dtype=torch.float32, device=self.dev)
             _call('grl_transpose', ptr(w2d), ptr(out), n, k, ld or k)
-            self.wc[key] = out
+            self.wc[key] = cast16(out) if b16 else out
         return self.wc[key]
 
     def w_dgrad(self, conv):
@@ -223,7 +279,7 @@ class Tape(object):
             n, c, k, _ = wd.shape
             out = torch.empty(c, k * k * n, dtype=torch.float32, device=self.dev)
             _call('grl_pack_dgrad_weight', ptr(wd), ptr(out), n, c, k, k)
-            self.wc[key] = out
+            self.wc[key] = cast16(out) if self.b16 else out
         return self.wc[key]
 
     def w_dgrad_s2(self, conv, py, px):
@@ -238,6 +294,8 @@ class Tape(object):
             kxs = [1] if px == 0 else [2, 0]
             wd = w.detach()[:, :, kys][:, :, :, kxs]              # [N][cin][kh][kw]
             self.wc[key] = wd.permute(1, 2, 3, 0).contiguous().view(w.shape[1], -1)
+            if self.b16:
+                self.wc[key] = cast16(self.wc[key])
         return self.wc[key]
 
     def backward(self):
@@ -268,6 +326,10 @@ def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate
     d.ldx = ldx or K
     d.k_out = k_out
     d.accumulate = accumulate
+    if dz.dtype == BF16:                   # bf16-storage operands (both): plain bf16 products, fp32 dW
+        if x.dtype != BF16:
+            raise _lib.GrlHipError('wgrad: dz is bf16 but x is %s' % x.dtype)
+        d.in_bf16 = 1
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
@@ -275,6 +337,8 @@ def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate
     ws = torch.empty(lib.grl_wgrad_workspace_floats(C.byref(d)), dtype=torch.float32, device=dz.device)
     d.workspace = ptr(ws)
     check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream()), 'grl_conv_wgrad_f32')
+    if engine._DEBUG_SYNC:
+        engine._debug_sync('wgrad %s bf16-in %d conv %s' % ((M, N, K), d.in_bf16, conv))
 
 
 # A layer's weight gradient depends on nothing downstream of it and nothing waits for it before the optimizer (or the
@@ -310,7 +374,7 @@ def colsum_into(g, M, Ccols, out, ld=None):
     """out[c] += sum_m g[m][c]."""
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Ccols), g)
-    _call('grl_col_stats', ptr(g), ptr(slab), M, Ccols, ld or Ccols, None)
+    _call(_k('grl_col_stats', g), ptr(g), ptr(slab), M, Ccols, ld or Ccols, None)
     _call('grl_slab_sum', ptr(slab), rows, 2 * Ccols, Ccols, ptr(out), 1)
 
 
@@ -320,7 +384,7 @@ class _BNState(object):
 
 def bn_apply(z, st, res, y, M, Cc, relu):
     """y = relu?((z - mean) * gamma*invstd + beta + res) -- centred first, as torch's train kernel."""
-    _call('grl_bn_apply_centered', ptr(z), ptr(st.mean), ptr(st.scale), ptr(st.beta), ptr(res), ptr(y), M, Cc,
+    _call(_k('grl_bn_apply_centered', z), ptr(z), ptr(st.mean), ptr(st.scale), ptr(st.beta), ptr(res), ptr(y), M, Cc,
           1 if relu else 0)
 
 
@@ -344,11 +408,11 @@ def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc
     """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
     same pass that writes dz).  ``mask_from_z``: y = relu(bn(z)) without a residual -- the ReLU mask is recomputed
     from z with the forward's own operations (st.scale, st.beta) instead of reading the activation."""
-    dz = _new((M, Cc), dy)
+    dz = _newl((M, Cc), dy)
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Cc), dy)
     coef = _new((2, Cc), dy)
-    _call('grl_bn_bwd', ptr(dy), ptr(z), None if mask_from_z else ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+    _call(_k('grl_bn_bwd', dy), ptr(dy), ptr(z), None if mask_from_z else ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma),
           ptr(dz), ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc,
           ptr(st.scale) if mask_from_z else None, ptr(st.beta) if mask_from_z else None)
     return dz
@@ -374,11 +438,11 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         geom = (H, W, cin, Ho, Wo, k, k, stride, pad)
     M = n_img * Ho * Wo
-    z = _new((M, N), x)
+    z = _newl((M, N), x)
     _, slab = gemm(x, wf, z, M, N, K, ldw=ldw or wf.shape[1], gbias=gbias, rows_per_group=rpg,
                    stats=True, conv=geom)
     st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
-    a = _new((M, N), x)
+    a = _newl((M, N), x)
     bn_apply(z, st, res, a, M, N, relu)
 
     def bwd():
@@ -391,7 +455,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             gres = tp.g.get(id(res))
             gacc = 1 if gres is not None else 0
             if gres is None:
-                gres = tp.g[id(res)] = _new((M, N), da)
+                gres = tp.g[id(res)] = _newl((M, N), da)
         dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
                          gres=gres, gres_acc=gacc, mask_from_z=relu and res is None)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
@@ -420,16 +484,16 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     # if x already has a gradient (residual joins), accumulate in the GEMM epilogue
     # (res = y = that tensor: every element is read and written by the same lane)
     cur = tp.g.get(id(x))
-    dx = cur if cur is not None else _new((Min, cin), dz)
+    dx = cur if cur is not None else _newl((Min, cin), dz)
     if k == 1:
         w2d = w.detach().view(N, -1)
-        wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1])
+        wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1], like=dz)
         if stride != 1:
             # a 1x1 stride-2 conv only reads the even pixels: its data gradient is a GEMM at OUTPUT
             # resolution scattered to them (a quarter of the zero-stuffed GEMM's FLOPs)
-            small = _new((M, cin), dz)
+            small = _newl((M, cin), dz)
             gemm(dz, wt, small, M, cin, N)
-            _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin, 1 if cur is not None else 0, 0, 0)
+            _call(_k('grl_dilate2', small), ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin, 1 if cur is not None else 0, 0, 0)
         else:
             gemm(dz, wt, dx, Min, cin, N, res=cur)
     elif stride == 1:
@@ -443,13 +507,13 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
             for px in (0, 1):
                 wc = tp.w_dgrad_s2(conv, py, px)                  # [cin][taps][N]
                 kh, kw = 1 + py, 1 + px
-                small = _new((M, cin), dz)
+                small = _newl((M, cin), dz)
                 gemm(dz, wc, small, M, cin, kh * kw * N, conv=(Ho, Wo, N, Ho, Wo, kh, kw, 1, 0))
-                _call('grl_dilate2', ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin,
+                _call(_k('grl_dilate2', small), ptr(small), ptr(dx), n_img, Ho, Wo, H, W, cin,
                       1 if cur is not None else 2, py, px)
     else:
-        src = _new((Min, N), dz)
-        _call('grl_dilate2', ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N, 0, 0, 0)
+        src = _newl((Min, N), dz)
+        _call(_k('grl_dilate2', dz), ptr(dz), ptr(src), n_img, Ho, Wo, H, W, N, 0, 0, 0)
         gemm(src, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
     if cur is None:
         tp.g[id(x)] = dx
@@ -460,22 +524,22 @@ def biased_conv_relu(tp, x, M, conv):
     w = conv.weight
     N, K = w.shape[0], w.shape[1]
     w2d = w.detach().view(N, K)
-    a = _new((M, N), x)
-    gemm(x, w2d, a, M, N, K, shift=conv.bias.detach(), relu=True)
+    a = _newl((M, N), x)
+    gemm(x, tp.w16(w2d, w), a, M, N, K, shift=conv.bias.detach(), relu=True)
 
     def bwd():
         da = tp.take(a)
         if da is None:
             return
-        g = _new((M, N), da)
-        _call('grl_relu_bwd', ptr(da), ptr(a), ptr(g), da.numel(), 0)
+        g = _newl((M, N), da)
+        _call(_k('grl_relu_bwd', da), ptr(da), ptr(a), ptr(g), da.numel(), 0)
         colsum_into(g, M, N, tp.pgrad(conv.bias))
         wgrad_async(tp, g, x, tp.pgrad(w), M, N, K)
         cur = tp.g.get(id(x))
         if cur is not None and tuple(cur.shape) != (M, K):
             cur = cur.view(M, K)
-        dx = cur if cur is not None else _new((M, K), g)
-        gemm(g, tp.w_t(w2d, w), dx, M, K, N, res=cur)
+        dx = cur if cur is not None else _newl((M, K), g)
+        gemm(g, tp.w_t(w2d, w, like=g), dx, M, K, N, res=cur)
         if cur is None:
             tp.g[id(x)] = dx
     tp.ops.append(bwd)
@@ -511,7 +575,7 @@ def linear_bn_relu(tp, x, M, lin, bn):
 
 def group_mean_op(tp, x, groups, rows, Cc):
     y = _new((groups, Cc), x)
-    _call('grl_group_mean', ptr(x), ptr(y), groups, rows, Cc, Cc, C.c_float(1.0), 0)
+    _call(_k('grl_group_mean', x), ptr(x), ptr(y), groups, rows, Cc, Cc, C.c_float(1.0), 0)
 
     def bwd():
         dy = tp.take(y)
@@ -519,12 +583,12 @@ def group_mean_op(tp, x, groups, rows, Cc):
             return
         cur = tp.g.get(id(x))
         if cur is None:
-            cur = _new(tuple(x.shape), x)
+            cur = _newl(tuple(x.shape), x)
             tp.g[id(x)] = cur
             acc = 0
         else:
             acc = 1
-        _call('grl_add_rowbcast', ptr(cur), ptr(dy), groups * rows, Cc, rows, C.c_float(1.0 / rows), acc)
+        add_rowbcast(cur, dy, groups * rows, Cc, rows, 1.0 / rows, acc)
     tp.ops.append(bwd)
     return y
 
@@ -565,28 +629,30 @@ def trunk_train(tp, model, x):
     M0 = n * Hs * Ws
     conv1, bn1 = base[0], base[1]
     ones, zeros = torch.ones(64, device=tp.dev), torch.zeros(64, device=tp.dev)
-    z0 = _new((M0, 64), x)
+    adt = BF16 if tp.b16 else torch.float32              # storage type of the activations from here on
+    z0 = torch.empty((M0, 64), dtype=adt, device=tp.dev)
     w0 = conv1.weight.detach().contiguous()
-    _call('grl_stem_conv7x7', ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0, None)
+    _call(_k('grl_stem_conv7x7', z0), ptr(x), ptr(w0), ptr(ones), ptr(zeros), ptr(z0), n, H, W, 0, None)
     rows = _lib.load().grl_col_stats_rows(M0)
     slab = _new((rows, 2, 64), x)
-    _call('grl_col_stats', ptr(z0), ptr(slab), M0, 64, 64, ptr(z0))
-    st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev, pivot=z0)
-    a0 = _new((M0, 64), x)
+    pivot = z0[0].float().contiguous() if tp.b16 else z0           # (the bf16 kernel takes the pivot as an fp32 vector)
+    _call(_k('grl_col_stats', z0), ptr(z0), ptr(slab), M0, 64, 64, ptr(pivot))
+    st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev, pivot=pivot)
+    a0 = _newl((M0, 64), z0)
     bn_apply(z0, st, None, a0, M0, 64, True)
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
-    p0 = _new((n * Hp * Wp, 64), x)
-    _call('grl_maxpool3x3s2', ptr(a0), ptr(p0), n, Hs, Ws, 64)
+    p0 = _newl((n * Hp * Wp, 64), z0)
+    _call(_k('grl_maxpool3x3s2', a0), ptr(a0), ptr(p0), n, Hs, Ws, 64)
 
     def bwd_stem():
         dp = tp.take(p0)
         if dp is None:
             return
-        da = _new((M0, 64), dp)
-        _call('grl_maxpool3x3s2_bwd', ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
+        da = _newl((M0, 64), dp)
+        _call(_k('grl_maxpool3x3s2_bwd', dp), ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
         dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
-        col = _new((M0, 160), dp)
-        _call('grl_stem_im2col', ptr(x), ptr(col), n, H0, W0, 160)    # H, W are rebound below
+        col = _newl((M0, 160), dp)
+        _call(_k('grl_stem_im2col', dp), ptr(x), ptr(col), n, H0, W0, 160)    # H, W are rebound below
         wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
     tp.ops.append(bwd_stem)
 
@@ -610,8 +676,8 @@ def trunk_train(tp, model, x):
     return cur
 
 
-def _pad32(vec, fill=0.0):
-    out = torch.full((32,), fill, dtype=torch.float32, device=vec.device)
+def _pad32(vec, fill=0.0, n=32):
+    out = torch.full((n,), fill, dtype=torch.float32, device=vec.device)
     out[:vec.numel()] = vec.detach().reshape(-1)
     return out
 
@@ -633,7 +699,7 @@ def gce_train(tp, model, x4, b, t):
         if dz1 is None:
             return
         dgb = _new((b, 1024), x4)
-        _call('grl_group_mean', ptr(dz1), ptr(dgb), b, rpc, 1024, 1024, C.c_float(float(rpc)), 0)
+        _call(_k('grl_group_mean', dz1), ptr(dz1), ptr(dgb), b, rpc, 1024, 1024, C.c_float(float(rpc)), 0)
         tmp = torch.empty(1024, 1024, dtype=torch.float32, device=tp.dev)
         wgrad(dgb, glo, tmp, b, 1024, 1024, accumulate=0)
         tp.pgrad(conv0.weight).view(1024, 3072)[:, 2048:] += tmp
@@ -645,23 +711,24 @@ def gce_train(tp, model, x4, b, t):
     tp.ops.insert(len(tp.ops) - 1, bwd_gbias)
 
     h2, _, _, _ = conv_bn(tp, h1, b * t, 16, 8, bb.corr_atte[2], bb.corr_atte[3], True)
-    # 256 -> 1 conv + BN(1): run as a 32-wide padded channel block (K of the data-gradient
-    # GEMM must be a multiple of 32); only column 0 is real.
+    # 256 -> 1 conv + BN(1): run as a PW-wide zero-padded channel block (K of the data-gradient GEMM must be a
+    # multiple of the K stage: 32 fp32, 64 in the bf16-storage datapath); only column 0 is real.
     conv5, bn6 = bb.corr_atte[5], bb.corr_atte[6]
-    w5 = torch.zeros(32, 256, dtype=torch.float32, device=tp.dev)
+    PW = 64 if tp.b16 else 32
+    w5 = torch.zeros(PW, 256, dtype=torch.float32, device=tp.dev)
     w5[0] = conv5.weight.detach().view(256)
-    z3 = _new((M, 32), x4)
-    _, slab = gemm(h2, w5, z3, M, 32, 256, stats=True)
-    g32, b32 = _pad32(bn6.weight), _pad32(bn6.bias)
-    rm32, rv32 = _pad32(bn6.running_mean), _pad32(bn6.running_var, 1.0)
-    st = bn_finalize(slab, slab.shape[0], 32, M, bn6, tp.dev, gamma=g32, beta=b32, rm=rm32, rv=rv32)
+    z3 = _newl((M, PW), x4)
+    _, slab = gemm(h2, tp.w16(w5), z3, M, PW, 256, stats=True)
+    g32, b32 = _pad32(bn6.weight, n=PW), _pad32(bn6.bias, n=PW)
+    rm32, rv32 = _pad32(bn6.running_mean, n=PW), _pad32(bn6.running_var, 1.0, n=PW)
+    st = bn_finalize(slab, slab.shape[0], PW, M, bn6, tp.dev, gamma=g32, beta=b32, rm=rm32, rv=rv32)
     bn6.running_mean.copy_(rm32[:1])
     bn6.running_var.copy_(rv32[:1])
-    y3 = _new((M, 32), x4)
-    bn_apply(z3, st, None, y3, M, 32, False)
+    y3 = _newl((M, PW), x4)
+    bn_apply(z3, st, None, y3, M, PW, False)
     cmap = _new((M,), x4)
-    xc, xu = _new((M, 2048), x4), _new((M, 2048), x4)
-    _call('grl_gate_apply', ptr(y3), 32, ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 2048)
+    xc, xu = _newl((M, 2048), x4), _newl((M, 2048), x4)
+    _call(_k('grl_gate_apply', x4), ptr(y3), PW, ptr(x4), ptr(cmap), ptr(xc), ptr(xu), M, 2048)
 
     def bwd_gate():
         dxc, dxu = tp.take(xc), tp.take(xu)
@@ -669,24 +736,24 @@ def gce_train(tp, model, x4, b, t):
             return
         dxc = dxc if dxc is not None else torch.zeros_like(xc)
         dxu = dxu if dxu is not None else torch.zeros_like(xu)
-        dy3 = torch.zeros((M, 32), dtype=torch.float32, device=tp.dev)
+        dy3 = torch.zeros((M, PW), dtype=x4.dtype, device=tp.dev)
         cur = tp.g.get(id(x4))
         if cur is None:
-            cur = _new((M, 2048), x4)
+            cur = _newl((M, 2048), x4)
             tp.g[id(x4)] = cur
             acc = 0
         else:
             acc = 1
-        _call('grl_gate_bwd', ptr(dxc), ptr(dxu), ptr(x4), ptr(cmap), ptr(cur), acc, ptr(dy3), 32, M, 2048)
-        dg32, db32 = torch.zeros(32, device=tp.dev), torch.zeros(32, device=tp.dev)
-        dz3 = bn_backward(dy3, z3, None, st, g32, dg32, db32, M, 32)
+        _call(_k('grl_gate_bwd', x4), ptr(dxc), ptr(dxu), ptr(x4), ptr(cmap), ptr(cur), acc, ptr(dy3), PW, M, 2048)
+        dg32, db32 = torch.zeros(PW, device=tp.dev), torch.zeros(PW, device=tp.dev)
+        dz3 = bn_backward(dy3, z3, None, st, g32, dg32, db32, M, PW)
         tp.pgrad(bn6.weight).add_(dg32[:1])
         tp.pgrad(bn6.bias).add_(db32[:1])
-        dw5 = torch.empty(32, 256, dtype=torch.float32, device=tp.dev)
-        wgrad(dz3, h2, dw5, M, 32, 256, accumulate=0)
+        dw5 = torch.empty(PW, 256, dtype=torch.float32, device=tp.dev)
+        wgrad(dz3, h2, dw5, M, PW, 256, accumulate=0)
         tp.pgrad(conv5.weight).view(1, 256).add_(dw5[:1])
-        dh2 = _new((M, 256), x4)
-        gemm(dz3, tp.w_t(w5, ('w5', id(conv5.weight))), dh2, M, 256, 32)
+        dh2 = _newl((M, 256), x4)
+        gemm(dz3, tp.w_t(w5, ('w5', id(conv5.weight)), like=dz3), dh2, M, 256, PW)
         tp.add_grad(h2, dh2)
     tp.ops.append(bwd_gate)
     if tp.taps is not None:
@@ -696,7 +763,7 @@ def gce_train(tp, model, x4, b, t):
 
 def _axpy_frame(dst_full, ti, src, b, t, frame, alpha=1.0):
     """dst_full[b][ti] += alpha * src[b]  (frame-sized rows)."""
-    _call('grl_axpy_strided', ptr(dst_full.view(-1)[ti * frame:]), t * frame, ptr(src), frame, b, frame,
+    _call(_k('grl_axpy_strided', dst_full), ptr(dst_full.view(-1)[ti * frame:]), t * frame, ptr(src), frame, b, frame,
           C.c_float(alpha), 1)
 
 
@@ -713,8 +780,8 @@ def trl_train(tp, model, xu, xc, b, t):
             (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward))
     tp.mark('trl')
     fk = engine._TrlFork(tp.dev, tp.taps is None)
-    memo0 = _new((Mb, Cc), xu)
-    _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
+    memo0 = _newl((Mb, Cc), xu)
+    _call(_k('grl_temporal_mean', xu), ptr(xu), ptr(memo0), b, t, frame)
     # per-direction aliases: same storage, their own gradient slots on the tape
     xu_d = (xu, xu.view_as(xu)) if fk.two else (xu, xu)
     memo_d = (memo0, memo0.view_as(memo0)) if fk.two else (memo0, memo0)
@@ -729,7 +796,7 @@ def trl_train(tp, model, xu, xc, b, t):
         if dm is None:
             return
         g = tp.full_grad(xu)
-        _call('grl_add_rowbcast', ptr(g), ptr(dm), b * t, frame, t, C.c_float(1.0 / t), 1)
+        add_rowbcast(g, dm, b * t, frame, t, 1.0 / t, 1)
     tp.ops.append(bwd_memo0)
 
     gapc = group_mean_op(tp, xc, b * t, PIX, Cc)          # full_grad(xc) accumulates inside
@@ -760,7 +827,7 @@ def trl_train(tp, model, xu, xc, b, t):
                 f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
                 dvec = _new((b, Cc), xu)
                 f2t = f2[di]
-                _call('grl_sqdiff_mean', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+                _call(_k('grl_sqdiff_mean', f1), ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
                 hid = _new((b, 128), xu)
                 catte = _new((b, Cc), xu)
                 w1, w2 = mlp[0].weight, mlp[2].weight
@@ -787,17 +854,17 @@ def trl_train(tp, model, xu, xc, b, t):
                     dd = _new((b, Cc), xu)
                     gemm(dhp, tp.w_t(w1.detach(), w1), dd, b, Cc, 128)
                     # through d = mean (f1 - f2)^2
-                    df1 = _new((Mb, Cc), xu)
+                    df1 = _newl((Mb, Cc), xu)
                     df2 = tp.full_grad(f2t)
-                    _call('grl_sqdiff_bwd', ptr(f1), ptr(f2t[ti * PIX:]), ptr(dd), ptr(df1),
+                    _call(_k('grl_sqdiff_bwd', f1), ptr(f1), ptr(f2t[ti * PIX:]), ptr(dd), ptr(df1),
                           ptr(df2[ti * PIX:]), b, PIX, Cc, t * frame, 1)
                     tp.add_grad(f1, df1)
                 tp.ops.append(bwd_atte)
                 if tp.taps is not None:
                     tp.taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte)
 
-                s = _new((Mb, Cc), xu)
-                _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
+                s = _newl((Mb, Cc), xu)
+                _call(_k('grl_add_strided', xu), ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
                 prev = memo[di]
 
                 def bwd_add(s=s, prev=prev, ti=ti, xu_al=xu_al):
@@ -818,8 +885,8 @@ def trl_train(tp, model, xu, xc, b, t):
         fcorr = _new((b, t, Cc), xu)
         _call('grl_add_strided', ptr(fc[0]), ptr(fc[1]), ptr(fcorr), 1, b * t * Cc, 0)
     f_uncorr = _new((b, Cc), xu)
-    _call('grl_group_mean', ptr(mf), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
-    _call('grl_group_mean', ptr(mb_), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
+    _call(_k('grl_group_mean', mf), ptr(mf), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 0)
+    _call(_k('grl_group_mean', mb_), ptr(mb_), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
 
     def bwd_funcorr():              # backward: runs FIRST of the TRL closures, on the launch stream; then the fork
         d = tp.take(f_uncorr)
@@ -829,8 +896,8 @@ def trl_train(tp, model, xu, xc, b, t):
         if d is not None:
             tp.held.append(d)
             for di, m in enumerate((mf, mb_)):
-                g = _new((Mb, Cc), xu)
-                _call('grl_add_rowbcast', ptr(g), ptr(d), Mb, Cc, PIX, C.c_float(1.0 / PIX), 0)
+                g = _newl((Mb, Cc), xu)
+                add_rowbcast(g, d, Mb, Cc, PIX, 1.0 / PIX, 0)
                 tp.add_grad(m, g)
                 tp.held.append(g)
         fk.fork()
@@ -846,6 +913,7 @@ class _GrlTrainFn(torch.autograd.Function):
         model = model_box[0]
         engine.touch_state(model)            # running statistics change below, unseen by torch
         tp = Tape(inputs.device)
+        tp.b16 = _train_mode[0] == 'bf16s'
         tp.reserve_param_grads(params, cuts=_grl_cuts(model))
         tp.taps = getattr(model, '_grl_taps', None)
         b, t = inputs.shape[:2]

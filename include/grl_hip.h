@@ -340,6 +340,8 @@ typedef struct GrlWgrad {
     int32_t math;           /* GRL_MATH_F32 (exact), GRL_MATH_BF16X3 (split-bf16 products) or GRL_MATH_BF16: the
                                bf16 MFMA datapaths apply to 128 x 128 tiles (N >= 128, C or K % 128 == 0), other
                                shapes run exact fp32; accumulation and the slab reduction are always fp32 */
+    int32_t in_bf16;        /* 1: dz and x are bf16 tensors (ldz / ldx in elements; train_engine math 'bf16s'): plain
+                               bf16 products on 128 x 128 tiles for every shape (N, K, ld % 8 == 0), fp32 dW */
 } GrlWgrad;
 int64_t grl_wgrad_workspace_floats(const GrlWgrad* desc);
 int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream);
@@ -446,6 +448,40 @@ int grl_rerank_expand(const float* V, const int32_t* rank, const int32_t* lcnt, 
  * t = sum over the non-zero k of V2[i] (ascending) of min(V2[i][k], V2[j][k]);  out [nq][ng] */
 int grl_rerank_jaccard(const float* V2q, const float* V2T, const float* D, int N, int nq,
                        float lambda_value, float one_minus_lambda, float* out, void* stream);
+
+/* ---- bf16-STORAGE training (train_engine.set_math('bf16s'); BASELINE configs[2] as a training batch) -------------
+ * The twins of the train-mode kernels above for bf16 activations / saved tensors / activation gradients in HBM
+ * (`void*` = bf16 tensor); statistics, per-channel vectors and parameter gradients stay fp32.  Same reference call
+ * sites as the fp32 entry points they mirror (resnets1.py:76-91, basebranch.py:38-66, grl_model.py:71-83,131-180
+ * and their autograd backward, trainer.py:54).  C % 8 == 0, 16-byte aligned tensors. */
+int grl_bn_apply_centered_bf16(const void* z, const float* mean, const float* scale, const float* beta,
+                               const void* res, void* y, int64_t M, int C, int relu, void* stream);
+/* pivot: an fp32 VECTOR [C] (or NULL), not a row of x as in grl_col_stats */
+int grl_col_stats_bf16(const void* x, float* slab, int M, int C, int ld, const float* pivot, void* stream);
+int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, const float* mean, const float* invstd,
+                    const float* gamma, void* dz, float* dgamma, float* dbeta, float* slab_ws, float* coef_ws,
+                    int M, int C, void* gres, int gres_accumulate, const float* mask_scale,
+                    const float* mask_beta, void* stream);
+int grl_relu_bwd_bf16(const void* dy, const void* act, void* out, int64_t n, int accumulate, void* stream);
+int grl_axpby_bf16(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, void* stream);
+int grl_axpy_strided_bf16(void* dst, int64_t dst_stride, const void* src, int64_t src_stride, int nb,
+                          int64_t inner, float alpha, int accumulate, void* stream);
+int grl_dilate2_bf16(const void* dz, void* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
+                     int oy_off, int ox_off, void* stream);
+int grl_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int n, int H, int W, int C, void* stream);
+/* fp32 clip in, bf16 im2col columns out (the stem's weight gradient) */
+int grl_stem_im2col_bf16(const float* x, void* col, int n, int H, int W, int Kp, void* stream);
+int grl_gate_apply_bf16(const void* y, int ldy, const void* x, float* cmap, void* xc, void* xu, int M, int C,
+                        void* stream);
+int grl_gate_bwd_bf16(const void* dxc, const void* dxu, const void* x, const float* cmap, void* dx,
+                      int accumulate, void* dy, int ldy, int M, int C, void* stream);
+/* v: fp32 per-group vectors, or (v_is_bf16) a bf16 tensor -- the temporal-mean backward */
+int grl_add_rowbcast_bf16(void* dst, const void* v, int64_t M, int64_t C, int64_t rows_per_group, float scale,
+                          int accumulate, int v_is_bf16, void* stream);
+int grl_sqdiff_bwd_bf16(const void* f1, const void* f2, const float* dd, void* df1, void* df2, int b, int rows,
+                        int C, int64_t f2_clip_stride, int accumulate_df2, void* stream);
+/* bf16 -> fp32 (n % 8 == 0) */
+int grl_cast_f32(const void* x, float* y, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -183,7 +183,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+try:                                     # the raw handle of torch's current HIP stream without building a Stream object:
+    _raw_stream, _get_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice     # ~0.3 us instead of ~4 us,
+except AttributeError:                   # per launch, ~1500 launches per training step (the step is host-bound in bf16 storage)
+    _raw_stream = None
+
+
 def stream():
+    if _raw_stream is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 

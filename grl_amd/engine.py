@@ -204,8 +204,16 @@ def _debug_sync(name):
     torch.cuda.synchronize()
 
 
+_fns = {}
+
+
 def _call(name, *args):
-    check(getattr(_lib.load(), name)(*args, _lib.stream()), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(_lib.load(), name)
+    rc = fn(*args, _lib.stream())
+    if rc:
+        check(rc, name)
     if _DEBUG_SYNC:
         _debug_sync(name)
 

@@ -147,7 +147,7 @@ def gather_rank_order(x, y, group=None):
     """(features, labels) of every rank concatenated in rank order -- the OIM look-up tables
     replay all ranks' updates in that order so they stay identical without a broadcast
     (oim.py:24-26 is order dependent for repeated labels).  Identity when not distributed."""
-    if not is_distributed():
+    if not is_distributed() or global_heads():      # (global heads: the block every rank holds is the global one already)
         return x, y
     world = dist.get_world_size(group)
     xl = [torch.empty_like(x) for _ in range(world)]
@@ -155,6 +155,46 @@ def gather_rank_order(x, y, group=None):
     _all_gather(xl, x.contiguous(), group)
     _all_gather(yl, y.contiguous(), group)
     return torch.cat(xl), torch.cat(yl)
+
+
+def global_heads():
+    """GRL_DP_GLOBAL_HEADS=1 (opt-in DP fidelity switch): the Siamese heads and the loss block see the GLOBAL batch, as
+    in the reference's single-process nn.DataParallel run where only the CNN is replicated and Siamese, the n^2
+    verification terms, batch-hard triplet mining and classifierBN run on the gathered batch on device 0
+    (mars_train.py:80-82, trainer.py:137-162).  Default (north_star): rank-local heads, gradient all-reduce only."""
+    return is_distributed() and os.environ.get('GRL_DP_GLOBAL_HEADS') == '1'
+
+
+class _AllGatherGrad(torch.autograd.Function):
+    """x [b_local, ...] -> the rank-ordered global batch [world * b_local, ...] on every rank.  Backward: every rank
+    holds the (identical) gradient of the global loss w.r.t. the global tensor and keeps its own slice, multiplied by
+    the world size -- GradSync AVERAGES parameter gradients afterwards, and sum_r J_r^T g_r is the gradient of the
+    global loss (the head parameters see identical full gradients on every rank; their average is that gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(world)]
+        _all_gather(parts, x, group)
+        ctx.rank, ctx.world, ctx.n = rank, world, x.size(0)
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo = ctx.rank * ctx.n
+        return g[lo:lo + ctx.n] * float(ctx.world), None
+
+
+def gather_global(x, group=None):
+    """Differentiable rank-ordered all-gather along dim 0 (identity when not distributed)."""
+    if not is_distributed():
+        return x
+    if x.requires_grad:
+        return _AllGatherGrad.apply(x, group)
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size(group))]
+    _all_gather(parts, x.contiguous(), group)
+    return torch.cat(parts, 0)
 
 
 def shard_rows(n, rank, world):

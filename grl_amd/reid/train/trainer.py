@@ -139,6 +139,13 @@ class SEQTrainer(BaseTrainer):
         the uncorrelated branch."""
         batch_size, seq_len = inputs[0].size(0), inputs[0].size(1)
         x_uncorr, x_corr = self.model(inputs[0])
+        if grl_dist.global_heads():
+            # opt-in DP fidelity (GRL_DP_GLOBAL_HEADS=1): as under the reference's nn.DataParallel, only the CNN is
+            # data parallel -- its outputs and the labels are gathered in rank order and the Siamese heads, the n^2
+            # verification terms, triplet mining and the OIM tables see the GLOBAL batch (mars_train.py:80-82)
+            x_uncorr, x_corr = grl_dist.gather_global(x_uncorr), grl_dist.gather_global(x_corr)
+            targets = grl_dist.gather_global(targets)
+            batch_size = x_corr.size(0)
         frame_corr = x_corr.reshape(batch_size * seq_len, -1)
         targetX = targets.unsqueeze(1).expand(batch_size, seq_len).reshape(-1)
         corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)

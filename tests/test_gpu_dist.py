@@ -292,3 +292,79 @@ def test_bench_gpus_2_prints_one_line_with_a_train_block():
         assert blk['allreduce_bytes_per_step'] >= 4 * 54758726
         assert blk['gradsync_collectives_per_step'] == len(blk['allreduce_buckets'])
         assert blk['clips_per_sec'] > 0
+
+
+def _global_heads_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GRL_DP_GLOBAL_HEADS='1')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from grl_amd import dist as grl_dist
+    dev = torch.device('cuda:0')
+    tr, opt, mods, crits = _trainer(dev)
+    for m in mods:
+        m.train()
+    clips, pids, _ = _batches()[0]
+    lo, hi = grl_dist.shard_pairs(B, rank, world)
+    loss = tr._forward([clips[lo:hi].to(dev)], pids[lo:hi].to(dev), 0, 0)[0]
+    sync = grl_dist.GradSync([p for m in mods for p in m.parameters()])
+    opt.zero_grad()
+    sync.begin()
+    loss.backward()
+    sync.finish()
+    grads = {'m%d.%s' % (i, k): p.grad.detach().cpu().clone() for i, m in enumerate(mods) for k, p in m.named_parameters()
+             if p.grad is not None}
+    out[rank] = (float(loss), grads, [c.lut.detach().cpu().clone() for c in crits])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_heads_switch_equals_gathered_batch_loss():
+    """GRL_DP_GLOBAL_HEADS=1 (the reference's nn.DataParallel semantics: only the CNN is replicated, the Siamese
+    heads / verification / triplet mining / OIM see the gathered batch -- mars_train.py:80-82, trainer.py:137-162):
+    two ranks on one device give, on every rank, the loss and the averaged gradients of a single process that runs
+    the CNN on the two shards (per-replica BatchNorm) and the heads + loss block ONCE on the concatenated outputs."""
+    world, port = 2, 33900 + os.getpid() % 1500
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    mp.spawn(_global_heads_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert all(torch.equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    # single-process emulation
+    from grl_amd.reid.evaluator import accuracy      # noqa: F401  (import side effects only)
+    dev = torch.device('cuda:0')
+    tr, opt, mods, crits = _trainer(dev)
+    cnn, siam, siamv = mods
+    for m in mods:
+        m.train()
+    clips, pids, _ = _batches()[0]
+    half = B // world
+    outs = [cnn(clips[r * half:(r + 1) * half].to(dev)) for r in range(world)]
+    xu, xc = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+
+    class _Shim(torch.nn.Module):
+        def forward(self, x):
+            return xu, xc
+    real = tr.model
+    tr.model = _Shim()
+    try:
+        loss = tr._forward([clips.to(dev)], pids.to(dev), 0, 0)[0]
+    finally:
+        tr.model = real
+    opt.zero_grad()
+    loss.backward()
+    assert abs(float(loss) - out[0][0]) <= 1e-6 * abs(float(loss)), (float(loss), out[0][0])
+    worst = 0.0
+    for i, m in enumerate(mods):
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            ref = p.grad.detach().cpu()
+            got = out[0][1]['m%d.%s' % (i, k)]
+            worst = max(worst, float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+    print('global heads: worst relative gradient difference vs the gathered-batch single process %.2e' % worst)
+    assert worst < 1e-5
+    assert all(float((a - c.lut.cpu()).abs().max()) < 1e-6 for a, c in zip(out[0][2], crits))

@@ -104,11 +104,19 @@ def _worker(rank, world, port, out):
     tp_params[0].grad, tp_params[1].grad = tape.pgrad(tp_params[0]), tape.pgrad(tp_params[1])
     sync2.finish()
     tape_out = (tp_params[0].grad.clone(), tp_params[1].grad.clone(), sync2.stray, sync2.collectives, list(sync2.launched))
+    # opt-in global heads (GRL_DP_GLOBAL_HEADS): differentiable rank-ordered all-gather; the backward keeps this
+    # rank's slice of the global gradient times the world size (GradSync averages afterwards)
+    from grl_amd.dist import gather_global
+    xg = torch.full((2, 3), float(rank + 1), requires_grad=True)
+    yg = gather_global(xg)
+    wg = torch.arange(12, dtype=torch.float32).view(4, 3)
+    (yg * wg).sum().backward()
+    gg_out = (yg.detach().clone(), xg.grad.clone(), gather_global(torch.tensor([rank, 7])))
     # evaluation features sharded by batch: rank r owns batches r, r + world, ...
     feats = [(i, torch.full((2 + i, 3), float(i)), [i] * (2 + i), [7] * (2 + i)) for i in range(5) if i % world == rank]
     gf, gp, gc = gather_feature_batches(feats, 5)
     out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone(), sync_out,
-                 (gf.clone(), gp, gc), tape_out)
+                 (gf.clone(), gp, gc), tape_out, gg_out)
     dist.destroy_process_group()
 
 
@@ -136,6 +144,9 @@ def test_gradient_allreduce_gloo_world2():
         assert torch.equal(g0, torch.full((6,), 15.0)) and torch.equal(g1, torch.full((3, 3), 1.5))
         assert stray == 0 and launched == [('late', 20), ('early', 8)]      # 4-float aligned slots: 8 | 12 + 8
         assert ncoll == 2 + 2                       # two buckets + the one-off None-pattern check (MIN, MAX)
+        yg, xgrad, lab = out[r][8]
+        assert torch.equal(yg, torch.tensor([[1.0] * 3] * 2 + [[2.0] * 3] * 2)) and lab.tolist() == [0, 7, 1, 7]
+        assert torch.equal(xgrad, torch.arange(12, dtype=torch.float32).view(4, 3)[2 * r:2 * r + 2] * 2)
         gf, gp, gc = out[r][6]
         assert gf.shape == (2 + 3 + 4 + 5 + 6, 3) and gp == [i for i in range(5) for _ in range(2 + i)]
         assert torch.equal(gf[:, 0], torch.tensor([float(i) for i in range(5) for _ in range(2 + i)])) and set(gc) == {7}

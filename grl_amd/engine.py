@@ -207,6 +207,14 @@ def _debug_sync(name):
 _fns = {}
 
 
+def _kb():
+    """The per-clip linears of the eval path (global descriptor, its bias term, the Siamese Q|K projection: M = clips or
+    frames, K = 1024..2048) accumulate K-BLOCKED in the exact-fp32 datapath: their 512-k segments then run as separate
+    workgroups (GrlGemm.splitk_ws) instead of one workgroup per tile walking all of K -- 55 -> ~15 us each -- and the
+    result does not depend on whether the library splits (M <= 256) or not: a clip's row stays batch-independent."""
+    return _math[0] in (MATH_F32, MATH_BF16S)
+
+
 def _call(name, *args):
     fn = _fns.get(name)
     if fn is None:
@@ -437,12 +445,12 @@ def gce_eval(plan, x4, b, t, taps=None):
     _call('grl_group_mean', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
     g = plan.glo_fc
     glo = _new((b, 1024), x4)
-    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True)
+    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True, kblock=_kb())
     # W.[x; g] = Wx.x + Wg.g : the broadcast-concat of basebranch.py:59-61 becomes a
     # per-clip bias added inside the accumulator epilogue.
     c0 = plan.corr0
     gb = _new((b, 1024), x4)
-    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072)
+    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072, kblock=_kb())
     h1 = _new((M, 1024), x4)
     gemm(x4, c0.w, h1, M, 1024, 2048, ldw=3072, gbias=gb, rows_per_group=t * PIX,
          scale=c0.scale, shift=c0.shift, relu=False)
@@ -649,10 +657,10 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     _call('grl_group_mean_bf16', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
     g = plan.glo_fc
     glo = _new((b, 1024), x)
-    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True, math=MATH_F32)
+    gemm(x_glo, g.w, glo, b, 1024, 2048, scale=g.scale, shift=g.shift, relu=True, math=MATH_F32, kblock=True)
     c0 = plan.corr0
     gb = _new((b, 1024), x)
-    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072, math=MATH_F32)
+    gemm(glo, c0.w[:, 2048:], gb, b, 1024, 1024, ldw=3072, math=MATH_F32, kblock=True)
     h1 = _newb((M, 1024), x)
     gemm(x4, c0.wb(), h1, M, 1024, 2048, ldw=3072, gbias=gb, rows_per_group=t * PIX,
          scale=c0.scale, shift=c0.shift, relu=False, math=MATH_BF16S)
@@ -745,7 +753,7 @@ def _attn_into(siam, x, out, ldy):
     b, t, c = x.shape
     x = x.contiguous()
     qk = _new((b * t, 2 * plan.D), x)
-    gemm(x, plan.wqk, qk, b * t, 2 * plan.D, c, scale=plan.scale, shift=plan.shift)
+    gemm(x, plan.wqk, qk, b * t, 2 * plan.D, c, scale=plan.scale, shift=plan.shift, kblock=_kb())
     _call('grl_siamese_attn', ptr(qk), ptr(x), ptr(out), b, t, plan.D, c, ldy)
     return out
 

@@ -52,7 +52,7 @@ class OIM(autograd.Function):
         c = lut.size(0)
         scale = torch.full((c,), float(scalar), dtype=torch.float32, device=x.device)
         logits = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        engine.gemm(x, lut, logits, n, c, D, scale=scale, math=MATH_F32)
+        engine.gemm(x, lut, logits, n, c, D, scale=scale, math=MATH_F32, kblock=True)      # (K-blocked: split over K, include/grl_hip.h)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(logits)
         ws = torch.empty(2 * n, dtype=torch.float32, device=x.device)

@@ -395,6 +395,45 @@ def test_gemm_bf16_storage(dev, M, N, K, conv):
     assert torch.equal(y, y32.bfloat16())                               # one rounding on the store
 
 
+@pytest.mark.parametrize('M,N,K,conv', [(49152, 256, 512, None), (65536, 512, 128, None), (49152 + 136, 264, 192, None),
+                                        (48 * 32 * 32, 256, 9 * 64, (32, 32, 64, 32, 32, 3, 3, 1, 1))])
+def test_gemm_bf16_256_kernel_selected_vs_torch_fp32(dev, M, N, K, conv):
+    """Direct check of gemm_bf16_256_kernel at sizes the AUTOMATIC heuristic hands to it (>= 192 tiles of 256 x 256,
+    N >= 256; verified through grl_gemm_bf16_tile_mode): against a plain torch fp32 product of the same
+    bf16-representable operands -- fp32 accumulation on both sides, one rounding on the store."""
+    import torch.nn.functional as F
+    from grl_amd import engine, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+    a = torch.randn(rows_in, cin, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(dev)
+    res = torch.randn(M, N, generator=g).bfloat16().to(dev)
+    sc, sh = (torch.rand(N, generator=g) + 0.5).to(dev), torch.randn(N, generator=g).to(dev)
+    outs = {}
+    for mode in (-1, 0):                           # automatic (the 256-tile kernel at these sizes) and never
+        old = lib.grl_gemm_bf16_tile_mode(mode)
+        try:
+            y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=res, relu=True, conv=conv, math=2)
+            outs[mode] = y
+        finally:
+            lib.grl_gemm_bf16_tile_mode(old)
+    if conv is None:
+        acc = a.float() @ w.float().t()
+    else:
+        H, W, Cc = conv[0], conv[1], conv[2]
+        x = a.float().view(-1, H, W, Cc).permute(0, 3, 1, 2)
+        wt = w.float().view(N, 3, 3, Cc).permute(0, 3, 1, 2)           # packed [N][tap][C] -> torch [N][C][kh][kw]
+        acc = F.conv2d(x, wt, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    ref = torch.relu(acc * sc + sh + res.float())
+    err = float((outs[-1].float() - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, err                          # one bf16 rounding of the output (2^-8 of the largest value)
+    assert float((outs[-1].float() - ref).abs().mean() / ref.abs().mean()) < 2e-3
+    assert torch.equal(outs[-1], outs[0])           # and bit-identical to the 128 x 128 family
+
+
 @pytest.mark.parametrize('M,N,K,conv,gb', [
     (700, 520, 256, None, False),                                     # ragged M and N (N % 8 == 0), 3 x 3 tiles
     (2 * 128 * 3, 256, 2048, None, True),                             # per-clip bias (GCE corr0), rows_per_group = 256

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Does the HIP training path LEARN, and does the 'mixed' datapath train like exact fp32?
+"""Does the HIP training path LEARN, and do the 'mixed' and 'bf16s' (bf16-storage) datapaths train like exact fp32?
 
 A small synthetic re-id problem (no dataset is available here): N identities, each a fixed low-frequency colour
 layout; a clip = its identity's layout + a per-clip and per-frame deviation + pixel noise (256 x 128, T frames).
@@ -79,12 +79,12 @@ def run(math):
     return curve, float(cmc[0]), float(mAP), secs
 
 
-print('# r02: does the HIP training path learn, and does `mixed` train like exact fp32?\n')
+print('# r03: does the HIP training path learn, and do `mixed` / `bf16s` train like exact fp32?\n')
 print('`tools/convergence_check.py %d`: %d synthetic identities (fixed colour layouts + per-clip / per-frame deviation + noise), '
       'random initialisation, the reference\'s 5-term loss and SGD settings, P x K = %d x 2 clips of %d frames per step; '
       'then fresh clips of the same identities are ranked on the 6144-d evaluator features (chance Rank-1 = %.1f %%).\n' % (ITERS, N_ID, P, T, 100.0 / N_ID))
 res = {}
-for m in ('f32', 'mixed'):
+for m in ('f32', 'mixed', 'bf16s'):
     res[m] = run(m)
 print('| iteration | ' + ' | '.join('%s: loss / clip-id acc / frame-id acc' % m for m in res) + ' |')
 print('|---|' + '---|' * len(res))

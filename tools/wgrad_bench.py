@@ -22,27 +22,32 @@ def record_shapes(b=32, t=4):
     seen = collections.OrderedDict()
     orig = TE.wgrad
 
-    def spy(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1):
-        key = (M, N, K, ldz or N, ldx or K, conv, k_out)
+    def spy(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
+        key = (M, N, K, ldz or N, ldx or K, conv, k_out, dz.dtype == torch.bfloat16)
         seen[key] = seen.get(key, 0) + 1
-        return orig(dz, x, dw, M, N, K, ldz=ldz, ldx=ldx, conv=conv, k_out=k_out, accumulate=accumulate)
+        return orig(dz, x, dw, M, N, K, ldz=ldz, ldx=ldx, conv=conv, k_out=k_out, accumulate=accumulate, math=math)
     TE.wgrad = spy
-    xu, xc = cnn(synth_clips(b, t, seed=0).cuda())
-    (xu.sum() + xc.sum()).backward()
+    old = TE.set_math(MATH)
+    try:
+        xu, xc = cnn(synth_clips(b, t, seed=0).cuda())
+        (xu.sum() + xc.sum()).backward()
+    finally:
+        TE.set_math(old)
     torch.cuda.synchronize()
     TE.wgrad = orig
     return seen
 
 
 def time_shape(key, iters=4):
-    M, N, K, ldz, ldx, conv, k_out = key
+    M, N, K, ldz, ldx, conv, k_out, b16 = key
     dev = torch.device('cuda:0')
-    dz = torch.randn(M, ldz, device=dev)
+    dt = torch.bfloat16 if b16 else torch.float32
+    dz = torch.randn(M, ldz, device=dev).to(dt)
     if conv is None:
-        x = torch.randn(M, ldx, device=dev)
+        x = torch.randn(M, ldx, device=dev).to(dt)
     else:
         H, W, Cc, Ho, Wo = conv[:5]
-        x = torch.randn(M // (Ho * Wo) * H * W, Cc, device=dev)
+        x = torch.randn(M // (Ho * Wo) * H * W, Cc, device=dev).to(dt)
     dw = torch.zeros(N, k_out or K, device=dev)
     for _ in range(2):
         TE.wgrad(dz, x, dw, M, N, K, ldz=ldz, ldx=ldx, conv=conv, k_out=k_out)
@@ -55,9 +60,12 @@ def time_shape(key, iters=4):
     return e0.elapsed_time(e1) / iters
 
 
+MATH = os.environ.get('GRL_WGRAD_BENCH_MATH', 'f32')       # 'bf16s': the bf16-in kernel on bf16 operands
+BT = tuple(int(v) for v in os.environ.get('GRL_WGRAD_BENCH_BT', '32x4').split('x'))
+
 if __name__ == '__main__':
     forced = [int(a) for a in sys.argv[1:]]
-    shapes = record_shapes()
+    shapes = record_shapes(*BT)
     tot = collections.OrderedDict([('auto', 0.0)] + [(s, 0.0) for s in forced])
     best_tot = 0.0
     print('%-62s %5s' % ('shape (M,N,K,ldz,ldx,conv,k_out)', 'calls') + '%16s' % 'auto' +

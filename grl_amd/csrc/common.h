@@ -32,6 +32,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // 128 x 128 family), < 0 = error.
 struct GrlGemm;
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s);
+bool grl_gemm_bf16_256_takes(const GrlGemm& d);        // would it?  (same predicate)
+int grl_gemm_bf16_256_stat_rows(const GrlGemm& d);     // rows of the statistics slab it writes (2 per 256-row tile)
 
 // train.hip: BatchNorm-backward finalize over an fp32 partial slab (shared with the bf16-storage kernels of train_bf16.hip)
 int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,

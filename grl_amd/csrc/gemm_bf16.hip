@@ -51,7 +51,11 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds, 16, 0, 0);
 }
 
-template <bool CONV>
+// STATS (bf16-storage TRAINING, round 3): per-channel sum / sum of squares of the raw fp32 accumulator (+ per-clip
+// bias) for train-mode BatchNorm, one partial per 128-row wave row: stats[2 * tile_m + wr][0|1][n].  A lane sums
+// its 16 rows, the 8 lanes that own the same 8 channels combine by xor-shuffles -- a fixed order, no cross-wave
+// step (each wave row writes its own slab row), so the epilogue keeps its one-barrier-per-tile structure.
+template <bool CONV, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
                                                                const int num_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
     const char* const w8 = reinterpret_cast<const char*>(p.w);
     const char* const zrow = reinterpret_cast<const char*>(g_zero_row) + sw;
     int m0, n0;
+    int cur_tile_m = 0;
 
     // Persistent workgroups (one per CU) walk tiles t = blockIdx.x, + gridDim.x, ...  XCD-aware
     // order: blocks b, b+8, ... share an XCD (gridDim.x is a multiple of 8 whenever a workgroup
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
         const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
         m0 = tile_m * TB;
         n0 = tile_n * TB;
+        if constexpr (STATS) cur_tile_m = tile_m;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (wave + 8 * i) * 8 + srow;
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
         // the K loop ended on a barrier: both stage buffers are free.  Request the NEXT tile's first
         // stage now, so that it lands under this tile's epilogue.
         const int cm0 = m0 + wr * 128, cn = n0 + wc * 64 + lcol;
+        const int stat_row = 2 * cur_tile_m + wr;
         const int next_t = t + (int)gridDim.x;
         if (next_t < num_tiles) {
             setup_tile(next_t);
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                 if (p.shift) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
             }
         }
+        f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // the four residual rows of this 32-row block are requested before the slab round trip
@@ -278,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
                         if (p.gbias)
                             v += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
+                        if constexpr (STATS) { ssum[u] += v; ssq[u] += v * v; }
                         v = v * sc[u] + sh[u];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -287,6 +296,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                         }
                     }
                     *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                }
+            }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ssum[u][e] += __shfl_xor(ssum[u][e], o);
+                        ssq[u][e] += __shfl_xor(ssq[u][e], o);
+                    }
+            }
+            if (lrow == 0 && n_ok) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 0) * p.N + cn + 4 * u) = ssum[u];
+                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 1) * p.N + cn + 4 * u) = ssq[u];
                 }
             }
         }
@@ -313,10 +341,29 @@ extern "C" int grl_gemm_bf16_tile_mode(int mode) {
 
 // Returns 1 when the 256 x 256 kernel took the launch, 0 when the caller should use the
 // 128 x 128 family (shape / feature not covered), < 0 on error.
+// Would grl_gemm_bf16_256 take this launch?  (grl_conv_gemm_f32_stat_rows asks too: the statistics slab then has
+// two rows per 256-row tile.)
+bool grl_gemm_bf16_256_takes(const GrlGemm& d) {
+    const int mode = g_mode;
+    if (mode == 0) return false;
+    if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.rowscale || d.out_f32) return false;
+    if (d.K % 64 || d.N % 8 || d.ldy % 8 || (d.res && d.ldres % 8) || d.lda % 8 || d.ldw % 8) return false;
+    if (d.conv && d.C % 64) return false;
+    if (!al16(d.a) || !al16(d.w) || !al16(d.y) || !al16(d.res) || !al16(d.scale) || !al16(d.shift) || !al16(d.gbias))
+        return false;
+    const int64_t a_bytes = d.conv ? (int64_t)(d.M / (d.Ho * d.Wo)) * d.H * d.W * d.C * 2 : (int64_t)d.M * d.lda * 2;
+    if (a_bytes >= (1ll << 32) || (int64_t)d.N * d.ldw * 2 >= (1ll << 32) || (d.conv && (d.H + 2 > 65535 || d.W + 2 > 65535))) return false;
+    const int64_t num_tiles = (int64_t)((d.M + TB - 1) / TB) * ((d.N + TB - 1) / TB);
+    if (mode < 0 && (num_tiles < 192 || d.N < 256)) return false;
+    return true;
+}
+
+int grl_gemm_bf16_256_stat_rows(const GrlGemm& d) { return 2 * ((d.M + TB - 1) / TB); }
+
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     const int mode = g_mode;
     if (mode == 0) return 0;
-    if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.stats || d.rowscale || d.out_f32) return 0;
+    if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.rowscale || d.out_f32) return 0;
     if (d.K % 64 || d.N % 8 || d.ldy % 8 || (d.res && d.ldres % 8) || d.lda % 8 || d.ldw % 8) return 0;
     if (d.conv && d.C % 64) return 0;
     if (!al16(d.a) || !al16(d.w) || !al16(d.y) || !al16(d.res) || !al16(d.scale) || !al16(d.shift) || !al16(d.gbias))
@@ -332,6 +379,8 @@ int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         return true;
     }();
     (void)attr;
@@ -343,7 +392,13 @@ int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
         return n / 8 * 8 > 0 ? n / 8 * 8 : 8;
     }();
     const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
-    if (d.conv)
+    if (d.stats) {
+        if (!al16(d.stats)) return 0;
+        if (d.conv)
+            hipLaunchKernelGGL((gemm_bf16_256_kernel<true, true>), dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        else
+            hipLaunchKernelGGL((gemm_bf16_256_kernel<false, true>), dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+    } else if (d.conv)
         hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
     else
         hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);

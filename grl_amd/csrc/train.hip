@@ -180,7 +180,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
-    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta) {
+    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta, float* __restrict__ gout) {
     constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
     __shared__ f32x4 red[2][4][LPR];
     const int chunk = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             }
             const f32x4 xh = zc * is;
             s += g; q += g * xh;
+            if (gout) *reinterpret_cast<f32x4*>(gout + (int64_t)r * C + c) = g;      // masked gradient, in place over dy
         }
     }
 #pragma unroll
@@ -1006,19 +1007,29 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
+    // gres == dy (y = relu(bn(z) + res), the residual's gradient not yet started): the reduce pass overwrites dy with
+    // the masked gradient g -- which IS the residual's gradient -- and the apply pass reads it back: the activation is
+    // read once instead of twice and no separate gres tensor is written (round 3; -2 of 9 tensor passes on the widest
+    // BatchNorms of the step)
+    const bool inplace = act && gres == dy && !gres_accumulate;
+    float* const gout = inplace ? const_cast<float*>(dy) : nullptr;
     if (C <= 64)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<16>, dim3(grl_ceil_div(C, 64), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
     else if (C <= 128)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(grl_ceil_div(C, 128), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total4 = (int64_t)M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
-                       coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta);
+    if (inplace)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, (const float*)nullptr, mean,
+                           invstd, gamma, coef_ws, dz, C, total4, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
+                           coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta);
     return grl_check_launch("grl_bn_bwd");
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void col_stats_b16_kernel(const __bf16* __rest
 __global__ __launch_bounds__(256) void bn_bwd_reduce_b16_kernel(
     const __bf16* __restrict__ dy, const __bf16* __restrict__ z, const __bf16* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab, int M, int C,
-    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR) {
+    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR, __bf16* __restrict__ gout) {
     __shared__ f32x8 red[2][256];
     const int chunk = blockIdx.y, sub = threadIdx.x % LPR, part = threadIdx.x / LPR, parts = 256 / LPR;
     const int c = blockIdx.x * 256 + sub * 8;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_b16_kernel(
                 for (int e = 0; e < 8; ++e) g[e] = t[e] > 0.f ? g[e] : 0.f;
             }
             s += g; q += g * (zc * is);
+            if (gout) st8(gout + o, g);               // masked gradient, in place over dy (see grl_bn_bwd)
         }
     }
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
@@ -298,23 +299,28 @@ __global__ void maxpool_bwd_b16_kernel(const __bf16* __restrict__ x, const __bf1
     }
 }
 
-// stem im2col for the 7x7 weight gradient (fp32 clip in, bf16 columns out): col[m][k], k = (c*7+ky)*7+kx, padded to Kp
+// stem im2col for the 7x7 weight gradient (fp32 clip in, bf16 columns out): col[m][k], k = (c*7+ky)*7+kx, padded to
+// Kp; a lane builds 8 consecutive k of one pixel and stores them as one 16-byte chunk
 __global__ void stem_im2col_b16_kernel(const float* __restrict__ x, __bf16* __restrict__ col, int H, int W, int Kp,
-                                       int64_t total) {
-    const int Ho = H / 2, Wo = W / 2;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = i % Kp;
-        int64_t m = i / Kp;
+                                       int64_t total8) {
+    const int Ho = H / 2, Wo = W / 2, K8 = Kp / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k0 = (int)(i % K8) * 8;
+        int64_t m = i / K8;
         const int ox = m % Wo; m /= Wo;
         const int oy = m % Ho;
         const int img = m / Ho;
-        float v = 0.f;
-        if (k < 147) {
-            const int c = k / 49, ky = (k / 7) % 7, kx = k % 7;
-            const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((int64_t)img * 3 + c) * H + iy) * W + ix];
+        f32x8 v = zero8();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            if (k < 147) {
+                const int c = k / 49, ky = (k / 7) % 7, kx = k % 7;
+                const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[e] = x[(((int64_t)img * 3 + c) * H + iy) * W + ix];
+            }
         }
-        col[i] = (__bf16)v;
+        st8(col + i * 8, v);
     }
 }
 
@@ -431,12 +437,19 @@ extern "C" int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, c
     GRL_REQUIRE(al16(dy) && al16(z) && al16(act) && al16(dz) && al16(gres), "bn_bwd_bf16: 16-byte aligned tensors");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
+    const bool inplace = act && gres == dy && !gres_accumulate;       // (as grl_bn_bwd: dy becomes the masked gradient)
     hipLaunchKernelGGL(bn_bwd_reduce_b16_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, CB16(dy), CB16(z),
-                       CB16(act), mean, invstd, slab_ws, M, C, mask_scale, mask_beta, lpr_for(C));
+                       CB16(act), mean, invstd, slab_ws, M, C, mask_scale, mask_beta, lpr_for(C),
+                       inplace ? const_cast<__bf16*>(CB16(dy)) : (__bf16*)nullptr);
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total8 = (int64_t)M * C / 8;
-    hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(dy), CB16(z), CB16(act),
-                       mean, invstd, gamma, coef_ws, B16(dz), C, total8, B16(gres), gres_accumulate, mask_scale, mask_beta);
+    if (inplace)
+        hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(dy), CB16(z), (const __bf16*)nullptr,
+                           mean, invstd, gamma, coef_ws, B16(dz), C, total8, (__bf16*)nullptr, 0, (const float*)nullptr,
+                           (const float*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(dy), CB16(z), CB16(act),
+                           mean, invstd, gamma, coef_ws, B16(dz), C, total8, B16(gres), gres_accumulate, mask_scale, mask_beta);
     return grl_check_launch("grl_bn_bwd_bf16");
 }
 
@@ -484,9 +497,9 @@ extern "C" int grl_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx
 
 extern "C" int grl_stem_im2col_bf16(const float* x, void* col, int n, int H, int W, int Kp, void* stream) {
     GRL_REQUIRE(x && col && n > 0 && Kp >= 147 && Kp % 32 == 0, "stem_im2col_bf16: bad args");
-    const int64_t total = (int64_t)n * (H / 2) * (W / 2) * Kp;
-    hipLaunchKernelGGL(stem_im2col_b16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, B16(col), H, W,
-                       Kp, total);
+    const int64_t total8 = (int64_t)n * (H / 2) * (W / 2) * (Kp / 8);
+    hipLaunchKernelGGL(stem_im2col_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, x, B16(col), H, W,
+                       Kp, total8);
     return grl_check_launch("grl_stem_im2col_bf16");
 }
 

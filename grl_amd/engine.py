@@ -182,7 +182,9 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
             d.splitk_ws, d.splitk_ws_floats = ptr(ws), need
     if want_stats:
         rows = lib.grl_conv_gemm_f32_stat_rows(C.byref(d))
-        slab = torch.empty((rows, 2, N), dtype=torch.float32, device=y.device)
+        # (bf16 storage: zero-filled -- the 256 x 256 kernel writes two rows per tile, the 128 x 128 family one per
+        # 128 rows; whichever takes the launch, rows it does not write must read as zero)
+        slab = (torch.zeros if d.math == MATH_BF16S else torch.empty)((rows, 2, N), dtype=torch.float32, device=y.device)
         d.stats = ptr(slab)
         check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
         if _DEBUG_SYNC:

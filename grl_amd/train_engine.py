@@ -451,11 +451,13 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             return
         act = a if relu else None
         gres, gacc = None, 0
-        if res is not None:                 # grad(res) (+)= da * (a > 0), written by the BN apply pass
+        if res is not None:                 # grad(res) (+)= da * (a > 0)
             gres = tp.g.get(id(res))
             gacc = 1 if gres is not None else 0
             if gres is None:
-                gres = tp.g[id(res)] = _newl((M, N), da)
+                # first contribution to grad(res): it IS the masked da -- the reduce pass of grl_bn_bwd masks da in
+                # place (gres == dy) and this tape entry adopts the buffer (da was popped: nobody else reads it)
+                gres = tp.g[id(res)] = da if relu else _newl((M, N), da)
         dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
                          gres=gres, gres_acc=gacc, mask_from_z=relu and res is None)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,

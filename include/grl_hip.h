@@ -294,7 +294,9 @@ int grl_bn_apply_centered(const float* z, const float* mean, const float* scale,
  * dgamma += sum g*xhat; dbeta += sum g; dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
  * slab_ws: grl_col_stats_rows(M)*2*C floats, coef_ws: 2*C floats. gamma/dgamma/dbeta may be NULL.
  * gres (may be NULL): gradient of the residual input of y = relu(bn(z) + res), which is the same
- * masked g: gres (+)= g in the same pass (resnets1.py:88-91). */
+ * masked g: gres (+)= g in the same pass (resnets1.py:88-91).  gres == dy with act given and gres_accumulate == 0:
+ * IN-PLACE form -- the reduce pass overwrites dy with g (dy is NOT const then) and the apply pass reads it back, so
+ * the caller's dy buffer becomes the residual's gradient: the activation is read once and no second tensor is written. */
 int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,

@@ -140,15 +140,21 @@ def test_bn_backward_and_column_statistics_twins(dev, M, Cc):
     st = TE.bn_finalize(slab32, rows, Cc, M, bn, dev, pivot=z)
     a32 = torch.empty_like(z)
     TE.bn_apply(z, st, None, a32, M, Cc, True)
-    for mode in ('act', 'from_z', 'none', 'gres'):
+    for mode in ('act', 'from_z', 'none', 'gres', 'inplace'):
         outs = []
         for b16 in (False, True):
             dt = BF if b16 else torch.float32
             dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
-            gres = torch.empty(M, Cc, device=dev, dtype=dt) if mode == 'gres' else None
-            act = a32.to(dt) if mode in ('act', 'gres') else None
-            dz = TE.bn_backward(dy.to(dt), z.to(dt), act, st, bn.weight, dg, db, M, Cc, gres=gres, mask_from_z=(mode == 'from_z'))
+            dyd = dy.to(dt).clone()
+            gres = torch.empty(M, Cc, device=dev, dtype=dt) if mode == 'gres' else (dyd if mode == 'inplace' else None)
+            act = a32.to(dt) if mode in ('act', 'gres', 'inplace') else None
+            dz = TE.bn_backward(dyd, z.to(dt), act, st, bn.weight, dg, db, M, Cc, gres=gres, mask_from_z=(mode == 'from_z'))
             outs.append((dz.float(), dg, db, None if gres is None else gres.float()))
+        if mode == 'gres':
+            ref_gres = outs
+        if mode == 'inplace':          # gres aliased to dy (masked in place) == the two-buffer form, bit for bit
+            for o, r in zip(outs, ref_gres):
+                assert all(torch.equal(x, y) for x, y in zip(o, r))
         (dz32, dg32, db32, gr32), (dz16, dg16, db16, gr16) = outs
         rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
         assert rel(dg16, dg32) < 2e-5 and rel(db16, db32) < 2e-5, mode
@@ -189,7 +195,9 @@ def test_wgrad_bf16_operands(dev, M, N, K, conv):
 
 
 @pytest.mark.parametrize('M,N,K,conv', [(2048, 256, 256, None), (4096, 64, 576, (32, 16, 64, 32, 16, 3, 3, 1, 1)), (1000, 2048, 512, None),
-                                        (16384, 64, 256, None)])
+                                        (16384, 64, 256, None),
+                                        (49152 + 136, 256, 512, None), (65536, 512, 128, None),          # (the 256 x 256 kernel's epilogue)
+                                        (48 * 32 * 32, 256, 9 * 64, (32, 32, 64, 32, 32, 3, 3, 1, 1))])
 def test_gemm_bf16_storage_statistics_epilogue(dev, M, N, K, conv):
     """Train-mode BatchNorm statistics out of the bf16-storage GEMM: per-channel sum / sum of squares of the RAW
     fp32 accumulators (taken before the output is rounded to bf16) against the fp32 kernel's on representable

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict_
 // totals to the threads of row group 0.  16 channels x 64 row groups (round 3; it was 64 x 16): the 64-channel layers
 // have up to 2048 slab rows (the stem 8192) and with 64 channels per workgroup ONE workgroup walked them, 128 dependent
 // fp64 adds per thread -- ~9 us per launch, 176 launches per training step.
-constexpr int FCH = 16, FRG = 64;
+// (FCH is a launch parameter: 16, or 4 where 16 would leave fewer than 32 workgroups -- C <= 256, the layers with the
+// most slab rows; FCH * FRG = 1024 threads either way.)
+inline int finalize_fch(int C) { return C >= 512 ? 16 : 4; }
 __device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int rows, int C, int c,
-                                            double* sh /*[2][FRG][FCH]*/, double& s, double& q) {
+                                            double* sh /*[2][FRG][FCH]*/, double& s, double& q, const int FCH) {
+    const int FRG = 1024 / FCH;
     const int cx = threadIdx.x % FCH, ry = threadIdx.x / FCH;
     s = 0.0; q = 0.0;
     if (c < C) {
@@ -105,12 +108,12 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
     const float* __restrict__ slab, int rows, int C, double count, const float* gamma,
     const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-    const float* __restrict__ pivot) {
-    __shared__ double sh[2 * FRG * FCH];
+    const float* __restrict__ pivot, const int FCH) {
+    __shared__ double sh[2 * 1024];
     const int c = blockIdx.x * FCH + (threadIdx.x % FCH);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     double s, q;
-    slab_totals(slab, rows, C, c, sh, s, q);
+    slab_totals(slab, rows, C, c, sh, s, q, FCH);
     if (threadIdx.x >= FCH || c >= C) return;
     const double md = s / count;                       // mean of (x - pivot)
     double var = q / count - md * md;
@@ -234,11 +237,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ slab,
                                                                int rows, int C, double count,
                                                                float* dgamma, float* dbeta,
-                                                               float* __restrict__ coef) {
-    __shared__ double sh[2 * FRG * FCH];
+                                                               float* __restrict__ coef, const int FCH) {
+    __shared__ double sh[2 * 1024];
     const int c = blockIdx.x * FCH + (threadIdx.x % FCH);
     double s, q;
-    slab_totals(slab, rows, C, c, sh, s, q);
+    slab_totals(slab, rows, C, c, sh, s, q, FCH);
     if (threadIdx.x >= FCH || c >= C) return;
     if (dbeta) dbeta[c] += (float)s;
     if (dgamma) dgamma[c] += (float)q;
@@ -949,8 +952,9 @@ extern "C" int grl_col_stats_rows(int M) { return (M + CHUNK - 1) / CHUNK; }
 
 int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,
                                hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, s, slab, rows, C, count, dgamma,
-                       dbeta, coef);
+    const int fch = finalize_fch(C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(grl_ceil_div(C, fch)), dim3(1024), 0, s, slab, rows, C, count, dgamma,
+                       dbeta, coef, fch);
     return grl_check_launch("bn_bwd_finalize");
 }
 
@@ -976,9 +980,10 @@ extern "C" int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t
                                      void* stream) {
     GRL_REQUIRE(slab && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, "bn_stats_finalize: bad args");
     GRL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats come together");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, FCH)), dim3(1024), 0, (hipStream_t)stream, slab,
+    const int fch = finalize_fch(C);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(grl_ceil_div(C, fch)), dim3(1024), 0, (hipStream_t)stream, slab,
                        rows, C, (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
-                       eps, mean, invstd, scale, shift, pivot);
+                       eps, mean, invstd, scale, shift, pivot, fch);
     return grl_check_launch("grl_bn_stats_finalize");
 }
 

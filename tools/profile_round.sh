@@ -16,7 +16,7 @@ pass() {  # name, rocprof args..., -- program args        (ONLY=ev|tr|c3 restric
     timeout 400 rocprofv3 "$@" > $O/$name.log 2>&1
     echo "$name rc=$?"
 }
-EV="--no-alt --no-cpu-baseline --steps 12 --warmup 4"
+EV="--no-alt --no-cpu-baseline --no-train-block --steps 12 --warmup 4"
 pass ev_stats --kernel-trace --stats --output-format csv -d $O/ev_stats -- python3 $R/bench.py $EV
 pass ev_mfma  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/ev_mfma -- python3 $R/bench.py $EV
 pass ev_fetch --pmc FETCH_SIZE --output-format csv -d $O/ev_fetch -- python3 $R/bench.py $EV
@@ -27,7 +27,18 @@ pass trm_stats --kernel-trace --stats --output-format csv -d $O/trm_stats -- pyt
 pass tr_mfma  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/tr_mfma -- python3 $R/bench.py $TR
 pass tr_fetch --pmc FETCH_SIZE --output-format csv -d $O/tr_fetch -- python3 $R/bench.py $TR
 pass tr_write --pmc WRITE_SIZE --output-format csv -d $O/tr_write -- python3 $R/bench.py $TR
-C3="--math bf16s --clips 64 --seq-len 8 --no-alt --no-cpu-baseline --steps 8 --warmup 3"
+# bf16-storage training (round 3): B x T = 32 x 4 and BASELINE configs[2] as a training batch (64 x 8)
+TB="--mode train --math bf16s --steps 4 --warmup 2"
+pass trb_stats --kernel-trace --stats --output-format csv -d $O/trb_stats -- python3 $R/bench.py $TB
+pass trb_mfma  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/trb_mfma -- python3 $R/bench.py $TB
+pass trb_fetch --pmc FETCH_SIZE --output-format csv -d $O/trb_fetch -- python3 $R/bench.py $TB
+pass trb_write --pmc WRITE_SIZE --output-format csv -d $O/trb_write -- python3 $R/bench.py $TB
+TB2="--mode train --math bf16s --clips 64 --seq-len 8 --steps 3 --warmup 2"
+pass trc_stats --kernel-trace --stats --output-format csv -d $O/trc_stats -- python3 $R/bench.py $TB2
+pass trc_mfma  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/trc_mfma -- python3 $R/bench.py $TB2
+pass trc_fetch --pmc FETCH_SIZE --output-format csv -d $O/trc_fetch -- python3 $R/bench.py $TB2
+pass trc_write --pmc WRITE_SIZE --output-format csv -d $O/trc_write -- python3 $R/bench.py $TB2
+C3="--math bf16s --clips 64 --seq-len 8 --no-alt --no-cpu-baseline --no-train-block --steps 8 --warmup 3"
 pass c3_stats --kernel-trace --stats --output-format csv -d $O/c3_stats -- python3 $R/bench.py $C3
 pass c3_mfma  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/c3_mfma -- python3 $R/bench.py $C3
 pass c3_fetch --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -- python3 $R/bench.py $C3

@@ -894,6 +894,163 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16in_kernel(const WgradArgs p, 
     }
 }
 
+// The same weight gradient on a 256 x 256 tile (N >= 256 and K >= 256: layers 3 / 4, GCE, every TRL 1x1 -- most of
+// the FLOPs).  The 128 x 128 form above moves 16 KB out of L2 per 2*128*128*32 FLOP (64 FLOP/B) and sits at the
+// L2 -> CU ceiling (~10 TB/s = 0.65 PFLOP/s); this tile halves the bytes per FLOP:
+//   * 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers), one workgroup
+//     per CU, pixel range split over gridDim.y as before;
+//   * a stage = 32 pixel rows of dz and of X, [m][256 columns] bf16 = 512-byte rows, 16-byte chunks XOR-swizzled by
+//     ((m & 3) << 2) | ((m >> 2) & 3) (the transpose reads `ds_read_b64_tr_b16` stay conflict free);
+//   * staging is LDS-DMA (`global_load_lds_dwordx4`, the swizzle and -- for the implicit-GEMM gather -- the tap on
+//     the per-lane SOURCE; rows past the pixel range / columns past N or K read a zero chunk), THREE stage buffers
+//     (96 KiB): the DMA of stage t + 2 is issued when stage t starts, waits are counted (`vmcnt(4)`: this wave's
+//     four pieces of the stage about to be read) in front of a raw barrier.
+__device__ uint4 g_wgrad_zero_chunk;
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void wgrad_b16in_256_kernel(const WgradArgs p, const int tiles_k) {
+    constexpr int TBW = 256, PLANE = 32 * 512, STG = 2 * PLANE, NBUF = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const sm8 = reinterpret_cast<char*>(smem);
+    const char* const dz8 = reinterpret_cast<const char*>(p.dz);
+    const char* const x8 = reinterpret_cast<const char*>(p.x);
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * TBW, k0 = tile_k * TBW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int m_begin = blockIdx.y * p.chunk;
+    const int m_end = min(p.M, m_begin + p.chunk);
+    // DMA pieces of this wave: piece i (0, 1) fills LDS rows 2 * (wave + 8 i) + (lane >> 5); a lane's chunk position
+    // is lane & 31 and its SOURCE chunk position ^ swizzle(row) -- the same for both pieces (rows differ by 16)
+    const int drow = 2 * wave + (lane >> 5);
+    const int sc = (lane & 31) ^ (((drow & 3) << 2) | ((drow >> 2) & 3));
+    const bool a_ok = n0 + 8 * sc < p.N;
+    const int kcol = k0 + 8 * sc;
+    const bool b_ok = kcol < p.K;
+    int ky = 0, kx = 0, cc = kcol;
+    if (CONV && b_ok) { const int tap = kcol / p.C; cc = kcol - tap * p.C; ky = tap / p.kw; kx = tap - ky * p.kw; }
+    int pimg[2], poy[2], pox[2];
+    const int adv_y = 32 / p.Wo, adv_x = 32 - adv_y * p.Wo;
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m_begin + drow + 16 * i, hw = p.Ho * p.Wo;
+            pimg[i] = m / hw;
+            const int rem = m - pimg[i] * hw;
+            poy[i] = rem / p.Wo;
+            pox[i] = rem - poy[i] * p.Wo;
+        }
+    }
+    const char* const zsrc = reinterpret_cast<const char*>(&g_wgrad_zero_chunk);
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    auto stage = [&](int buf, int m0) {                        // 4 LDS-DMA wave-instructions per wave
+        char* const base = sm8 + buf * STG;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + drow + 16 * i;
+            const char* sa = (m < m_end && a_ok) ? dz8 + ((int64_t)m * p.ldz + n0 + 8 * sc) * 2 : zsrc;
+            const char* sb = zsrc;
+            if (CONV) {
+                const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
+                if (m < m_end && b_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    sb = x8 + ((((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + cc) * 2;
+                pox[i] += adv_x;
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
+                poy[i] += adv_y;
+                while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
+            } else if (m < m_end && b_ok) {
+                sb = x8 + ((int64_t)m * p.ldx + kcol) * 2;
+            }
+            __builtin_amdgcn_global_load_lds((gp_t)sa, (lp_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gp_t)sb, (lp_t)(base + PLANE + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nst = (m_end - m_begin + 31) / 32;
+    const int fhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    if (nst > 0) stage(0, m_begin);
+    if (nst > 1) stage(1, m_begin + 32);
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    // per-lane fragment offsets inside a stage (row group rd, MFMA tile): the swizzle depends on the row only
+    unsigned aoff[4][2], boff[2][2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int row = 8 * (g >> 1) + 4 * rd + q;
+        const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wr * 128 + i * 32 + 16 * (g & 1) + 4 * pp;
+            aoff[i][rd] = 512 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wc * 64 + j * 32 + 16 * (g & 1) + 4 * pp;
+            boff[j][rd] = PLANE + 512 * row + 16 * ((col >> 3) ^ sw) + 2 * (col & 7);
+        }
+    }
+    for (int st = 0; st < nst; ++st) {
+        // this wave's four pieces of stage st have landed (the four of stage st + 1 may still be in flight) ...
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... and every wave's; all waves are out of stage st - 1
+        if (st + 2 < nst) stage((st + 2) % NBUF, m_begin + (st + 2) * 32);
+        const unsigned sbase = lds_base + (st % NBUF) * STG;
+#define GRL_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define GRL_FRAG(lo4, hi4) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                   // two k-steps of 16 rows (8192 bytes) per stage
+            s16x4 ra[4][2], rb[2][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (ks == 0) GRL_TR(ra[i][rd], sbase + aoff[i][rd], 0);
+                    else GRL_TR(ra[i][rd], sbase + aoff[i][rd], 8192);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (ks == 0) GRL_TR(rb[j][rd], sbase + boff[j][rd], 0);
+                    else GRL_TR(rb[j][rd], sbase + boff[j][rd], 8192);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(GRL_FRAG(ra[i][0], ra[i][1]), GRL_FRAG(rb[j][0], rb[j][1]),
+                                                                        acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef GRL_TR
+#undef GRL_FRAG
+    }
+    float* out = p.slab + (int64_t)blockIdx.y * p.slab_stride;
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wc * 64 + j * 32 + col_l;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (n < p.N) out[(int64_t)n * p.K + k] = acc[i][j][r];
+            }
+    }
+}
+
 // dW (torch layout [N][C][taps], or [N][K] when taps == 1) (+)= sum_z slab[z][n][t*C + c]
 // A lane owns FOUR consecutive slab columns (same tap: C % 4 == 0) and keeps four slabs' loads in flight; the sum
 // runs over z = 0, 1, 2, ... in that order whatever the unrolling (round 3: the scalar one-load-at-a-time form ran at
@@ -1116,7 +1273,7 @@ static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
         int64_t f = atoi(e);
         return (int)(f < 1 ? 1 : (f > max_splits ? max_splits : f));
     }
-    const double slots = (bm == 64 && bn == 64) ? 1024.0 : 512.0;
+    const double slots = (bm == 64 && bn == 64) ? 1024.0 : (bm == 256 ? 256.0 : 512.0);
     int64_t smax = (int64_t)(3.0 * slots / (double)tiles) + 1;
     if (smax > max_splits) smax = max_splits;
     int best = 1;
@@ -1133,7 +1290,14 @@ static int wgrad_splits(const GrlWgrad& d, int bm, int bn) {
 }
 
 static void wgrad_tile(const GrlWgrad& d, int* bm, int* bn) {
-    if (d.in_bf16) { *bm = 128; *bn = 128; return; }      // one tile shape: edges are zero-filled, tiles may straddle taps
+    if (d.in_bf16) {                                       // edges are zero-filled, tiles may straddle taps
+        static const bool big = [] { const char* e = getenv("GRL_WGRAD_B16_256"); return !e || atoi(e) != 0; }();     // (0: A/B only)
+        // (measured per shape, tools/wgrad_bench.py: with fewer than ~8 tiles of 256 x 256 the pixel range is cut into
+        // too many short splits -- 16384 x 1024 x 256: 28 -> 34 us -- so small N x K stays on the 128 x 128 tile)
+        const bool t256 = big && d.N >= 256 && d.K >= 256 && (int64_t)d.N * d.K >= (1 << 19);
+        *bm = *bn = t256 ? 256 : 128;
+        return;
+    }
     *bm = d.N >= 128 ? 128 : 64;
     const int cdiv = d.conv ? d.C : d.K;
     *bn = (cdiv % 128 == 0) ? 128 : 64;
@@ -1184,7 +1348,17 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
         if (d.conv) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true>), grid, dim3(256), lds, s, a, tiles_k);  \
         else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, false>), grid, dim3(256), lds, s, a, tiles_k);        \
     } while (0)
-    if (d.in_bf16) {
+    if (d.in_bf16 && bm == 256) {
+        constexpr size_t lds256 = (size_t)3 * 2 * 32 * 512;              // three stages of (dz, X) planes: 96 KiB
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute((const void*)wgrad_b16in_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            (void)hipFuncSetAttribute((const void*)wgrad_b16in_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            return true;
+        }();
+        (void)attr;
+        if (d.conv) hipLaunchKernelGGL((wgrad_b16in_256_kernel<true>), grid, dim3(512), lds256, s, a, tiles_k);
+        else hipLaunchKernelGGL((wgrad_b16in_256_kernel<false>), grid, dim3(512), lds256, s, a, tiles_k);
+    } else if (d.in_bf16) {
         if (d.conv) hipLaunchKernelGGL((wgrad_b16in_kernel<true>), grid, dim3(256), (size_t)4 * 32 * 256, s, a, tiles_k);
         else hipLaunchKernelGGL((wgrad_b16in_kernel<false>), grid, dim3(256), (size_t)4 * 32 * 256, s, a, tiles_k);
     } else if (bm == 128 && bn == 128 && d.math == GRL_MATH_BF16X3) {

@@ -165,6 +165,8 @@ def test_bn_backward_and_column_statistics_twins(dev, M, Cc):
 
 @pytest.mark.parametrize('M,N,K,conv', [(4096, 128, 2048, None), (1000, 64, 64, None), (5000, 256, 64, None), (260, 2048, 128, None),
                                         (1024, 64, 160, None),
+                                        (4096, 512, 2048, None), (5000, 264, 520, None), (33, 256, 256, None),     # (the 256 x 256 LDS-DMA tile)
+                                        (4 * 16 * 8, 512, 9 * 512, (16, 8, 512, 16, 8, 3, 3, 1, 1)),
                                         (2 * 16 * 8, 128, 9 * 128, (16, 8, 128, 16, 8, 3, 3, 1, 1)),
                                         (3 * 16 * 8, 64, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1)),
                                         (2 * 8 * 8, 256, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1)),

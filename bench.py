@@ -128,7 +128,7 @@ def cpu_baseline(sd, ssd):
                       "step, T=%d, %d timed passes (%.1f s)" % (cores, os.cpu_count() or 0, nb, T, passes, dt)}
 
 
-def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default'):
+def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default', graph=False):
     """One SEQTrainer step (forward + 5-term loss + HIP backward + bucketed gradient all-reduce when a process
     group is up + SGD) on b x t synthetic pair-interleaved clips per rank.  Timed with a barrier + device sync on
     both sides, MAX over ranks.  Returns a dict (ms_per_step, and the gradient-sync bookkeeping)."""
@@ -182,6 +182,13 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
 
     old = train_engine.set_math(math)
     try:
+        if graph and sync is None:
+            # the SAME step -- forward, loss block, backward on its three streams, fused SGD -- captured once into a HIP
+            # graph and replayed (grl_amd/train_graph.py; bit-identical to the eager step, tested): no Python between
+            # the ~1500 launches.  Matters where the step is host-bound (bf16 storage); single GPU only.
+            from grl_amd.train_graph import GraphedTrainStep
+            gstep = GraphedTrainStep(tr, opt, clips, pids, warmup=max(warmup, 2))
+            step = lambda: gstep()[0]
         for _ in range(warmup):
             loss = step()
         barrier()
@@ -209,8 +216,8 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
     return out
 
 
-def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4):
-    return train_series(dev, math, steps, warmup, b, t)["ms_per_step"]
+def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4, graph=False):
+    return train_series(dev, math, steps, warmup, b, t, graph=graph)["ms_per_step"]
 
 
 def train_block(dev, rank, world, dist, backend):
@@ -249,6 +256,8 @@ def secondary_block(dev, cnn, siam, steps):
     out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
         m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
         for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'mixed', 'bf16x3', 'bf16s'))}
+    # (`--mode train --graph` replays the same step from a HIP graph -- grl_amd.train_graph, bit-identical; measured 4 %
+    # SLOWER than the eager step in every mode on this stack, DESIGN.md 4c, so it is not part of the default line)
     v = train_step_ms(dev, 'bf16s', b=64, t=8)
     out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = {
         "ms_per_step": round(v, 2), "clips_per_sec": round(64 / v * 1e3, 1), "frames_per_sec": round(512 / v * 1e3)}
@@ -281,7 +290,8 @@ def train_bench(args, dev, dist, rank, world, backend):
     pair-interleaved clips per rank (mars_train.py -b 32 --seq_len 4)."""
     if args.math not in ('f32', 'mixed', 'bf16x3', 'bf16', 'bf16s'):
         raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16 | bf16s')
-    r = train_series(dev, args.math, steps=args.steps, warmup=args.warmup, b=B, t=T, rank=rank, world=world, dist=dist)
+    r = train_series(dev, args.math, steps=args.steps, warmup=args.warmup, b=B, t=T, rank=rank, world=world, dist=dist,
+                     graph=args.graph)
     if rank == 0:
         n = max(world, 1)
         line = {
@@ -294,7 +304,7 @@ def train_bench(args, dev, dist, rank, world, backend):
                       "bf16s": "bf16 storage (activations, saved tensors, activation gradients), bf16 MFMA, f32 accumulate / statistics / parameter gradients"}[args.math],
             "data": "synthetic",
             "config": {"workload": "GRL train step (fwd + loss + bwd + allreduce + SGD), B x T = %d x %d per GPU" % (B, T),
-                       "clips_per_gpu": B, "seq_len": T, "math": args.math,
+                       "clips_per_gpu": B, "seq_len": T, "math": args.math, "hip_graph_replay": bool(args.graph and dist is None),
                        "parallelism": "dp%d (4 gradient buckets all-reduced over RCCL under the backward)" % n},
             "dist_backend": backend if dist is not None else None,
             "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None,
@@ -405,6 +415,7 @@ def main():
                     help="eval (default): the headline clip-features/sec; train: secondary series, one "
                          "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
     ap.add_argument('--no-train-block', action='store_true', help='skip the configs[3] `train` block of the eval line')
+    ap.add_argument('--graph', action='store_true', help='--mode train: replay the step from a HIP graph (single GPU)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher check (CPU tests): every rank joins a gloo group, the ranks are counted with an '
                          'all-reduce, rank 0 prints {"dry_run": true, "world_size": N}; no GPU is touched')

@@ -292,7 +292,10 @@ class Tape(object):
         if key not in self.wc:
             kys = [1] if py == 0 else [2, 0]
             kxs = [1] if px == 0 else [2, 0]
-            wd = w.detach()[:, :, kys][:, :, :, kxs]              # [N][cin][kh][kw]
+            wd = w.detach()
+            # (plain selects + stack, not list indexing: an index LIST becomes a host tensor and a host->device copy,
+            # which a HIP-graph capture of the step cannot contain)
+            wd = torch.stack([torch.stack([wd[:, :, ky, kx] for kx in kxs], 2) for ky in kys], 2)      # [N][cin][kh][kw]
             self.wc[key] = wd.permute(1, 2, 3, 0).contiguous().view(w.shape[1], -1)
             if self.b16:
                 self.wc[key] = cast16(self.wc[key])

@@ -307,3 +307,57 @@ def test_bf16_storage_step_at_configs2_size_properties():
     for k in grads[0]:
         assert torch.equal(grads[1][k], grads[0][k] * 2), k
         assert torch.equal(grads[2][k], grads[0][k]), k
+
+
+@pytest.mark.parametrize('math', ['bf16s', 'f32'])
+def test_graphed_train_step_equals_eager_bit_for_bit(math):
+    """grl_amd.train_graph.GraphedTrainStep: the whole SEQTrainer step (forward, 5-term loss, HIP backward on three
+    streams, fused SGD) captured into a HIP graph.  Three replays on changing batches leave the parameters, BatchNorm
+    statistics and OIM tables bit-identical to three eager steps from the same start."""
+    import contextlib, io
+    from grl_amd import train_engine as TE
+    from grl_amd.train_graph import GraphedTrainStep
+    from grl_amd.reid import models
+    from grl_amd.reid.train import SEQTrainer
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.synthetic import synth_state_dict, synth_clips_structured
+    dev = torch.device('cuda:0')
+    B, T = 8, 4
+
+    def build():
+        with contextlib.redirect_stdout(io.StringIO()):
+            cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+        siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+        siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+        cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'))
+        siam.load_state_dict(synth_state_dict(siam, seed=0, prefix='siamese.'))
+        siamv.load_state_dict(synth_state_dict(siamv, seed=0, prefix='siamese_video.'))
+        mods = [m.to(dev).train() for m in (cnn, siam, siamv)]
+        crits = [OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev) for _ in range(2)]
+        tr = SEQTrainer(mods[0], mods[1], mods[2], PairLoss().to(dev), crits[0], crits[1], None)
+        opt = torch.optim.SGD(tr._all_params(), lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True, fused=True)
+        return tr, opt, mods, crits
+
+    batches = [(synth_clips_structured(B, T, seed=60 + i).to(dev), (torch.tensor([5, 5, 9, 9, 300, 300, 77, 77]) + i).to(dev))
+               for i in range(5)]
+
+    def snap(mods, crits):
+        return [v.detach().clone() for m in mods for v in m.state_dict().values()] + [c.lut.detach().clone() for c in crits]
+    old = TE.set_math(math)
+    try:
+        tr, opt, mods, crits = build()                      # eager: 2 warm-up steps + 3 steps
+        losses_e = []
+        for i, (c, p) in enumerate(batches):
+            out = tr._forward([c], p, 0, 0)
+            opt.zero_grad(set_to_none=True); out[0].backward(); opt.step()
+            losses_e.append(float(out[0].detach()))
+        ref = snap(mods, crits)
+        tr, opt, mods, crits = build()                      # graphed: two real warm-up steps inside the constructor, then 3 replays
+        step = GraphedTrainStep(tr, opt, batches[2][0], batches[2][1], warmup_batches=batches[:2])
+        for i in (2, 3, 4):
+            out = step(*batches[i])
+            assert float(out[0].detach()) == losses_e[i], (i, float(out[0].detach()), losses_e[i])
+        got = snap(mods, crits)
+    finally:
+        TE.set_math(old)
+    assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))

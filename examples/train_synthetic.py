@@ -112,7 +112,7 @@ if __name__ == '__main__':
     ap.add_argument('--iters', type=int, default=4)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--augment', action='store_true', help='raw uint8 clips + on-device flip / erase / normalise')
-    ap.add_argument('--train-math', default=None, choices=['f32', 'mixed', 'bf16x3', 'bf16'],
+    ap.add_argument('--train-math', default=None, choices=['f32', 'mixed', 'bf16x3', 'bf16', 'bf16s'],
                     help="training GEMM datapath (grl_amd.train_engine.set_math; default exact fp32; 'mixed' = fp32 forward, "
                          "split-bf16 backward GEMMs)")
     ap.add_argument('--seed', type=int, default=0)

@@ -43,6 +43,8 @@ _TRAIN_MATH = {'f32': (MATH_F32, MATH_F32), 'bf16x3': (engine.MATH_BF16X3, engin
                'bf16s': (MATH_F32, MATH_F32)}       # (bf16s: the datapath follows the operand dtype, see gemm below)
 BF16 = torch.bfloat16
 _train_mode = [__import__('os').environ.get('GRL_TRAIN_MATH', 'f32')]
+_in_backward = [False]   # a tape is replaying (Tape.backward): see gemm()
+_BWD_KBLOCK = __import__('os').environ.get('GRL_BWD_KBLOCK') == '1'      # A/B only: K-blocked data gradients as in round 2
 _train_math = [_TRAIN_MATH[_train_mode[0]][0]]       # datapath of the GEMMs issued NOW (Tape.backward switches it)
 
 
@@ -66,7 +68,11 @@ def gemm(a, w, *args, **kw):
         return engine.gemm(a, w, *args, **kw)
     kw.setdefault('math', _train_math[0])
     if kw['math'] == MATH_F32:
-        kw.setdefault('kblock', True)    # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock)
+        # K-blocked accumulation (include/grl_hip.h: GrlGemm.kblock) in the FORWARD -- it decides the ReLU masks and
+        # with them the parameter gradients' agreement with the reference -- and for the skinny GEMMs of either pass
+        # (M <= 256: K-blocked is what lets them split over K).  The data-gradient GEMMs of the backward keep the one
+        # chain: no mask depends on them, and the K-blocked kernels cost ~4 % on K >= 1024 (round 3).
+        kw.setdefault('kblock', (not _in_backward[0]) or args[1] <= 256 or _BWD_KBLOCK)
     return engine.gemm(a, w, *args, **kw)
 
 
@@ -310,11 +316,13 @@ class Tape(object):
                 sync.own(p, self.flat, off)
         fwd_math = _train_math[0]
         _train_math[0] = _TRAIN_MATH[_train_mode[0]][1]          # 'mixed': the backward GEMMs' datapath
+        was, _in_backward[0] = _in_backward[0], True
         try:
             for fn in reversed(self.ops):
                 fn()
         finally:
             _train_math[0] = fwd_math
+            _in_backward[0] = was
         self.wgrad_join()
         self.ops = _Ops(self)
 

@@ -1,43 +1,51 @@
 #!/usr/bin/env python
-"""cProfile of the host side of one training step (which Python functions the launch overhead sits in).
-   python tools/train_host_profile.py [math]"""
+"""cProfile of the host side of the CNN's training forward AND backward (the backward closures normally run on
+autograd's worker thread, out of cProfile's sight: here the tape is replayed from the main thread).
+   python tools/train_host_profile.py [math] [B] [T]"""
 import os, sys, contextlib, io, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from grl_amd import train_engine as TE
+from grl_amd import train_engine as TE, engine
 from grl_amd.reid import models
-from grl_amd.reid.train import SEQTrainer
-from grl_amd.reid.loss import OIMLoss, PairLoss
 from grl_amd.synthetic import synth_clips, synth_state_dict
 math = sys.argv[1] if len(sys.argv) > 1 else 'bf16s'
+B, T = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (32, 4)
 dev = torch.device('cuda:0')
 with contextlib.redirect_stdout(io.StringIO()):
     cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
-siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
-siamv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
 cnn.load_state_dict(synth_state_dict(cnn, seed=0))
-cnn, siam, siamv = cnn.to(dev).train(), siam.to(dev).train(), siamv.to(dev).train()
-tr = SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev),
-                OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), None)
-opt = torch.optim.SGD(tr._all_params(), lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True, fused=True)
-clips = synth_clips(32, 4, seed=0).to(dev)
-pids = (torch.arange(32, device=dev) // 2 * 7) % 625
+cnn = cnn.to(dev).train()
+clips = synth_clips(B, T, seed=0).to(dev)
+r1, r2 = torch.randn(B, 2048, device=dev), torch.randn(B, T, 2048, device=dev)
 TE.set_math(math)
+params = tuple(cnn.parameters())
 
 
-def step():
-    loss, _, _, _ = tr._forward([clips], pids, 0, 0)
-    opt.zero_grad(); loss.backward(); opt.step()
+def fwd_bwd():
+    """what _GrlTrainFn.forward / backward do, on this thread"""
+    tp = TE.Tape(dev)
+    tp.b16 = math == 'bf16s'
+    tp.reserve_param_grads(params, cuts=TE._grl_cuts(cnn))
+    x = clips.view(B * T, 3, 256, 128)
+    x4 = TE.trunk_train(tp, cnn, x)
+    xu, xc, _ = TE.gce_train(tp, cnn, x4, B, T)
+    fu, fc = TE.trl_train(tp, cnn, xu, xc, B, T)
+    fc2d = fc.view(B * T, 2048)
+    xcn = TE.bn1d_l2norm(tp, fc2d, B * T, 2048, cnn.corr_bn)
+    xun = TE.bn1d_l2norm(tp, fu, B, 2048, cnn.uncorr_bn)
+    tp.g[id(xun)] = r1
+    tp.g[id(xcn)] = r2.view(B * T, 2048)
+    tp.backward()
 
 
 for _ in range(3):
-    step()
+    fwd_bwd()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
-    step()
+    fwd_bwd()
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(32)

@@ -220,10 +220,10 @@ class Tape(object):
             self.wheld = []
 
     def flush(self, lo=0, label='rest'):
-        self.wgrad_join()
         sync = _grad_sync[0]
         if sync is None or self.flat is None or lo is None:
-            return
+            return                  # (single GPU: nothing consumes parameter gradients before the end of the backward,
+        self.wgrad_join()           #  where Tape.backward joins the weight-gradient stream; no mid-backward joins)
         hi = self.flat.numel() - self._sent
         if lo < hi:
             sync.reduce(self.flat[lo:hi], label)

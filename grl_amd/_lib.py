@@ -39,6 +39,11 @@ class GrlWgrad(C.Structure):
                                     'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math', 'in_bf16')]
 
 
+class GrlPrepEntry(C.Structure):
+    _fields_ = [('src', _fp), ('dst', _fp), ('base', _i64), ('strides', _i64 * 4), ('dims', _i32 * 4),
+                ('tiled', _i32), ('out_bf16', _i32)]
+
+
 _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
@@ -137,6 +142,7 @@ _SIGNATURES = {
     'grl_add_rowbcast_bf16': ([_fp, _fp, _i64, _i64, _i64, C.c_float, C.c_int, C.c_int, _fp], C.c_int),
     'grl_sqdiff_bwd_bf16': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _i64, C.c_int, _fp], C.c_int),
     'grl_cast_f32': ([_fp, _fp, _i64, _fp], C.c_int),
+    'grl_weight_prep': ([_fp, C.c_int, _fp], C.c_int),
 }
 
 _lib = None

@@ -341,6 +341,50 @@ __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict_
         if (c0 + j < C && r0 + tx < R) y[(int64_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
 }
 
+// ---------------------------------------------------------------------------------
+// All weight re-layouts of one training step in ONE launch (round 3).  A step needs ~90 packed / transposed copies of
+// the parameters (tap-major 3x3 packs, transposes and tap-flipped packs for the data gradients, the parity-class packs
+// of the stride-2 data gradients) and, in bf16 storage, ~140 bf16 casts: 230 tiny launches, 15 % of all launches of a
+// step that is host-bound in that mode.  Every one of them is a gather dst[j] = src[base + sum_d i_d * stride_d]
+// over at most four destination dimensions (+ an optional bf16 rounding); 2-D transposes go through LDS tiles.  The
+// table lives in device memory and is built once per model (train_engine.WeightPrep): sources are the parameters
+// themselves, destinations persistent buffers.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const GrlPrepEntry* __restrict__ table) {
+    __shared__ float tile[32][33];
+    const GrlPrepEntry e = table[blockIdx.y];
+    const float* __restrict__ src = e.src + e.base;
+    float* const d32 = reinterpret_cast<float*>(e.dst);
+    __bf16* const d16 = reinterpret_cast<__bf16*>(e.dst);
+    if (e.tiled) {                     // dst[r][c] = src[r * strides[2] + c * strides[3]], strides[2] == 1 (a transpose)
+        const int R = e.dims[2], Cn = e.dims[3];
+        const int tr = (R + 31) / 32, tc = (Cn + 31) / 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+            const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+            __syncthreads();
+            for (int j = ty; j < 32; j += 8)            // read along r (the source's contiguous direction)
+                if (c0 + j < Cn && r0 + tx < R) tile[j][tx] = src[(int64_t)(c0 + j) * e.strides[3] + (r0 + tx)];
+            __syncthreads();
+            for (int j = ty; j < 32; j += 8)
+                if (r0 + j < R && c0 + tx < Cn) {
+                    const float v = tile[tx][j];
+                    const int64_t o = (int64_t)(r0 + j) * Cn + c0 + tx;
+                    if (e.out_bf16) d16[o] = (__bf16)v; else d32[o] = v;
+                }
+        }
+        return;
+    }
+    const int64_t n3 = e.dims[3], n2 = e.dims[2], n1 = e.dims[1];
+    const int64_t total = (int64_t)e.dims[0] * n1 * n2 * n3;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i3 = j % n3, r3 = j / n3;
+        const int64_t i2 = r3 % n2, r2 = r3 / n2;
+        const int64_t i1 = r2 % n1, i0 = r2 / n1;
+        const float v = src[i0 * e.strides[0] + i1 * e.strides[1] + i2 * e.strides[2] + i3 * e.strides[3]];
+        if (e.out_bf16) d16[j] = (__bf16)v; else d32[j] = v;
+    }
+}
+
 // data-gradient weights of a kxk conv: out[c][kk-1-t][n] = w[n][c][t]
 __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
                                          int N, int C, int taps) {
@@ -1224,6 +1268,12 @@ extern "C" int grl_transpose(const float* x, float* y, int R, int C, int ldx, vo
     hipLaunchKernelGGL(transpose_kernel, dim3(grl_ceil_div(C, 32), grl_ceil_div(R, 32)), dim3(256), 0,
                        (hipStream_t)stream, x, y, R, C, ldx);
     return grl_check_launch("grl_transpose");
+}
+
+extern "C" int grl_weight_prep(const GrlPrepEntry* table_dev, int count, void* stream) {
+    GRL_REQUIRE(table_dev && count > 0, "weight_prep: bad args");
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(64, count), dim3(256), 0, (hipStream_t)stream, table_dev);
+    return grl_check_launch("grl_weight_prep");
 }
 
 extern "C" int grl_pack_dgrad_weight(const float* w, float* out, int N, int C, int kh, int kw, void* stream) {

@@ -451,6 +451,22 @@ int grl_rerank_expand(const float* V, const int32_t* rank, const int32_t* lcnt, 
 int grl_rerank_jaccard(const float* V2q, const float* V2T, const float* D, int N, int nq,
                        float lambda_value, float one_minus_lambda, float* out, void* stream);
 
+/* All weight re-layouts (and bf16 casts) of one training step in one launch: a table of gathers
+ * dst[j] = src[base + i0*strides[0] + i1*strides[1] + i2*strides[2] + i3*strides[3]], j = ((i0*dims[1] + i1)*dims[2] +
+ * i2)*dims[3] + i3, fp32 in, fp32 or bf16 out; `tiled` = a 2-D transpose (dims[0] = dims[1] = 1, strides[2] = 1)
+ * through LDS tiles.  The table is DEVICE memory (built once per model by the host); it replaces, per step, the
+ * grl_pack_conv_weight / grl_transpose / grl_pack_dgrad_weight / grl_cast_bf16 launches of
+ * resnets1.py:62-68's and grl_model.py:95-121's weights. */
+typedef struct GrlPrepEntry {
+    const float* src;
+    void*        dst;
+    int64_t      base;
+    int64_t      strides[4];
+    int32_t      dims[4];
+    int32_t      tiled, out_bf16;
+} GrlPrepEntry;
+int grl_weight_prep(const GrlPrepEntry* table_dev, int count, void* stream);
+
 /* ---- bf16-STORAGE training (train_engine.set_math('bf16s'); BASELINE configs[2] as a training batch) -------------
  * The twins of the train-mode kernels above for bf16 activations / saved tensors / activation gradients in HBM
  * (`void*` = bf16 tensor); statistics, per-channel vectors and parameter gradients stay fp32.  Same reference call

@@ -361,3 +361,37 @@ def test_graphed_train_step_equals_eager_bit_for_bit(math):
     finally:
         TE.set_math(old)
     assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16s'])
+def test_weight_prep_table_equals_per_layer_path(math):
+    """train_engine.WeightPrep: from the second step on every packed / transposed / bf16-cast weight of the step comes
+    out of ONE grl_weight_prep launch (a table of gathers logged during the first step).  Three steps with it leave
+    parameters and gradients bit-identical to three steps on the per-layer path, and the table covers the step."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clips = [synth_clips_structured(B, T, seed=70 + i).cuda() for i in range(3)]
+    g = torch.Generator().manual_seed(3)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs = []
+    old = TE.set_math(math)
+    try:
+        for prep in (True, False):
+            TE.WEIGHT_PREP = prep
+            cnn = _fresh()
+            opt = torch.optim.SGD(cnn.parameters(), lr=1e-2, momentum=0.9)
+            for c in clips:
+                xu, xc = cnn(c)
+                opt.zero_grad(set_to_none=True)
+                ((xu * r1).sum() + (xc * r2).sum()).backward()
+                opt.step()
+            outs.append(([p.detach().clone() for p in cnn.parameters()], [p.grad.clone() for p in cnn.parameters() if p.grad is not None]))
+            if prep:
+                wp = cnn.__dict__['_grl_weight_prep'][math == 'bf16s']
+                assert wp.ready and wp.count >= (120 if math == "bf16s" else 80), wp.count
+    finally:
+        TE.WEIGHT_PREP = True
+        TE.set_math(old)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

@@ -229,8 +229,21 @@ def train_block(dev, rank, world, dist, backend):
            "n_gpus": max(world, 1), "dist_backend": backend if dist is not None else None,
            "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None}
     for m in ('f32', 'mixed'):
+        release_cached_blocks()
         out[m] = train_series(dev, m, steps=5, warmup=2, b=64, t=4, rank=rank, world=world, dist=dist)
     return out
+
+
+def release_cached_blocks():
+    """Between two series of one process, never inside a timed region: drop the previous series' model / optimizer
+    and hand its cached blocks back to the driver, so that every series starts from the allocator state of a fresh
+    process.  (Round 3 found a later series up to 40 % slower than in a fresh process -- bf16x3 train 54-64 ms vs
+    39.3; the cause was a Tape <-> closure-list reference cycle in train_engine that kept every finished step's flat
+    gradient buffer alive until a full garbage collection.  Fixed there; tools/train_mode_sequence.py)"""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
 
 def secondary_block(dev, cnn, siam, steps):
@@ -240,6 +253,7 @@ def secondary_block(dev, cnn, siam, steps):
     from grl_amd import engine
     from grl_amd.synthetic import synth_clips, synth_eval_features
     out = {}
+    release_cached_blocks()
     c3 = synth_clips(64, 8, seed=0).to(dev)
     with engine.math_mode('bf16s'):
         for _ in range(3):
@@ -253,12 +267,17 @@ def secondary_block(dev, cnn, siam, steps):
     out["configs[2] bf16s, 64 clips x 8 frames"] = {"clip_features_per_sec": round(64 / ms * 1e3, 1), "ms_per_step": round(ms, 3),
                                                      "frames_per_sec": round(512 / ms * 1e3)}
     del c3
+
+    def fresh(m, **kw):
+        release_cached_blocks()
+        return train_step_ms(dev, m, **kw)
     out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
         m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
-        for m, v in ((m, train_step_ms(dev, m)) for m in ('f32', 'mixed', 'bf16x3', 'bf16s'))}
+        for m, v in ((m, fresh(m)) for m in ('f32', 'mixed', 'bf16x3', 'bf16s'))}
     # (`--mode train --graph` replays the same step from a HIP graph -- grl_amd.train_graph, bit-identical; measured 4 %
     # SLOWER than the eager step in every mode on this stack, DESIGN.md 4c, so it is not part of the default line)
-    v = train_step_ms(dev, 'bf16s', b=64, t=8)
+    v = fresh('bf16s', b=64, t=8)
+    release_cached_blocks()
     out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = {
         "ms_per_step": round(v, 2), "clips_per_sec": round(64 / v * 1e3, 1), "frames_per_sec": round(512 / v * 1e3)}
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]

@@ -12,6 +12,7 @@ Reference call sites: reid/models/grl_model.py:211-228 (+ basebranch.py:52-68,
 resnets1.py:73-109), reid/models/Siamese.py:79-142, reid/models/Siamese_video.py:158-184.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -123,10 +124,11 @@ class _Ops(list):
 
     def __init__(self, tape):
         list.__init__(self)
-        self.tape = tape
+        self._tape = weakref.ref(tape)       # weak: Tape <-> _Ops must not be a cycle, or every finished step's
+                                             # flat gradient buffer waits for a full garbage collection
 
     def append(self, fn):
-        side = self.tape.side
+        side = self._tape().side
         if side is not None:
             inner = fn
 

@@ -54,7 +54,28 @@ __global__ void bn_apply_centered_b16_kernel(const __bf16* __restrict__ z, const
                                              const float* __restrict__ scale, const float* __restrict__ beta,
                                              const __bf16* __restrict__ res, __bf16* __restrict__ y, int C8,
                                              int64_t total8, int relu) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (step % C8 == 0) {
+        // a thread meets the SAME eight channels in every iteration: their vectors live in registers (three 32-byte
+        // vector loads per 16 bytes of payload were L1 traffic that capped the pass below the HBM rate)
+        const int c = (int)(i % C8) * 8;
+        const f32x8 mu = ld8f(mean + c), sc = ld8f(scale + c);
+        f32x8 be = zero8();
+        if (beta) be = ld8f(beta + c);
+        for (; i < total8; i += step) {
+            f32x8 v = (ld8(z + i * 8) - mu) * sc;
+            if (beta) v += be;
+            if (res) v += ld8(res + i * 8);
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            st8(y + i * 8, v);
+        }
+        return;
+    }
+    for (; i < total8; i += step) {
         const int c = (int)(i % C8) * 8;
         f32x8 v = (ld8(z + i * 8) - ld8f(mean + c)) * ld8f(scale + c);
         if (beta) v += ld8f(beta + c);
@@ -149,7 +170,39 @@ __global__ void bn_bwd_apply_b16_kernel(const __bf16* __restrict__ dy, const __b
                                         int64_t total8, __bf16* __restrict__ gres, int gres_accumulate,
                                         const float* __restrict__ mscale, const float* __restrict__ mbeta) {
     const int C8 = C >> 3;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (step % C8 == 0) {              // a thread's eight channels are loop-invariant: the vectors live in registers
+        const int c = (int)(i % C8) * 8;
+        const f32x8 mu = ld8f(mean + c), is = ld8f(invstd + c), k0 = ld8f(coef + c), k1 = ld8f(coef + C + c);
+        f32x8 gm = is;
+        if (gamma) gm = gm * ld8f(gamma + c);
+        f32x8 ms = zero8(), mb = zero8();
+        if (mscale) ms = ld8f(mscale + c);
+        if (mbeta) mb = ld8f(mbeta + c);
+        for (; i < total8; i += step) {
+            f32x8 g = ld8(dy + i * 8);
+            const f32x8 zc = ld8(z + i * 8) - mu;
+            if (act) {
+                const f32x8 a = ld8(act + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            } else if (mscale) {
+                f32x8 t = zc * ms;
+                if (mbeta) t += mb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = t[e] > 0.f ? g[e] : 0.f;
+            }
+            if (gres) {
+                f32x8 r = g;
+                if (gres_accumulate) r += ld8(gres + i * 8);
+                st8(gres + i * 8, r);
+            }
+            st8(dz + i * 8, gm * (g - k0 - (zc * is) * k1));
+        }
+        return;
+    }
+    for (; i < total8; i += step) {
         const int c = (int)(i % C8) * 8;
         f32x8 g = ld8(dy + i * 8);
         const f32x8 zc = ld8(z + i * 8) - ld8f(mean + c);

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
 
-ABI_VERSION = 3       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+ABI_VERSION = 4       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
@@ -82,6 +82,8 @@ _SIGNATURES = {
     'grl_pack_dgrad_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_dilate2': ([_fp, _fp] + [C.c_int] * 9 + [_fp], C.c_int),
     'grl_maxpool3x3s2_bwd': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_stem_wgrad_workspace_floats': ([C.c_int, C.c_int, C.c_int], _i64),
+    'grl_stem_wgrad': ([_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_im2col': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_wgrad_workspace_floats': ([C.POINTER(GrlWgrad)], _i64),
     'grl_conv_wgrad_f32': ([C.POINTER(GrlWgrad), _fp], C.c_int),

@@ -17,6 +17,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -573,6 +575,145 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// Weight gradient of the 7x7/s2 stem conv WITHOUT the im2col matrix (round 3): dW[o][k] = sum_m dz[m][o] * col[m][k],
+// k = (c*7+ky)*7+kx (torch's [64][3][7][7]), col[m][k] = x[img][c][2oy-3+ky][2ox-3+kx].  The im2col matrix is
+// 1048576 x 160 floats = 671 MB per 32 x 4 step, written by one launch and read back by the next (0.44 + 0.26 ms at
+// the very end of the backward, where nothing overlaps it).  Here a persistent workgroup walks 8 x 16-pixel tiles:
+// the tile's NCHW input patch (3 x 21 x 37, as in the forward stem kernel) and its dz rows go to LDS, the B operand
+// col[m][k] is read out of the patch through a k -> offset table (ds_read_b32), and each of the eight waves accumulates one 32-channel
+// half of the 64 x 160 result over its quarter of the tile's pixels in 5 v_mfma_f32_32x32x2_f32 accumulators.  Exact fp32
+// products in every training math mode (dz may be stored as bf16: converted exactly).  The workgroups' partial
+// results go to `ws` slabs, summed in slab order by wgrad_reduce_kernel: deterministic.
+constexpr int SW_TH = 8, SW_TW = 16, SW_PH = 2 * SW_TH + 5, SW_PW = 2 * SW_TW + 5, SW_PWP = SW_PW + 1;
+constexpr int SW_PATCH = 3 * SW_PH * SW_PWP;          // floats; cell SW_PATCH is a zero (padded k)
+constexpr int SW_K = 160;
+constexpr int SW_WGS = 512;                           // persistent workgroups = partial slabs
+
+template <bool DZ16>
+__global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dzv,
+                                                         float* __restrict__ ws, int n, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float patch[SW_PATCH + 4];
+    __shared__ __attribute__((aligned(16))) float dzs[128 * 64];      // [pixel][channel ^ 32*(pixel & 1)]: see below
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tx_n = (Wo + SW_TW - 1) / SW_TW, ty_n = (Ho + SW_TH - 1) / SW_TH;
+    const int tiles = n * ty_n * tx_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    // eight waves: wave = 2 * (pixel quarter) + (channel tile).  A wave accumulates its 32 output channels x 160 k over
+    // its quarter of every tile's pixels: five accumulators (80 AGPRs), two waves per SIMD
+    const int ot = wave & 1, pq = wave >> 1;
+    // the lane's five B columns k = kt*32 + l31 -> offset into the patch (k >= 147: the zero cell)
+    int koff[5];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+        const int k = kt * 32 + l31;
+        koff[kt] = k < 147 ? ((k / 49) * SW_PH + (k / 7) % 7) * SW_PWP + k % 7 : -1;
+    }
+    f32x16 acc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    if (tid < 4) patch[SW_PATCH + tid] = 0.f;
+    constexpr int P_N = 3 * SW_PH * SW_PW, P_IT = (P_N + 511) / 512;
+    float pv[P_IT];
+    f32x4 dv[4];                                       // 128 pixels x 16 float4: item = tid + it*512 -> (pixel, quad)
+    // a thread stages the SAME patch cells and dz quads of every tile: their coordinates are computed once
+    int p_rq[P_IT], p_g[P_IT], p_l[P_IT];              // (row << 8 | col) inside the patch, global / LDS offsets
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int i = tid + it * 512;
+        const int c = i / (SW_PH * SW_PW), r = (i / SW_PW) % SW_PH, q = i % SW_PW;
+        p_rq[it] = i < P_N ? (r << 8 | q) : -1;
+        p_g[it] = (c * H + r) * W + q;
+        p_l[it] = (c * SW_PH + r) * SW_PWP + q;
+    }
+    // global -> registers for tile t (every load issued before anything waits)
+    auto fetch = [&](const int t) {
+        const int img = t / (ty_n * tx_n), tr = t - img * (ty_n * tx_n);
+        const int oy0 = (tr / tx_n) * SW_TH, ox0 = (tr % tx_n) * SW_TW;
+        const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+        const float* xi = x + (int64_t)img * 3 * H * W + (int64_t)iy0 * W + ix0;
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int iy = iy0 + (p_rq[it] >> 8), ix = ix0 + (p_rq[it] & 255);
+            const bool ok = p_rq[it] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            pv[it] = ok ? xi[p_g[it]] : 0.f;
+        }
+        const int64_t row0 = ((int64_t)img * Ho + oy0) * Wo + ox0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * 512, m = i >> 4, q4 = (i & 15) * 4;
+            const int my = m / SW_TW, mx = m % SW_TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy0 + my < Ho && ox0 + mx < Wo) {
+                const int64_t row = row0 + (int64_t)my * Wo + mx;
+                if (DZ16) {
+                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dzv) + row * 64 + q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)h[e];
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dzv) + row * 64 + q4);
+                }
+            }
+            dv[it] = v;
+        }
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        __syncthreads();                               // the previous tile's MFMAs are done with the LDS tiles
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (p_rq[it] >= 0) patch[p_l[it]] = pv[it];
+        // dz rows: odd pixels are stored with their two 32-channel halves swapped, so the two half-waves of an A read
+        // (pixels m, m+1; same channel tile) hit disjoint banks
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * 512, m = i >> 4, q4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(dzs + m * 64 + (q4 ^ ((m & 1) << 5))) = dv[it];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < tiles) fetch(t + gridDim.x);      // the next tile's loads fly under this tile's MFMAs
+        // pixels pq*32 .. pq*32+31, two per MFMA step (lane half lh takes pixel 2s + lh)
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int m = pq * 32 + 2 * sidx + lh;
+            const int pb = (2 * (pq * 2 + (sidx >> 3))) * SW_PWP + 2 * ((2 * sidx + lh) & 15);
+            const float a = dzs[m * 64 + ((ot * 32 + l31) ^ ((m & 1) << 5))];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                const float b = patch[koff[kt] < 0 ? SW_PATCH : pb + koff[kt]];
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kt], 0, 0, 0);
+            }
+        }
+    }
+    // the four pixel quarters summed in order through LDS (reusing the dz tile: 2 channel tiles x 3 x 4 KB per
+    // accumulator), the quarter-0 waves write the workgroup's slab [64][160]
+    float* red = dzs;
+    float* out = ws + (int64_t)blockIdx.x * 64 * SW_K;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        __syncthreads();
+        if (pq > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((ot * 3 + pq - 1) * 16 + r) * 64 + lane] = acc[b][r];
+        }
+        __syncthreads();
+        if (pq == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[b][r];
+                v += red[((ot * 3 + 0) * 16 + r) * 64 + lane];
+                v += red[((ot * 3 + 1) * 16 + r) * 64 + lane];
+                v += red[((ot * 3 + 2) * 16 + r) * 64 + lane];
+                const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[o * SW_K + b * 32 + l31] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Weight-gradient GEMM:  dW[n][k] = sum_m dz[m][n] * Xg[m][k]   (reduction over pixels)
 // Both operands are stored with the reduction index as the ROW, so a stage is a copy of
 // 32 rows of dz (BM floats) and 32 (gathered) rows of X (BN floats) into LDS as
@@ -590,8 +731,6 @@ struct WgradArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // MATH 0: exact fp32 (above).  MATH 3 / 1 (128 x 128 tiles only): the staging pass splits every
 // operand value into bf16 hi (+ lo = bf16(v - hi) for MATH 3) and writes [m][out] bf16 planes with
@@ -1364,6 +1503,31 @@ extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, 
     hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, col, H, W, Kp,
                        total);
     return grl_check_launch("grl_stem_im2col");
+}
+
+static int stem_wgrad_wgs(int n, int H, int W) {
+    const int64_t tiles = (int64_t)n * grl_ceil_div(H / 2, SW_TH) * grl_ceil_div(W / 2, SW_TW);
+    return (int)(tiles < SW_WGS ? tiles : SW_WGS);
+}
+
+extern "C" int64_t grl_stem_wgrad_workspace_floats(int n, int H, int W) {
+    return n > 0 && H > 0 && W > 0 ? (int64_t)stem_wgrad_wgs(n, H, W) * 64 * SW_K : 0;
+}
+
+extern "C" int grl_stem_wgrad(const float* x, const void* dz, int dz_bf16, float* dw, float* ws, int n, int H, int W,
+                              int accumulate, void* stream) {
+    GRL_REQUIRE(x && dz && dw && ws && n > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_wgrad: bad args");
+    GRL_REQUIRE(((uintptr_t)dz & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)dw & 3) == 0, "stem_wgrad: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int wgs = stem_wgrad_wgs(n, H, W);
+    if (dz_bf16)
+        hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(wgs), dim3(512), 0, s, x, dz, ws, n, H, W);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(wgs), dim3(512), 0, s, x, dz, ws, n, H, W);
+    if (int e = grl_check_launch("grl_stem_wgrad")) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)64 * (SW_K / 4))), dim3(256), 0, s, ws, wgs,
+                       (int64_t)64 * SW_K, 64, SW_K, 1, SW_K, dw, 147, accumulate ? 1 : 0);
+    return grl_check_launch("grl_stem_wgrad (reduce)");
 }
 
 // How many private slabs the pixel range is split into.  The grid is tiles x splits workgroups

@@ -12,6 +12,7 @@ Reference call sites: reid/models/grl_model.py:211-228 (+ basebranch.py:52-68,
 resnets1.py:73-109), reid/models/Siamese.py:79-142, reid/models/Siamese_video.py:158-184.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -424,6 +425,9 @@ class Tape(object):
         self.ops = _Ops(self)
 
 
+STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
+
+
 def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
     """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32 (datapath: the training math mode)."""
     d = GrlWgrad()
@@ -761,9 +765,14 @@ def trunk_train(tp, model, x):
         da = _newl((M0, 64), dp)
         _call(_k('grl_maxpool3x3s2_bwd', dp), ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
         dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
-        col = _newl((M0, 160), dp)
-        _call(_k('grl_stem_im2col', dp), ptr(x), ptr(col), n, H0, W0, 160)    # H, W are rebound below
-        wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
+        if STEM_WGRAD_FUSED:          # straight from the NCHW clip: no 671 MB im2col matrix (csrc/train.hip)
+            ws = torch.empty(_lib.load().grl_stem_wgrad_workspace_floats(n, H0, W0), dtype=torch.float32, device=tp.dev)
+            _call('grl_stem_wgrad', ptr(x), ptr(dz), 1 if dz.dtype == BF16 else 0, ptr(tp.pgrad(conv1.weight)), ptr(ws),
+                  n, H0, W0, 1)                                               # H, W are rebound below
+        else:
+            col = _newl((M0, 160), dp)
+            _call(_k('grl_stem_im2col', dp), ptr(x), ptr(col), n, H0, W0, 160)
+            wgrad(dz, col, tp.pgrad(conv1.weight), M0, 64, 160, k_out=147)
     tp.ops.append(bwd_stem)
 
     if tp.taps is not None:

@@ -34,8 +34,8 @@ extern "C" {
 const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
- * grew, grl_bn_bwd gained two pointers -- round 3: 3). */
-#define GRL_ABI_VERSION 3
+ * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad). */
+#define GRL_ABI_VERSION 4
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */
@@ -324,6 +324,14 @@ int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W,
 /* nn.MaxPool2d(3,2,1) backward (first-maximum rule, deterministic gather form) */
 int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
                          void* stream);
+/* Weight gradient of the 7x7/s2/p3 stem conv (resnets1.py:106-107 / basebranch.py:27) straight from the NCHW clip:
+ * dw[64][3][7][7] (+)= sum over output pixels of dz[pixel][64] (x) the pixel's 147 input taps -- no im2col matrix
+ * (grl_stem_im2col + grl_conv_wgrad_f32 write and re-read 671 MB per 32 x 4 step).  x: fp32 [n][3][H][W]; dz: fp32, or
+ * bf16 when dz_bf16 (converted exactly); exact fp32 products.  ws: grl_stem_wgrad_workspace_floats(n, H, W) floats
+ * (one partial [64][160] per persistent workgroup, summed in workgroup order: deterministic). */
+int64_t grl_stem_wgrad_workspace_floats(int n, int H, int W);
+int grl_stem_wgrad(const float* x, const void* dz, int dz_bf16, float* dw, float* ws, int n, int H, int W,
+                   int accumulate, void* stream);
 /* im2col of the NCHW stem input for the 7x7 weight gradient: [n*H/2*W/2][Kp], 147 real columns */
 int grl_stem_im2col(const float* x, float* col, int n, int H, int W, int Kp, void* stream);
 

@@ -397,3 +397,39 @@ def test_bn_backward_mask_recomputed_from_z_is_the_activation_mask(M, Cc):
         dz = TE.bn_backward(dy, z, a, st, bn.weight, dg, db, M, Cc, mask_from_z=from_z)
         out.append((dz, dg, db))
     assert all(torch.equal(x, y) for x, y in zip(*out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,H,W", [(3, 64, 32), (2, 256, 128), (2, 36, 20), (1, 16, 32)])
+@pytest.mark.parametrize("dz_bf16", [0, 1])
+def test_stem_weight_gradient_without_im2col_matches_autograd(n, H, W, dz_bf16):
+    """grl_stem_wgrad: dW of the 7x7/s2/p3 stem conv (resnets1.py:106-107) straight from the NCHW clip -- persistent
+    workgroups, patch + dz tile in LDS, B operand through the k -> offset table -- against torch's float64 autograd:
+    exact-fp32 products, so 2e-6; ragged tiles (36 x 20: partial 8 x 16 tiles), accumulation into a non-zero dW, bf16 dz
+    converted exactly; and the same result twice (fixed slab order)."""
+    from grl_amd import _lib
+    from grl_amd._lib import ptr
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n * 1000 + H)
+    x = torch.randn(n, 3, H, W, generator=g).to(dev)
+    Ho, Wo = H // 2, W // 2
+    dz = torch.randn(n * Ho * Wo, 64, generator=g).to(dev)
+    if dz_bf16:
+        dz = dz.bfloat16()
+    w = torch.zeros(64, 3, 7, 7, dtype=torch.float64, device=dev, requires_grad=True)
+    out = torch.nn.functional.conv2d(x.double(), w, stride=2, padding=3)
+    ref = torch.autograd.grad(out, w, dz.double().view(n, Ho, Wo, 64).permute(0, 3, 1, 2))[0]
+    outs = []
+    for _ in range(2):
+        dw = torch.full((64, 3, 7, 7), 0.25, device=dev)
+        ws = torch.empty(lib.grl_stem_wgrad_workspace_floats(n, H, W), device=dev)
+        _lib.check(lib.grl_stem_wgrad(ptr(x), ptr(dz), dz_bf16, ptr(dw), ptr(ws), n, H, W, 1, _lib.stream()))
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    err = ((outs[0].double() - 0.25 - ref).norm() / ref.norm()).item()
+    assert err < 2e-6, err
+    dw = torch.full((64, 3, 7, 7), 7.0, device=dev)                        # accumulate = 0 overwrites
+    _lib.check(lib.grl_stem_wgrad(ptr(x), ptr(dz), dz_bf16, ptr(dw), ptr(ws), n, H, W, 0, _lib.stream()))
+    assert ((dw.double() - ref).norm() / ref.norm()).item() < 2e-6

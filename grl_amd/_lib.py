@@ -82,6 +82,10 @@ _SIGNATURES = {
     'grl_pack_dgrad_weight': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_dilate2': ([_fp, _fp] + [C.c_int] * 9 + [_fp], C.c_int),
     'grl_maxpool3x3s2_bwd': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_relu_maxpool3x3s2': ([_fp] * 6 + [C.c_int] * 4 + [_fp], C.c_int),
+    'grl_maxpool3x3s2_bwd_idx': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_relu_maxpool3x3s2_bf16': ([_fp] * 6 + [C.c_int] * 4 + [_fp], C.c_int),
+    'grl_maxpool3x3s2_bwd_idx_bf16': ([_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_wgrad_workspace_floats': ([C.c_int, C.c_int, C.c_int], _i64),
     'grl_stem_wgrad': ([_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_im2col': ([_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),

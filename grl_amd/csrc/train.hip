@@ -552,6 +552,99 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     }
 }
 
+// Stem tail of the TRAINING forward in one pass (round 3): p = maxpool3x3/s2/p1(relu((z - mean) * scale + beta)) with
+// the window's first maximum recorded (idx = ky*3 + kx in scan order, torch's argmax rule) -- the post-ReLU map (268 MB
+// per 32 x 4 step) is never written: the backward routes dp through idx (maxpool_bwd_idx_kernel) and recomputes the
+// ReLU mask from z (grl_bn_bwd's mask_scale form).  Same three fp32 operations per element as bn_apply_centered_kernel.
+__global__ void bn_relu_maxpool_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                       const float* __restrict__ scale, const float* __restrict__ beta,
+                                       float* __restrict__ y, uint8_t* __restrict__ idx, int n, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C >> 2;
+    const int64_t total = (int64_t)n * Ho * Wo * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int ox = r % Wo; r /= Wo;
+        const int oy = r % Ho;
+        const int img = r / Ho;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), sc = *reinterpret_cast<const f32x4*>(scale + c);
+        f32x4 be = {0.f, 0.f, 0.f, 0.f};
+        if (beta) be = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        uint32_t pos = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(z + (((int64_t)img * H + iy) * W + ix) * C + c) - mu;
+                v = v * sc;
+                if (beta) v += be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = v[e] > 0.f ? v[e] : 0.f;
+                    if (a > m[e]) { m[e] = a; pos = (pos & ~(0xffu << (8 * e))) | ((uint32_t)(ky * 3 + kx) << (8 * e)); }
+                }
+            }
+        }
+        reinterpret_cast<f32x4*>(y)[i] = m;
+        reinterpret_cast<uint32_t*>(idx)[i] = pos;
+    }
+}
+
+// max-pool 3x3/s2/p1 backward from the recorded first-maximum positions: one lane per 2x2 block of input pixels
+// (x 4 channels); the block meets the windows (a..a+1, b..b+1): reads 4 x (dy + idx) instead of a 5 x 5 input patch.
+__global__ void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
+                                       float* __restrict__ dx, int H, int W, int C4, int64_t total4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C = C4 * 4;
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t r = i / C4;
+        const int b = r % Wb; r /= Wb;
+        const int a = r % Hb;
+        const int img = r / Hb;
+        f32x4 g[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) g[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            const int oy = a + wy;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int ox = b + wx;
+                if (ox >= Wo) continue;
+                const int64_t o = (((int64_t)img * Ho + oy) * Wo + ox) * C + c;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const uint32_t pos = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+                for (int u = wy; u < 2; ++u)              // window a+1 only reaches the block's second row (ky = 0)
+#pragma unroll
+                    for (int v = wx; v < 2; ++v) {
+                        const uint32_t k = (uint32_t)((u - 2 * wy + 1) * 3 + (v - 2 * wx + 1));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (((pos >> (8 * e)) & 0xffu) == k) g[u][v][e] += d[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int iy = 2 * a + u, ix = 2 * b + v;
+                if (iy < H && ix < W)
+                    *reinterpret_cast<f32x4*>(dx + (((int64_t)img * H + iy) * W + ix) * C + c) = g[u][v];
+            }
+    }
+}
+
 // stem im2col for the 7x7 weight gradient: col[m][k], k = (c*7+ky)*7+kx, padded to Kp
 __global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int H, int W,
                                    int Kp, int64_t total) {
@@ -1495,6 +1588,24 @@ extern "C" int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, 
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W,
                        C / 4, total4);
     return grl_check_launch("grl_maxpool3x3s2_bwd");
+}
+
+extern "C" int grl_bn_relu_maxpool3x3s2(const float* z, const float* mean, const float* scale, const float* beta, float* y,
+                                        uint8_t* idx, int n, int H, int W, int C, void* stream) {
+    GRL_REQUIRE(z && mean && scale && y && idx && n > 0 && C % 4 == 0 && ((uintptr_t)idx & 3) == 0, "bn_relu_maxpool: bad args");
+    const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, z, mean, scale, beta,
+                       y, idx, n, H, W, C);
+    return grl_check_launch("grl_bn_relu_maxpool3x3s2");
+}
+
+extern "C" int grl_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int n, int H, int W, int C,
+                                        void* stream) {
+    GRL_REQUIRE(idx && dy && dx && n > 0 && C % 4 == 0 && ((uintptr_t)idx & 3) == 0, "maxpool_bwd_idx: bad args");
+    const int64_t total4 = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);      // 2x2 input blocks
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, idx, dy, dx, H, W,
+                       C / 4, total4);
+    return grl_check_launch("grl_maxpool3x3s2_bwd_idx");
 }
 
 extern "C" int grl_stem_im2col(const float* x, float* col, int n, int H, int W, int Kp, void* stream) {

@@ -284,6 +284,99 @@ __global__ void dilate2_b16_kernel(const __bf16* __restrict__ dz, __bf16* __rest
     }
 }
 
+// bf16-storage twins of bn_relu_maxpool_kernel / maxpool_bwd_idx_kernel (train.hip): a lane owns 8 channels; every tap
+// is rounded to bf16 before the comparison, exactly what the separate passes compared (the stored bf16 activation).
+__global__ void bn_relu_maxpool_b16_kernel(const __bf16* __restrict__ z, const float* __restrict__ mean,
+                                           const float* __restrict__ scale, const float* __restrict__ beta,
+                                           __bf16* __restrict__ y, uint8_t* __restrict__ idx, int n, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C8 = C >> 3;
+    const int64_t total = (int64_t)n * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        int64_t r = i / C8;
+        const int ox = r % Wo; r /= Wo;
+        const int oy = r % Ho;
+        const int img = r / Ho;
+        const f32x8 mu = ld8f(mean + c), sc = ld8f(scale + c);
+        const f32x8 be = beta ? ld8f(beta + c) : zero8();
+        f32x8 m;
+        uint32_t pos[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; pos[e] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                f32x8 v = (ld8(z + (((int64_t)img * H + iy) * W + ix) * C + c) - mu) * sc;
+                if (beta) v += be;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = (float)(__bf16)(v[e] > 0.f ? v[e] : 0.f);
+                    if (a > m[e]) { m[e] = a; pos[e] = (uint32_t)(ky * 3 + kx); }
+                }
+            }
+        }
+        st8(y + i * 8, m);
+        uint2 pk;
+        pk.x = pos[0] | pos[1] << 8 | pos[2] << 16 | pos[3] << 24;
+        pk.y = pos[4] | pos[5] << 8 | pos[6] << 16 | pos[7] << 24;
+        reinterpret_cast<uint2*>(idx)[i] = pk;
+    }
+}
+
+__global__ void maxpool_bwd_idx_b16_kernel(const uint8_t* __restrict__ idx, const __bf16* __restrict__ dy,
+                                           __bf16* __restrict__ dx, int H, int W, int C8, int64_t total8) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C = C8 * 8;
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        int64_t r = i / C8;
+        const int b = r % Wb; r /= Wb;
+        const int a = r % Hb;
+        const int img = r / Hb;
+        f32x8 g[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) g[u][v] = zero8();
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            const int oy = a + wy;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int ox = b + wx;
+                if (ox >= Wo) continue;
+                const int64_t o = (((int64_t)img * Ho + oy) * Wo + ox) * C + c;
+                const f32x8 d = ld8(dy + o);
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+#pragma unroll
+                for (int u = wy; u < 2; ++u)
+#pragma unroll
+                    for (int v = wx; v < 2; ++v) {
+                        const uint32_t k = (uint32_t)((u - 2 * wy + 1) * 3 + (v - 2 * wx + 1));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint32_t pe = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                            if (pe == k) g[u][v][e] += d[e];
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int iy = 2 * a + u, ix = 2 * b + v;
+                if (iy < H && ix < W) st8(dx + (((int64_t)img * H + iy) * W + ix) * C + c, g[u][v]);
+            }
+    }
+}
+
 // max-pool 3x3/s2/p1 backward, gather form with torch's first-maximum rule (see maxpool_bwd_kernel in train.hip):
 // one lane per 2x2 block of input pixels x 8 channels
 __global__ void maxpool_bwd_b16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
@@ -546,6 +639,26 @@ extern "C" int grl_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx
     hipLaunchKernelGGL(maxpool_bwd_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, CB16(x), CB16(dy),
                        B16(dx), H, W, C / 8, total8);
     return grl_check_launch("grl_maxpool3x3s2_bwd_bf16");
+}
+
+extern "C" int grl_bn_relu_maxpool3x3s2_bf16(const void* z, const float* mean, const float* scale, const float* beta, void* y,
+                                             uint8_t* idx, int n, int H, int W, int C, void* stream) {
+    GRL_REQUIRE(z && mean && scale && y && idx && n > 0 && C % 8 == 0 && al16(z) && al16(y) && ((uintptr_t)idx & 7) == 0,
+                "bn_relu_maxpool_bf16: bad args");
+    const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(bn_relu_maxpool_b16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, CB16(z), mean, scale,
+                       beta, B16(y), idx, n, H, W, C);
+    return grl_check_launch("grl_bn_relu_maxpool3x3s2_bf16");
+}
+
+extern "C" int grl_maxpool3x3s2_bwd_idx_bf16(const uint8_t* idx, const void* dy, void* dx, int n, int H, int W, int C,
+                                             void* stream) {
+    GRL_REQUIRE(idx && dy && dx && n > 0 && C % 8 == 0 && al16(dy) && al16(dx) && ((uintptr_t)idx & 7) == 0,
+                "maxpool_bwd_idx_bf16: bad args");
+    const int64_t total8 = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_idx_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, idx, CB16(dy),
+                       B16(dx), H, W, C / 8, total8);
+    return grl_check_launch("grl_maxpool3x3s2_bwd_idx_bf16");
 }
 
 extern "C" int grl_stem_im2col_bf16(const float* x, void* col, int n, int H, int W, int Kp, void* stream) {

@@ -426,6 +426,7 @@ class Tape(object):
 
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
+STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
 
 
 def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
@@ -752,19 +753,34 @@ def trunk_train(tp, model, x):
     pivot = z0[0].float().contiguous() if tp.b16 else z0           # (the bf16 kernel takes the pivot as an fp32 vector)
     _call(_k('grl_col_stats', z0), ptr(z0), ptr(slab), M0, 64, 64, ptr(pivot))
     st = bn_finalize(slab, rows, 64, M0, bn1, tp.dev, pivot=pivot)
-    a0 = _newl((M0, 64), z0)
-    bn_apply(z0, st, None, a0, M0, 64, True)
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     p0 = _newl((n * Hp * Wp, 64), z0)
-    _call(_k('grl_maxpool3x3s2', a0), ptr(a0), ptr(p0), n, Hs, Ws, 64)
+    fused_tail = STEM_TAIL_FUSED and tp.taps is None
+    if fused_tail:
+        # BatchNorm apply + ReLU + max-pool in one pass with the windows' first-maximum positions: the post-ReLU map
+        # (268 MB per 32 x 4 step) is never written; the backward routes dp through the positions and recomputes the
+        # ReLU mask from z0 (bit-identical to the separate passes, tested)
+        a0 = None
+        pidx = torch.empty((n * Hp * Wp, 64), dtype=torch.uint8, device=tp.dev)
+        _call(_k('grl_bn_relu_maxpool3x3s2', z0), ptr(z0), ptr(st.mean), ptr(st.scale), ptr(st.beta), ptr(p0), ptr(pidx),
+              n, Hs, Ws, 64)
+    else:
+        a0 = _newl((M0, 64), z0)
+        bn_apply(z0, st, None, a0, M0, 64, True)
+        _call(_k('grl_maxpool3x3s2', a0), ptr(a0), ptr(p0), n, Hs, Ws, 64)
 
     def bwd_stem():
         dp = tp.take(p0)
         if dp is None:
             return
         da = _newl((M0, 64), dp)
-        _call(_k('grl_maxpool3x3s2_bwd', dp), ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
-        dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
+        if fused_tail:
+            _call(_k('grl_maxpool3x3s2_bwd_idx', dp), ptr(pidx), ptr(dp), ptr(da), n, Hs, Ws, 64)
+            dz = bn_backward(da, z0, None, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64,
+                             mask_from_z=True)
+        else:
+            _call(_k('grl_maxpool3x3s2_bwd', dp), ptr(a0), ptr(dp), ptr(da), n, Hs, Ws, 64)
+            dz = bn_backward(da, z0, a0, st, bn1.weight, tp.pgrad(bn1.weight), tp.pgrad(bn1.bias), M0, 64)
         if STEM_WGRAD_FUSED:          # straight from the NCHW clip: no 671 MB im2col matrix (csrc/train.hip)
             ws = torch.empty(_lib.load().grl_stem_wgrad_workspace_floats(n, H0, W0), dtype=torch.float32, device=tp.dev)
             _call('grl_stem_wgrad', ptr(x), ptr(dz), 1 if dz.dtype == BF16 else 0, ptr(tp.pgrad(conv1.weight)), ptr(ws),

@@ -324,6 +324,14 @@ int grl_dilate2(const float* dz, float* up, int n, int Ho, int Wo, int H, int W,
 /* nn.MaxPool2d(3,2,1) backward (first-maximum rule, deterministic gather form) */
 int grl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int n, int H, int W, int C,
                          void* stream);
+/* Stem tail of the training forward in one pass: y = maxpool3x3/s2/p1(relu((z - mean) * scale + beta)) (resnets1.py:108-
+ * 110 in train mode: bn1, relu, maxpool) plus idx[pixel][C] (uint8: ky*3 + kx of the window's FIRST maximum in scan
+ * order, torch's argmax rule) -- the post-ReLU map is never written.  grl_maxpool3x3s2_bwd_idx routes dy through idx
+ * (dx = gradient of the post-ReLU map, H x W = the map's size); the ReLU mask then comes from grl_bn_bwd's mask_scale
+ * form.  idx: 4-byte aligned (bf16: 8-byte). */
+int grl_bn_relu_maxpool3x3s2(const float* z, const float* mean, const float* scale, const float* beta, float* y,
+                             uint8_t* idx, int n, int H, int W, int C, void* stream);
+int grl_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int n, int H, int W, int C, void* stream);
 /* Weight gradient of the 7x7/s2/p3 stem conv (resnets1.py:106-107 / basebranch.py:27) straight from the NCHW clip:
  * dw[64][3][7][7] (+)= sum over output pixels of dz[pixel][64] (x) the pixel's 147 input taps -- no im2col matrix
  * (grl_stem_im2col + grl_conv_wgrad_f32 write and re-read 671 MB per 32 x 4 step).  x: fp32 [n][3][H][W]; dz: fp32, or
@@ -495,6 +503,9 @@ int grl_axpy_strided_bf16(void* dst, int64_t dst_stride, const void* src, int64_
 int grl_dilate2_bf16(const void* dz, void* up, int n, int Ho, int Wo, int H, int W, int C, int accumulate,
                      int oy_off, int ox_off, void* stream);
 int grl_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int n, int H, int W, int C, void* stream);
+int grl_bn_relu_maxpool3x3s2_bf16(const void* z, const float* mean, const float* scale, const float* beta, void* y,
+                                  uint8_t* idx, int n, int H, int W, int C, void* stream);
+int grl_maxpool3x3s2_bwd_idx_bf16(const uint8_t* idx, const void* dy, void* dx, int n, int H, int W, int C, void* stream);
 /* fp32 clip in, bf16 im2col columns out (the stem's weight gradient) */
 int grl_stem_im2col_bf16(const float* x, void* col, int n, int H, int W, int Kp, void* stream);
 int grl_gate_apply_bf16(const void* y, int ldy, const void* x, float* cmap, void* xc, void* xu, int M, int C,

@@ -395,3 +395,75 @@ def test_weight_prep_table_equals_per_layer_path(math):
         TE.set_math(old)
     assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f32", "bf16s"])
+def test_fused_stem_tail_equals_separate_passes(math):
+    """train_engine.STEM_TAIL_FUSED: BatchNorm apply + ReLU + max-pool of the stem in one pass that records the windows'
+    first-maximum positions (the post-ReLU map is never written), max-pool backward through the positions, ReLU mask
+    recomputed from z -- against bn_apply + grl_maxpool3x3s2 / grl_maxpool3x3s2_bwd on the stored activation: outputs,
+    every parameter gradient and the running statistics bit-identical over two steps (odd map sizes included at the
+    kernel level below)."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clips = [synth_clips_structured(B, T, seed=90 + i).cuda() for i in range(2)]
+    g = torch.Generator().manual_seed(6)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs = []
+    old = TE.set_math(math)
+    try:
+        for fused in (True, False):
+            TE.STEM_TAIL_FUSED = fused
+            cnn = _fresh()
+            opt = torch.optim.SGD(cnn.parameters(), lr=1e-2, momentum=0.9)
+            keep = []
+            for c in clips:
+                xu, xc = cnn(c)
+                opt.zero_grad(set_to_none=True)
+                ((xu * r1).sum() + (xc * r2).sum()).backward()
+                keep += [xu.detach().clone(), xc.detach().clone()]
+                opt.step()
+            outs.append(keep + [v.detach().clone() for v in cnn.state_dict().values()] +
+                        [p.grad.clone() for p in cnn.parameters() if p.grad is not None])
+    finally:
+        TE.STEM_TAIL_FUSED = True
+        TE.set_math(old)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b16", [False, True])
+@pytest.mark.parametrize("n,H,W", [(2, 9, 7), (3, 16, 8), (1, 5, 12)])
+def test_bn_relu_maxpool_with_positions_matches_torch(b16, n, H, W):
+    """grl_bn_relu_maxpool3x3s2(_bf16) + grl_maxpool3x3s2_bwd_idx(_bf16) against torch (BatchNorm apply -> ReLU ->
+    MaxPool2d(3, 2, 1) and its autograd) on odd map sizes: pooled values equal, the routed gradient equals torch's
+    max-pool backward (ties among zeros aside: their gradient is masked by the ReLU anyway, so compare after the mask)."""
+    from grl_amd import _lib
+    from grl_amd._lib import ptr
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    Cc = 64
+    g = torch.Generator().manual_seed(H * 100 + W)
+    dt = torch.bfloat16 if b16 else torch.float32
+    sfx = '_bf16' if b16 else ''
+    z = torch.randn(n * H * W, Cc, generator=g).to(dev).to(dt)
+    mean, scale, beta = (torch.randn(Cc, generator=g) * 0.1).to(dev), (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.2).to(dev)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty(n * Hp * Wp, Cc, device=dev, dtype=dt)
+    idx = torch.empty(n * Hp * Wp, Cc, device=dev, dtype=torch.uint8)
+    _lib.check(getattr(lib, 'grl_bn_relu_maxpool3x3s2' + sfx)(ptr(z), ptr(mean), ptr(scale), ptr(beta), ptr(y), ptr(idx), n, H, W, Cc, _lib.stream()))
+    a = torch.relu((z.float() - mean) * scale + beta).to(dt).float()            # the stored activation of the separate passes
+    a4 = a.view(n, H, W, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    p = torch.nn.functional.max_pool2d(a4, 3, 2, 1)
+    assert torch.equal(y.float().view(n, Hp, Wp, Cc).permute(0, 3, 1, 2), p.detach())
+    dp = torch.randn(n * Hp * Wp, Cc, generator=g).to(dev).to(dt)
+    da = torch.empty(n * H * W, Cc, device=dev, dtype=dt)
+    _lib.check(getattr(lib, 'grl_maxpool3x3s2_bwd_idx' + sfx)(ptr(idx), ptr(dp), ptr(da), n, H, W, Cc, _lib.stream()))
+    ref = torch.autograd.grad(p, a4, dp.float().view(n, Hp, Wp, Cc).permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1).reshape(n * H * W, Cc)
+    mask = (a > 0).float()
+    got = da.float() * mask
+    want = (ref * mask).to(dt).float() if b16 else ref * mask
+    assert torch.allclose(got, want, rtol=0, atol=1e-2 if b16 else 0)

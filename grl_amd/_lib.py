@@ -73,8 +73,8 @@ _SIGNATURES = {
     'grl_bn_stats_finalize': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
                                _fp, _fp, _fp, _fp, _fp, _fp], C.c_int),
     'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
-    'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
-    'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp], C.c_int),
+    'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
     'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
     'grl_axpby': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
     'grl_axpy_strided': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),
@@ -134,9 +134,9 @@ _SIGNATURES = {
     'grl_add_strided_bf16': ([_fp, _fp, _fp, C.c_int, _i64, _i64, _fp], C.c_int),
     'grl_row_sqnorm': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     # bf16-storage training twins (train_bf16.hip)
-    'grl_bn_apply_centered_bf16': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bn_apply_centered_bf16': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_col_stats_bf16': ([_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
-    'grl_bn_bwd_bf16': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp], C.c_int),
+    'grl_bn_bwd_bf16': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
     'grl_relu_bwd_bf16': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
     'grl_axpby_bf16': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
     'grl_axpy_strided_bf16': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),

@@ -159,7 +159,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __rest
 __global__ void bn_apply_centered_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                          const float* __restrict__ scale, const float* __restrict__ beta,
                                          const float* __restrict__ res, float* __restrict__ y, int C4,
-                                         int64_t total4, int relu) {
+                                         int64_t total4, int relu, uint8_t* __restrict__ bits) {
+    // bits (may be NULL): one byte per four outputs, bit e = (y[e] > 0) -- the ReLU mask the backward of a RESIDUAL
+    // BatchNorm reads instead of the whole activation (1/16 of its bytes; grl_bn_bwd's relu_bits)
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (step % C4 == 0) {
@@ -180,6 +182,7 @@ __global__ void bn_apply_centered_kernel(const float* __restrict__ z, const floa
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
             reinterpret_cast<f32x4*>(y)[i] = v;
+            if (bits) bits[i] = (uint8_t)((v[0] > 0.f) | (v[1] > 0.f) << 1 | (v[2] > 0.f) << 2 | (v[3] > 0.f) << 3);
         }
         return;
     }
@@ -194,6 +197,7 @@ __global__ void bn_apply_centered_kernel(const float* __restrict__ z, const floa
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         reinterpret_cast<f32x4*>(y)[i] = v;
+        if (bits) bits[i] = (uint8_t)((v[0] > 0.f) | (v[1] > 0.f) << 1 | (v[2] > 0.f) << 2 | (v[3] > 0.f) << 3);
     }
 }
 
@@ -207,7 +211,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
-    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta, float* __restrict__ gout) {
+    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta, float* __restrict__ gout,
+    const uint8_t* __restrict__ bits) {
     constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
     __shared__ f32x4 red[2][4][LPR];
     const int chunk = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -226,7 +231,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         for (int r = chunk * CHUNK + wave * (CHUNK / 4) + sub; r < rend; r += RPW) {       // 12 loads in flight
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)r * C + c);
             const f32x4 zc = *reinterpret_cast<const f32x4*>(z + (int64_t)r * C + c) - mu;
-            if (act) {
+            if (bits) {                               // the forward's recorded (y > 0) bits instead of the activation
+                const uint32_t mk = bits[((int64_t)r * C + c) >> 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+            } else if (act) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(act + (int64_t)r * C + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -279,7 +288,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ coef, float* __restrict__ dz, int C,
                                     int64_t total4, float* __restrict__ gres, int gres_accumulate,
-                                    const float* __restrict__ mscale, const float* __restrict__ mbeta) {
+                                    const float* __restrict__ mscale, const float* __restrict__ mbeta,
+                                    const uint8_t* __restrict__ bits) {
     const int C4 = C >> 2;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -295,7 +305,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         for (; i < total4; i += step) {
             f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
             const f32x4 zc = reinterpret_cast<const f32x4*>(z)[i] - mu;
-            if (act) {
+            if (bits) {
+                const uint32_t mk = bits[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+            } else if (act) {
                 const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -319,7 +333,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         const int c = (int)(i % C4) * 4;
         f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
         const f32x4 zc = reinterpret_cast<const f32x4*>(z)[i] - *reinterpret_cast<const f32x4*>(mean + c);
-        if (act) {
+        if (bits) {
+            const uint32_t mk = bits[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+        } else if (act) {
             const f32x4 a = reinterpret_cast<const f32x4*>(act)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -1486,18 +1504,19 @@ extern "C" int grl_bn_apply(const float* z, const float* scale, const float* shi
 }
 
 extern "C" int grl_bn_apply_centered(const float* z, const float* mean, const float* scale, const float* beta,
-                                     const float* res, float* y, int64_t M, int C, int relu, void* stream) {
+                                     const float* res, float* y, int64_t M, int C, int relu, uint8_t* relu_bits,
+                                     void* stream) {
     GRL_REQUIRE(z && mean && scale && y && M > 0 && C % 4 == 0, "bn_apply_centered: bad args");
     const int64_t total4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_centered_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, z, mean,
-                       scale, beta, res, y, C / 4, total4, relu);
+                       scale, beta, res, y, C / 4, total4, relu, relu_bits);
     return grl_check_launch("grl_bn_apply_centered");
 }
 
 extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                           const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                           float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
-                          const float* mask_scale, const float* mask_beta, void* stream) {
+                          const float* mask_scale, const float* mask_beta, const uint8_t* relu_bits, void* stream) {
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 4 == 0, "bn_bwd: bad args");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
@@ -1505,25 +1524,26 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     // the masked gradient g -- which IS the residual's gradient -- and the apply pass reads it back: the activation is
     // read once instead of twice and no separate gres tensor is written (round 3; -2 of 9 tensor passes on the widest
     // BatchNorms of the step)
-    const bool inplace = act && gres == dy && !gres_accumulate;
+    const bool inplace = (act || relu_bits) && gres == dy && !gres_accumulate;
     float* const gout = inplace ? const_cast<float*>(dy) : nullptr;
     if (C <= 64)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<16>, dim3(grl_ceil_div(C, 64), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout, relu_bits);
     else if (C <= 128)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(grl_ceil_div(C, 128), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout, relu_bits);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
-                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout);
+                           invstd, slab_ws, M, C, mask_scale, mask_beta, gout, relu_bits);
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total4 = (int64_t)M * C / 4;
     if (inplace)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, (const float*)nullptr, mean,
-                           invstd, gamma, coef_ws, dz, C, total4, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
+                           invstd, gamma, coef_ws, dz, C, total4, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                           (const uint8_t*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dy, z, act, mean, invstd, gamma,
-                           coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta);
+                           coef_ws, dz, C, total4, gres, gres_accumulate, mask_scale, mask_beta, relu_bits);
     return grl_check_launch("grl_bn_bwd");
 }
 

@@ -53,7 +53,8 @@ inline int grid_for(int64_t n, int block = 256) {
 __global__ void bn_apply_centered_b16_kernel(const __bf16* __restrict__ z, const float* __restrict__ mean,
                                              const float* __restrict__ scale, const float* __restrict__ beta,
                                              const __bf16* __restrict__ res, __bf16* __restrict__ y, int C8,
-                                             int64_t total8, int relu) {
+                                             int64_t total8, int relu, uint8_t* __restrict__ bits) {
+    // bits (may be NULL): one byte per eight outputs, bit e = (stored bf16 y[e] > 0): grl_bn_bwd_bf16's relu_bits
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (step % C8 == 0) {
@@ -72,6 +73,12 @@ __global__ void bn_apply_centered_b16_kernel(const __bf16* __restrict__ z, const
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
             st8(y + i * 8, v);
+            if (bits) {
+                uint32_t mk = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mk |= (uint32_t)((float)(__bf16)v[e] > 0.f) << e;
+                bits[i] = (uint8_t)mk;
+            }
         }
         return;
     }
@@ -85,6 +92,12 @@ __global__ void bn_apply_centered_b16_kernel(const __bf16* __restrict__ z, const
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         st8(y + i * 8, v);
+        if (bits) {
+            uint32_t mk = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mk |= (uint32_t)((float)(__bf16)v[e] > 0.f) << e;
+            bits[i] = (uint8_t)mk;
+        }
     }
 }
 
@@ -123,7 +136,8 @@ __global__ __launch_bounds__(256) void col_stats_b16_kernel(const __bf16* __rest
 __global__ __launch_bounds__(256) void bn_bwd_reduce_b16_kernel(
     const __bf16* __restrict__ dy, const __bf16* __restrict__ z, const __bf16* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab, int M, int C,
-    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR, __bf16* __restrict__ gout) {
+    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR, __bf16* __restrict__ gout,
+    const uint8_t* __restrict__ bits) {
     __shared__ f32x8 red[2][256];
     const int chunk = blockIdx.y, sub = threadIdx.x % LPR, part = threadIdx.x / LPR, parts = 256 / LPR;
     const int c = blockIdx.x * 256 + sub * 8;
@@ -137,7 +151,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_b16_kernel(
             const int64_t o = (int64_t)r * C + c;
             f32x8 g = ld8(dy + o);
             const f32x8 zc = ld8(z + o) - mu;
-            if (act) {
+            if (bits) {                               // the forward's recorded (y > 0) bits instead of the activation
+                const uint32_t mk = bits[o >> 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+            } else if (act) {
                 const f32x8 a = ld8(act + o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -168,7 +186,8 @@ __global__ void bn_bwd_apply_b16_kernel(const __bf16* __restrict__ dy, const __b
                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                         const float* __restrict__ coef, __bf16* __restrict__ dz, int C,
                                         int64_t total8, __bf16* __restrict__ gres, int gres_accumulate,
-                                        const float* __restrict__ mscale, const float* __restrict__ mbeta) {
+                                        const float* __restrict__ mscale, const float* __restrict__ mbeta,
+                                        const uint8_t* __restrict__ bits) {
     const int C8 = C >> 3;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -183,7 +202,11 @@ __global__ void bn_bwd_apply_b16_kernel(const __bf16* __restrict__ dy, const __b
         for (; i < total8; i += step) {
             f32x8 g = ld8(dy + i * 8);
             const f32x8 zc = ld8(z + i * 8) - mu;
-            if (act) {
+            if (bits) {
+                const uint32_t mk = bits[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+            } else if (act) {
                 const f32x8 a = ld8(act + i * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -206,7 +229,11 @@ __global__ void bn_bwd_apply_b16_kernel(const __bf16* __restrict__ dy, const __b
         const int c = (int)(i % C8) * 8;
         f32x8 g = ld8(dy + i * 8);
         const f32x8 zc = ld8(z + i * 8) - ld8f(mean + c);
-        if (act) {
+        if (bits) {
+            const uint32_t mk = bits[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (mk >> e) & 1u ? g[e] : 0.f;
+        } else if (act) {
             const f32x8 a = ld8(act + i * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
@@ -560,11 +587,12 @@ inline int lpr_for(int C) {         // lanes per row of the column reductions: 8
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int grl_bn_apply_centered_bf16(const void* z, const float* mean, const float* scale, const float* beta,
-                                          const void* res, void* y, int64_t M, int C, int relu, void* stream) {
+                                          const void* res, void* y, int64_t M, int C, int relu, uint8_t* relu_bits,
+                                          void* stream) {
     GRL_REQUIRE(z && mean && scale && y && M > 0 && C % 8 == 0 && al16(z) && al16(y) && al16(res), "bn_apply_centered_bf16: bad args");
     const int64_t total8 = M * C / 8;
     hipLaunchKernelGGL(bn_apply_centered_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, CB16(z),
-                       mean, scale, beta, CB16(res), B16(y), C / 8, total8, relu);
+                       mean, scale, beta, CB16(res), B16(y), C / 8, total8, relu, relu_bits);
     return grl_check_launch("grl_bn_apply_centered_bf16");
 }
 
@@ -578,24 +606,25 @@ extern "C" int grl_col_stats_bf16(const void* x, float* slab, int M, int C, int 
 extern "C" int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, const float* mean, const float* invstd,
                                const float* gamma, void* dz, float* dgamma, float* dbeta, float* slab_ws, float* coef_ws,
                                int M, int C, void* gres, int gres_accumulate, const float* mask_scale,
-                               const float* mask_beta, void* stream) {
+                               const float* mask_beta, const uint8_t* relu_bits, void* stream) {
     GRL_REQUIRE(dy && z && mean && invstd && dz && slab_ws && coef_ws && M > 0 && C % 8 == 0, "bn_bwd_bf16: bad args");
     GRL_REQUIRE(al16(dy) && al16(z) && al16(act) && al16(dz) && al16(gres), "bn_bwd_bf16: 16-byte aligned tensors");
     const int rows = grl_col_stats_rows(M);
     hipStream_t s = (hipStream_t)stream;
-    const bool inplace = act && gres == dy && !gres_accumulate;       // (as grl_bn_bwd: dy becomes the masked gradient)
+    const bool inplace = (act || relu_bits) && gres == dy && !gres_accumulate;       // (as grl_bn_bwd: dy becomes the masked gradient)
     hipLaunchKernelGGL(bn_bwd_reduce_b16_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, CB16(dy), CB16(z),
                        CB16(act), mean, invstd, slab_ws, M, C, mask_scale, mask_beta, lpr_for(C),
-                       inplace ? const_cast<__bf16*>(CB16(dy)) : (__bf16*)nullptr);
+                       inplace ? const_cast<__bf16*>(CB16(dy)) : (__bf16*)nullptr, relu_bits);
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total8 = (int64_t)M * C / 8;
     if (inplace)
         hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(dy), CB16(z), (const __bf16*)nullptr,
                            mean, invstd, gamma, coef_ws, B16(dz), C, total8, (__bf16*)nullptr, 0, (const float*)nullptr,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (const uint8_t*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(dy), CB16(z), CB16(act),
-                           mean, invstd, gamma, coef_ws, B16(dz), C, total8, B16(gres), gres_accumulate, mask_scale, mask_beta);
+                           mean, invstd, gamma, coef_ws, B16(dz), C, total8, B16(gres), gres_accumulate, mask_scale, mask_beta,
+                           relu_bits);
     return grl_check_launch("grl_bn_bwd_bf16");
 }
 

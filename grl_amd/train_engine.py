@@ -426,6 +426,7 @@ class Tape(object):
 
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
+RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B and tests only
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
 
 
@@ -495,10 +496,11 @@ class _BNState(object):
     __slots__ = ('mean', 'invstd', 'scale', 'shift', 'beta')
 
 
-def bn_apply(z, st, res, y, M, Cc, relu):
-    """y = relu?((z - mean) * gamma*invstd + beta + res) -- centred first, as torch's train kernel."""
+def bn_apply(z, st, res, y, M, Cc, relu, bits=None):
+    """y = relu?((z - mean) * gamma*invstd + beta + res) -- centred first, as torch's train kernel.
+    ``bits``: uint8 tensor that receives the (y > 0) mask, one bit per output (RELU_BITS)."""
     _call(_k('grl_bn_apply_centered', z), ptr(z), ptr(st.mean), ptr(st.scale), ptr(st.beta), ptr(res), ptr(y), M, Cc,
-          1 if relu else 0)
+          1 if relu else 0, ptr(bits))
 
 
 def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None, pivot=None):
@@ -517,7 +519,7 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
-def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False):
+def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False, bits=None):
     """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
     same pass that writes dz).  ``mask_from_z``: y = relu(bn(z)) without a residual -- the ReLU mask is recomputed
     from z with the forward's own operations (st.scale, st.beta) instead of reading the activation."""
@@ -525,9 +527,9 @@ def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Cc), dy)
     coef = _new((2, Cc), dy)
-    _call(_k('grl_bn_bwd', dy), ptr(dy), ptr(z), None if mask_from_z else ptr(act), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-          ptr(dz), ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc,
-          ptr(st.scale) if mask_from_z else None, ptr(st.beta) if mask_from_z else None)
+    _call(_k('grl_bn_bwd', dy), ptr(dy), ptr(z), None if (mask_from_z or bits is not None) else ptr(act), ptr(st.mean),
+          ptr(st.invstd), ptr(gamma), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(slab), ptr(coef), M, Cc, ptr(gres), gres_acc,
+          ptr(st.scale) if mask_from_z else None, ptr(st.beta) if mask_from_z else None, ptr(bits))
     return dz
 
 
@@ -556,7 +558,12 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
                    stats=True, conv=geom)
     st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
     a = _newl((M, N), x)
-    bn_apply(z, st, res, a, M, N, relu)
+    # y = relu(bn(z) + res): the backward needs the mask (y > 0); recorded as one bit per output here, it is read
+    # back instead of the whole activation (1/16 of the bytes of the widest BatchNorms of the step)
+    bits = None
+    if relu and res is not None and RELU_BITS:
+        bits = torch.empty(M * N // (8 if a.dtype == BF16 else 4), dtype=torch.uint8, device=tp.dev)
+    bn_apply(z, st, res, a, M, N, relu, bits=bits)
 
     def bwd():
         da = tp.take(a)
@@ -572,7 +579,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
                 # place (gres == dy) and this tape entry adopts the buffer (da was popped: nobody else reads it)
                 gres = tp.g[id(res)] = da if relu else _newl((M, N), da)
         dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
-                         gres=gres, gres_acc=gacc, mask_from_z=relu and res is None)
+                         gres=gres, gres_acc=gacc, mask_from_z=relu and res is None, bits=bits)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
                                    kcols=kcols, ldw=ldw)
         if gbias is not None:

@@ -34,7 +34,7 @@ extern "C" {
 const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
- * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad). */
+ * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits). */
 #define GRL_ABI_VERSION 4
 int grl_abi_version(void);
 
@@ -286,7 +286,9 @@ int grl_bn_apply(const float* z, const float* scale, const float* shift, const f
  * torch's training kernel does (F.batch_norm(training=True); resnets1.py:76-91, grl_model.py:222-226):
  * exact where the folded form cancels (BatchNorm1d over a few similar rows).  beta may be NULL. */
 int grl_bn_apply_centered(const float* z, const float* mean, const float* scale, const float* beta,
-                          const float* res, float* y, int64_t M, int C, int relu, void* stream);
+                          const float* res, float* y, int64_t M, int C, int relu,
+                          uint8_t* relu_bits /* may be NULL: M*C/4 bytes, bit e of byte i = (y[4i + e] > 0) */,
+                          void* stream);
 
 /* BatchNorm (+ReLU) backward: g = dy*(act>0) (act NULL: no mask -- unless mask_scale is given: then the ReLU
  * mask of y = relu((z - mean)*mask_scale + mask_beta) is RECOMPUTED from z with the forward's own three fp32
@@ -296,11 +298,13 @@ int grl_bn_apply_centered(const float* z, const float* mean, const float* scale,
  * gres (may be NULL): gradient of the residual input of y = relu(bn(z) + res), which is the same
  * masked g: gres (+)= g in the same pass (resnets1.py:88-91).  gres == dy with act given and gres_accumulate == 0:
  * IN-PLACE form -- the reduce pass overwrites dy with g (dy is NOT const then) and the apply pass reads it back, so
- * the caller's dy buffer becomes the residual's gradient: the activation is read once and no second tensor is written. */
+ * the caller's dy buffer becomes the residual's gradient: the activation is read once and no second tensor is written.
+ * relu_bits (may be NULL): the mask bytes grl_bn_apply_centered recorded in the forward; they replace `act` (which
+ * is then not read at all -- 1/16 of its bytes): same mask, same result. */
 int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* mean,
                const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
-               const float* mask_scale, const float* mask_beta, void* stream);
+               const float* mask_scale, const float* mask_beta, const uint8_t* relu_bits, void* stream);
 
 /* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
 int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);
@@ -489,13 +493,14 @@ int grl_weight_prep(const GrlPrepEntry* table_dev, int count, void* stream);
  * sites as the fp32 entry points they mirror (resnets1.py:76-91, basebranch.py:38-66, grl_model.py:71-83,131-180
  * and their autograd backward, trainer.py:54).  C % 8 == 0, 16-byte aligned tensors. */
 int grl_bn_apply_centered_bf16(const void* z, const float* mean, const float* scale, const float* beta,
-                               const void* res, void* y, int64_t M, int C, int relu, void* stream);
+                               const void* res, void* y, int64_t M, int C, int relu,
+                               uint8_t* relu_bits /* may be NULL: M*C/8 bytes, one bit per stored output */, void* stream);
 /* pivot: an fp32 VECTOR [C] (or NULL), not a row of x as in grl_col_stats */
 int grl_col_stats_bf16(const void* x, float* slab, int M, int C, int ld, const float* pivot, void* stream);
 int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, const float* mean, const float* invstd,
                     const float* gamma, void* dz, float* dgamma, float* dbeta, float* slab_ws, float* coef_ws,
                     int M, int C, void* gres, int gres_accumulate, const float* mask_scale,
-                    const float* mask_beta, void* stream);
+                    const float* mask_beta, const uint8_t* relu_bits, void* stream);
 int grl_relu_bwd_bf16(const void* dy, const void* act, void* out, int64_t n, int accumulate, void* stream);
 int grl_axpby_bf16(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, void* stream);
 int grl_axpy_strided_bf16(void* dst, int64_t dst_stride, const void* src, int64_t src_stride, int nb,

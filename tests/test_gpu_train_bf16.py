@@ -38,8 +38,8 @@ def test_elementwise_twins_equal_rounded_fp32(dev):
     for relu, r in ((1, res), (0, None), (1, None)):
         y32 = torch.empty(M, Cc, device=dev); y16 = torch.empty(M, Cc, device=dev, dtype=BF)
         rb, zb = None if r is None else r.bfloat16(), z.bfloat16()       # (temporaries must outlive the launch)
-        _call('grl_bn_apply_centered', ptr(z), ptr(mean), ptr(scale), ptr(beta), ptr(r), ptr(y32), M, Cc, relu)
-        _call('grl_bn_apply_centered_bf16', ptr(zb), ptr(mean), ptr(scale), ptr(beta), ptr(rb), ptr(y16), M, Cc, relu)
+        _call('grl_bn_apply_centered', ptr(z), ptr(mean), ptr(scale), ptr(beta), ptr(r), ptr(y32), M, Cc, relu, None)
+        _call('grl_bn_apply_centered_bf16', ptr(zb), ptr(mean), ptr(scale), ptr(beta), ptr(rb), ptr(y16), M, Cc, relu, None)
         assert torch.equal(y16, y32.bfloat16())
     act = torch.relu(z)
     for acc in (0, 1):
@@ -467,3 +467,39 @@ def test_bn_relu_maxpool_with_positions_matches_torch(b16, n, H, W):
     got = da.float() * mask
     want = (ref * mask).to(dt).float() if b16 else ref * mask
     assert torch.allclose(got, want, rtol=0, atol=1e-2 if b16 else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f32", "bf16s"])
+def test_relu_mask_bits_equal_reading_the_activation(math):
+    """train_engine.RELU_BITS: the residual BatchNorms (y = relu(bn(z) + res)) record (y > 0) as one bit per output in the
+    forward apply pass and their backward reads those bytes instead of the activation (grl_bn_bwd's relu_bits, both the
+    in-place and the accumulating form occur in a bottleneck stack): outputs, every gradient and the running statistics
+    bit-identical to the act-reading path over two steps."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clips = [synth_clips_structured(B, T, seed=95 + i).cuda() for i in range(2)]
+    g = torch.Generator().manual_seed(7)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs = []
+    old = TE.set_math(math)
+    try:
+        for bits in (True, False):
+            TE.RELU_BITS = bits
+            cnn = _fresh()
+            opt = torch.optim.SGD(cnn.parameters(), lr=1e-2, momentum=0.9)
+            keep = []
+            for c in clips:
+                xu, xc = cnn(c)
+                opt.zero_grad(set_to_none=True)
+                ((xu * r1).sum() + (xc * r2).sum()).backward()
+                keep += [xu.detach().clone(), xc.detach().clone()]
+                opt.step()
+            outs.append(keep + [v.detach().clone() for v in cnn.state_dict().values()] +
+                        [p.grad.clone() for p in cnn.parameters() if p.grad is not None])
+    finally:
+        TE.RELU_BITS = True
+        TE.set_math(old)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))

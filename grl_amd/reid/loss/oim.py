@@ -59,15 +59,18 @@ class OIM(autograd.Function):
         if weight is not None:
             require_device(weight, 'OIM class weight')
             weight = weight.contiguous()
-        _call('grl_softmax_ce', ptr(logits), c, ptr(y), ptr(weight), n, c, ptr(loss), None, ptr(dlogits), c,
+        # correct[0] = rows whose arg-max is the label (first index on ties, as the reference's topk read-out,
+        # eva_functions.py:118-131): the trainer's precision comes out of the same launch instead of topk / eq / sum
+        correct = torch.empty((), dtype=torch.float32, device=x.device)
+        _call('grl_softmax_ce', ptr(logits), c, ptr(y), ptr(weight), n, c, ptr(loss), ptr(correct), ptr(dlogits), c,
               ptr(ws))
         ctx.save_for_backward(x, y, dlogits)
         ctx.lut, ctx.momentum, ctx.scalar = lut, momentum, float(scalar)
-        ctx.mark_non_differentiable(logits)
-        return loss, logits
+        ctx.mark_non_differentiable(logits, correct)
+        return loss, logits, correct
 
     @staticmethod
-    def backward(ctx, gloss, _glogits):
+    def backward(ctx, gloss, _glogits, _gcorrect):
         x, y, dlogits = ctx.saved_tensors
         lut, m = ctx.lut, ctx.momentum
         n, D = x.shape
@@ -84,7 +87,11 @@ class OIM(autograd.Function):
 
 
 def oim(inputs, targets, lut, momentum=0.5, scalar=1.0, weight=None):
-    return OIM.apply(inputs, targets, lut, momentum, scalar, weight)
+    """(loss, scaled logits) as the reference's OIMLoss.forward; the logits carry ``grl_top1 = (correct rows, rows)``
+    (device scalar) for the trainer's precision read-out."""
+    loss, logits, correct = OIM.apply(inputs, targets, lut, momentum, scalar, weight)
+    logits.grl_top1 = (correct, logits.size(0))
+    return loss, logits
 
 
 class OIMLoss(nn.Module):

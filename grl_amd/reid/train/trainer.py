@@ -129,6 +129,16 @@ class SEQTrainer(BaseTrainer):
         return [imgs], pids.to(self.device)
 
     @staticmethod
+    def _top1(output_id, target):
+        """top-1 precision of the id logits (trainer.py:127,139,153: accuracy(output.data, target.data)[0]).  The OIM
+        criterion's cross-entropy launch already counted the rows whose arg-max is the label (same tie rule as topk);
+        any other criterion goes through the reference's accuracy()."""
+        top1 = getattr(output_id, 'grl_top1', None)
+        if top1 is not None:
+            return top1[0] * (1.0 / top1[1])
+        return accuracy(output_id.data, target.data)[0]
+
+    @staticmethod
     def _pair_prob(encode_scores):
         """softmax over the two verification logits, class-1 column (trainer.py:146-148)."""
         return pair_prob(encode_scores)
@@ -149,7 +159,7 @@ class SEQTrainer(BaseTrainer):
         frame_corr = x_corr.reshape(batch_size * seq_len, -1)
         targetX = targets.unsqueeze(1).expand(batch_size, seq_len).reshape(-1)
         corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)
-        corr_prec_id_frame, = accuracy(output_id.data, targetX.data)
+        corr_prec_id_frame = self._top1(output_id, targetX)
 
         pairs = targets.data.view(batch_size // 2, -1)
         tar_probe, tar_gallery = pairs[:, 0], pairs[:, 1]
@@ -157,13 +167,13 @@ class SEQTrainer(BaseTrainer):
 
         encode_scores, siamese_out = self.siamese_model(x_corr)
         corr_id_loss_vid, output_id = self.criterion_corr(siamese_out, target)
-        corr_prec_id_vid, = accuracy(output_id.data, target.data)
+        corr_prec_id_vid = self._top1(output_id, target)
         corr_loss_tri = criterion_triplet(siamese_out, target).mean()
         corr_loss_ver, _ = self.criterion_ver(self._pair_prob(encode_scores), tar_probe, tar_gallery)
 
         encode_scores, siamese_out = self.siamese_model_uncorr(x_uncorr)
         uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out, target)
-        uncorr_prec_id_vid, = accuracy(output_id.data, target.data)
+        uncorr_prec_id_vid = self._top1(output_id, target)
         # (the reference also evaluates the uncorr verification loss but never adds it)
 
         corr_loss = corr_id_loss_frame + corr_id_loss_vid + corr_loss_ver * 20 + corr_loss_tri

@@ -433,3 +433,26 @@ def test_stem_weight_gradient_without_im2col_matches_autograd(n, H, W, dz_bf16):
     dw = torch.full((64, 3, 7, 7), 7.0, device=dev)                        # accumulate = 0 overwrites
     _lib.check(lib.grl_stem_wgrad(ptr(x), ptr(dz), dz_bf16, ptr(dw), ptr(ws), n, H, W, 0, _lib.stream()))
     assert ((dw.double() - ref).norm() / ref.norm()).item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_oim_top1_read_out_equals_reference_accuracy():
+    """SEQTrainer._top1: the precision taken from the cross-entropy launch (rows whose arg-max is the label) equals
+    the reference's accuracy(output.data, target.data)[0] (eva_functions.py:118-131: topk / eq / sum), ties included."""
+    from grl_amd.reid.loss import OIMLoss
+    from grl_amd.reid.evaluator import accuracy
+    from grl_amd.reid.train import SEQTrainer
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    crit = OIMLoss(64, 37, scalar=30, momentum=0.5).to(dev)
+    crit.lut.copy_(torch.nn.functional.normalize(torch.randn(37, 64, generator=g), dim=1))
+    crit.lut[5] = crit.lut[4]                                   # a tie between classes 4 and 5 for every row
+    x = torch.nn.functional.normalize(torch.randn(48, 64, generator=g), dim=1).to(dev)
+    y = torch.randint(0, 37, (48,), generator=g).to(dev)
+    y[:6] = torch.tensor([4, 5, 4, 5, 4, 5])
+    x[:6] = crit.lut[4]                                         # rows whose two best classes tie exactly
+    loss, logits = crit(x, y)
+    want = accuracy(logits.data, y.data)[0]
+    got = SEQTrainer._top1(logits, y)
+    assert float(got) == float(want), (float(got), float(want))
+    assert 0.0 < float(got) < 1.0

@@ -661,6 +661,12 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'round3':
         torch.manual_seed(0); torch.set_num_threads(8)
         round3_goldens(import_reference()[0])
+    elif len(sys.argv) > 1 and sys.argv[1] == 'b64t4':
+        # BASELINE configs[3]'s per-GPU batch (64 clips x 4 frames): the reference's fp32 AND float64 runs (the float64
+        # run peaks at ~45 GB of host memory; run it alone)
+        torch.manual_seed(0); torch.set_num_threads(8)
+        train_golden_conditioned(import_reference()[0], os.path.join(HERE, 'grl_train_cond_b64t4.npz'), B=64, T=4,
+                                 clip_seed=11, xu_stride=16, xc_stride=64)
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         torch.manual_seed(0); torch.set_num_threads(8)
         trainer_step_golden(import_reference()[0], os.path.join(HERE, 'trainer_step_cond_b8t4.npz'))

@@ -182,7 +182,7 @@ def _fresh_cnn_conditioned():
 
 @pytest.mark.parametrize('fname,math', [('grl_train_cond_b8t4.npz', 'f32'), ('grl_train_cond_b8t4.npz', 'mixed'),
                                         ('grl_train_cond_b4t8.npz', 'f32'), ('grl_train_cond_b32t4.npz', 'f32'),
-                                        ('grl_train_cond_b32t4.npz', 'mixed')])
+                                        ('grl_train_cond_b32t4.npz', 'mixed'), ('grl_train_cond_b64t4.npz', 'f32')])
 def test_train_forward_backward_matches_reference_golden_1e3(golden, fname, math):
     """(``math``: the default exact-fp32 step, and 'mixed' = the same forward with split-bf16 backward GEMMs.)
     THE end-to-end backward pin: HIP train-mode forward + backward of the whole CNN against the
@@ -194,7 +194,8 @@ def test_train_forward_backward_matches_reference_golden_1e3(golden, fname, math
     a 1 % gradient bug in any layer fails here (tolerance model: tests/train_cond_check.py).
     The chaotic default-weight fixtures below stay as stress tests.  Round 3: the same pin at B x T = 4 x 8 (the
     T = 8 recurrence of BASELINE configs[2]: the memo-block BatchNorms run 8 times per forward) and at configs[1]'s
-    FULL size 32 x 4 (grl_train_cond_b32t4.npz: the reference's fp32 + float64 runs at that size)."""
+    FULL size 32 x 4 (grl_train_cond_b32t4.npz: the reference's fp32 + float64 runs at that size); and BASELINE
+    configs[3]'s per-GPU batch 64 x 4 (grl_train_cond_b64t4.npz)."""
     import train_cond_check as TC
     from grl_amd.synthetic import synth_clips_structured
     g = golden(fname)

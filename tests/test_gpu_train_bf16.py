@@ -230,29 +230,38 @@ def _fresh(profile='conditioned'):
     return cnn.cuda().train()
 
 
-def test_bf16_storage_step_against_reference_fixture(golden):
-    """The whole CNN forward + backward in bf16 storage against the reference's fp32 run on the conditioned fixture
-    (tests/golden/grl_train_cond_b8t4.npz).  STATED bf16 TOLERANCE: every stored activation carries one 2^-9
+@pytest.mark.parametrize('fname,med_tol,cos_min,cos_med', [('grl_train_cond_b8t4.npz', 0.2, 0.97, 0.99),
+                                                            ('grl_train_cond_b4t8.npz', 0.3, 0.9, 0.97),
+                                                            ('grl_train_cond_b32t4.npz', 0.15, 0.98, 0.99)])
+def test_bf16_storage_step_against_reference_fixture(golden, fname, med_tol, cos_min, cos_med):
+    """The whole CNN forward + backward in bf16 storage against the reference's fp32 run on the conditioned fixtures
+    (8 x 4; 4 x 8 = the T = 8 recurrence of BASELINE configs[2]; the full 32 x 4).  STATED bf16 TOLERANCE: every stored activation carries one 2^-9
     rounding, ~50 train-mode layers deep: outputs within 3e-2 relative L2 (measured 1.6-1.8e-2); parameter
     gradients -- random projections of an L2-normalised, batch-normalised output, which amplify forward noise
     ~10x -- at cosine >= 0.97 for every >= 2-D weight and a median relative L2 error <= 0.2 (measured: median
     0.12-0.14, cosine median 0.993, min 0.987); BatchNorm running statistics within 5e-2 (the variance over the B = 8 rows of
-    the pooled feature moves 2 % with the forward's 8e-3).  The exact-fp32 path keeps the 1e-3 pin."""
+    the pooled feature moves 2 % with the forward's 8e-3).  The exact-fp32 path keeps the 1e-3 pin.
+    Measured per fixture (median relative L2 / min cosine / median cosine): 8 x 4: 0.107 / 0.981 / 0.995; 32 x 4: 0.084 /
+    0.991 / 0.997; 4 x 8: 0.198 / 0.939 / 0.983 -- the per-clip BatchNorm1d layers normalise over FOUR rows there, which
+    amplifies the forward's bf16 noise more (stated, looser bounds for that fixture)."""
     import train_cond_check as TC
     from grl_amd import train_engine as TE
     from grl_amd.synthetic import synth_clips_structured
-    g = golden('grl_train_cond_b8t4.npz')
+    g = golden(fname)
     B, T = int(g['meta.B']), int(g['meta.T'])
+    clip_seed = int(g['meta.clip_seed']) if 'meta.clip_seed' in g.files else 3
+    su = int(g['meta.xu_stride']) if 'meta.xu_stride' in g.files else 1
+    sc = int(g['meta.xc_stride']) if 'meta.xc_stride' in g.files else 4
     cnn = _fresh()
     r1, r2 = TC.upstream(B, T)
     old = TE.set_math('bf16s')
     try:
-        xu, xc = cnn(synth_clips_structured(B, T, seed=3).cuda())
+        xu, xc = cnn(synth_clips_structured(B, T, seed=clip_seed).cuda())
         ((xu * r1.cuda()).sum() + (xc * r2.cuda()).sum()).backward()
     finally:
         TE.set_math(old)
     l2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
-    e_u, e_c = l2(xu.detach().cpu().numpy(), g['x_uncorr']), l2(xc.detach().cpu().numpy()[..., ::4], g['x_corr_s4'])
+    e_u, e_c = l2(xu.detach().cpu().numpy()[..., ::su], g['x_uncorr']), l2(xc.detach().cpu().numpy()[..., ::sc], g['x_corr_s4'])
     print('bf16s vs reference fp32: outputs rel L2 %.2e %.2e' % (e_u, e_c))
     assert e_u < 3e-2 and e_c < 3e-2
     errs, cosw = [], []
@@ -268,7 +277,7 @@ def test_bf16_storage_step_against_reference_fixture(golden):
     errs = np.array(sorted(errs))
     print('bf16s gradients vs reference fp32: relative L2 median %.2e p90 %.2e; weight cosine min %.4f median %.4f' % (
         np.median(errs), errs[int(0.9 * len(errs))], min(cosw), float(np.median(cosw))))
-    assert np.median(errs) < 0.2 and min(cosw) > 0.97 and np.median(cosw) > 0.99
+    assert np.median(errs) < med_tol and min(cosw) > cos_min and np.median(cosw) > cos_med
     sd = cnn.state_dict()
     for k in [k for k in g.files if k.startswith('stat.') and 'num_batches' not in k]:
         assert np.abs(sd[k[5:]].double().cpu().numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1e-30) < 5e-2, k

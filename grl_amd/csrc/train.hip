@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict_
 }
 
 // Sum the [rows][2][C] partial slab for FCH channels with FRG row groups (1024 threads), fp64 accumulation in a
-// fixed order (a thread over its rows r = ry, ry + FRG, ..., then the row groups in index order); returns the two
+// fixed order (a thread over its rows r = ry, ry + FRG, ..., then the row groups by a fixed binary tree); returns the two
 // totals to the threads of row group 0.  16 channels x 64 row groups (round 3; it was 64 x 16): the 64-channel layers
 // have up to 2048 slab rows (the stem 8192) and with 64 channels per workgroup ONE workgroup walked them, 128 dependent
 // fp64 adds per thread -- ~9 us per launch, 176 launches per training step.
@@ -97,10 +97,17 @@ __device__ __forceinline__ void slab_totals(const float* __restrict__ slab, int 
     sh[ry * FCH + cx] = s;
     sh[FRG * FCH + ry * FCH + cx] = q;
     __syncthreads();
-    if (ry == 0) {
-        s = 0.0; q = 0.0;
-        for (int g = 0; g < FRG; ++g) { s += sh[g * FCH + cx]; q += sh[FRG * FCH + g * FCH + cx]; }
+    // the row groups' partials summed by a fixed binary tree (FRG = 64 or 256: 6 or 8 levels).  The serial loop over
+    // the groups that stood here was a chain of up to 256 dependent LDS reads on a handful of threads -- 3 to 7 us of
+    // the ~9 us these 176 launches per step took.
+    for (int half = FRG >> 1; half > 0; half >>= 1) {
+        if (ry < half) {
+            sh[ry * FCH + cx] += sh[(ry + half) * FCH + cx];
+            sh[FRG * FCH + ry * FCH + cx] += sh[FRG * FCH + (ry + half) * FCH + cx];
+        }
+        __syncthreads();
     }
+    if (ry == 0) { s = sh[cx]; q = sh[FRG * FCH + cx]; }
 }
 
 // BN forward finalize: batch mean / biased var from the partial slab, running-stat

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
         const int r1 = min(M, (chunk + 1) * CHUNK);
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
         if (pivot) pv = *reinterpret_cast<const f32x4*>(pivot + c);
-        for (int r = chunk * CHUNK + wave; r < r1; r += 4) {
+#pragma unroll 8
+        for (int r = chunk * CHUNK + wave; r < r1; r += 4) {       // (8 loads in flight: on the small BatchNorm1d inputs this loop is pure latency)
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c) - pv;
             s += v; q += v * v;
         }

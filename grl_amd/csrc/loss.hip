@@ -106,21 +106,31 @@ __global__ __launch_bounds__(256) void oim_grad_kernel(const float* __restrict__
                                                        const float* __restrict__ lut,
                                                        const float* __restrict__ g, float alpha,
                                                        float* __restrict__ dx, int n, int c, int D) {
-    extern __shared__ float sl[];                      // [OG_ROWS][c]
+    extern __shared__ __attribute__((aligned(16))) float sl[];     // [OG_ROWS][cp], cp = c rounded up to 4, zero padded
+    const int cp = (c + 3) & ~3;
     const int r0 = blockIdx.y * OG_ROWS, k = blockIdx.x * 256 + threadIdx.x;
-    for (int t = threadIdx.x; t < OG_ROWS * c; t += 256) {
-        const int r = t / c, j = t - r * c;
-        sl[t] = (r0 + r < n) ? dl[(int64_t)(r0 + r) * ldd + j] : 0.f;
+    for (int t = threadIdx.x; t < OG_ROWS * cp; t += 256) {
+        const int r = t / cp, j = t - r * cp;
+        sl[t] = (r0 + r < n && j < c) ? dl[(int64_t)(r0 + r) * ldd + j] : 0.f;
     }
     __syncthreads();
     if (k >= D) return;
     float acc[OG_ROWS];
 #pragma unroll
     for (int r = 0; r < OG_ROWS; ++r) acc[r] = 0.f;
-    for (int j = 0; j < c; ++j) {
-        const float w = lut[(int64_t)j * D + k];
+    // four classes per step: one 16-byte LDS read per gradient row instead of four scalar ones (the kernel was bound by
+    // LDS instruction issue: 8 broadcast reads per class and lane), j ascending within a row as before
+#pragma unroll 8
+    for (int j = 0; j < cp; j += 4) {                  // 32 LUT loads in flight per lane: the loop is L2-latency bound
+        float w[4];
 #pragma unroll
-        for (int r = 0; r < OG_ROWS; ++r) acc[r] = fmaf(sl[r * c + j], w, acc[r]);
+        for (int e = 0; e < 4; ++e) w[e] = j + e < c ? lut[(int64_t)(j + e) * D + k] : 0.f;
+#pragma unroll
+        for (int r = 0; r < OG_ROWS; ++r) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + r * cp + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r] = fmaf(d4[e], w[e], acc[r]);
+        }
     }
     const float a = alpha * (g ? g[0] : 1.f);
 #pragma unroll
@@ -281,7 +291,7 @@ extern "C" int grl_softmax_ce(const float* logits, int64_t ld, const int64_t* la
 extern "C" int grl_oim_grad(const float* dlogits, int64_t ldd, const float* lut, const float* g, float alpha,
                             float* dx, int n, int c, int D, void* stream) {
     GRL_REQUIRE(dlogits && lut && dx && n > 0 && c > 0 && D > 0 && ldd >= c, "oim_grad: bad args");
-    const size_t lds = (size_t)OG_ROWS * c * sizeof(float);
+    const size_t lds = (size_t)OG_ROWS * ((c + 3) & ~3) * sizeof(float);
     GRL_REQUIRE(lds <= 160 * 1024, "oim_grad: more than 5120 classes");
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)oim_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(1024) void group_mean_kernel(const float* __restric
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const float* xp = x + (int64_t)g * rows * C + c;
+#pragma unroll 8
         for (int r = wave; r < rows; r += RED_WAVES) s += *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C);
     }
     red[wave][threadIdx.x & 63] = s;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(1024) void sqdiff_mean_kernel(const float* __restri
     if (c < C) {
         const float* p1 = f1 + (int64_t)g * rows * C + c;
         const float* p2 = f2 + (int64_t)g * f2_stride + c;
+#pragma unroll 8
         for (int r = wave; r < rows; r += RED_WAVES) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p1 + (int64_t)r * C) -
                             *reinterpret_cast<const f32x4*>(p2 + (int64_t)r * C);
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(256) void channel_atte_out_kernel(
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= C) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < Hd; ++j) s += *reinterpret_cast<const f32x4*>(w2t + (int64_t)j * C + c) * hs[j];
+#pragma unroll 16
+    for (int j = 0; j < Hd; ++j) s += *reinterpret_cast<const f32x4*>(w2t + (int64_t)j * C + c) * hs[j];   // (latency: 64 workgroups, 128 dependent-free loads each)
     f32x4 a;
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = sigmoidf_(s[e]);

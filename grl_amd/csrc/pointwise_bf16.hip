@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void group_mean_b16_kernel(const __bf16* __res
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     if (c < C) {
         const __bf16* xp = x + (int64_t)g * rows * C + c;
+#pragma unroll 8
         for (int r = part; r < rows; r += 8) s += ld8(xp + (int64_t)r * C);
     }
     red[part][sub] = s;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void sqdiff_mean_b16_kernel(const __bf16* __re
     if (c < C) {
         const __bf16* p1 = f1 + (int64_t)g * rows * C + c;
         const __bf16* p2 = f2 + (int64_t)g * f2_stride + c;
+#pragma unroll 8
         for (int r = part; r < rows; r += 8) {
             const f32x8 t = ld8(p1 + (int64_t)r * C) - ld8(p2 + (int64_t)r * C);
             s += t * t;

@@ -230,6 +230,7 @@ class Tape(object):
         self.b16 = False     # bf16-storage step: the packed / transposed weights below are handed out as bf16 copies
         self.prep = None     # WeightPrep being recorded (first step of a model in this storage mode), or None
         self.params_by_ptr = None
+        self.prep_event = None  # WeightPrep launched on the side stream: the launch stream joins it before layer 1
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
@@ -426,6 +427,7 @@ class Tape(object):
 
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
+PREP_ASYNC = os.environ.get('GRL_PREP_ASYNC', '1') != '0'               # A/B and tests only
 RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B and tests only
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
 
@@ -802,6 +804,9 @@ def trunk_train(tp, model, x):
         tp.taps['stem'] = engine._to_nchw(a0, n, Hs, Ws)
         tp.taps['pool'] = engine._to_nchw(p0, n, Hp, Wp)
     cur, H, W = p0, Hp, Wp
+    if tp.prep_event is not None:                        # the step's weight table, launched next to the stem
+        torch.cuda.current_stream(tp.dev).wait_event(tp.prep_event)
+        tp.prep_event = None
     for li in (4, 5, 6, 7):
         tp.mark('layer%d' % (li - 3))
         for blk in base[li]:
@@ -1059,7 +1064,18 @@ class _GrlTrainFn(torch.autograd.Function):
         if WEIGHT_PREP:
             wp = _weight_prep(model, tp.b16)
             if wp.ready:
-                wp.run()                                 # every packed / transposed / bf16 weight of the step: one launch
+                # every packed / transposed / bf16 weight of the step: one launch.  Nothing before layer 1 reads them
+                # (the stem takes the raw conv weight), so the launch runs on the (idle) weight-gradient stream next to
+                # the stem and the launch stream joins it in front of layer 1
+                if WGRAD_STREAM and PREP_ASYNC:
+                    ws = _wgrad_stream(tp.dev)
+                    ws.wait_stream(torch.cuda.current_stream(tp.dev))      # after the optimizer's parameter update
+                    with torch.cuda.stream(ws):
+                        wp.run()
+                        tp.prep_event = torch.cuda.Event()
+                        tp.prep_event.record(ws)
+                else:
+                    wp.run()
                 tp.wc.update(wp.cache)
             else:                                        # first step in this mode: per-layer path, logged
                 tp.prep = wp

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
 
-ABI_VERSION = 4       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+ABI_VERSION = 5       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
@@ -27,7 +27,8 @@ class GrlGemm(C.Structure):
                [(n, _i32) for n in ('M', 'N', 'K', 'lda', 'ldw', 'ldy', 'ldres', 'rows_per_group',
                                     'relu', 'epilogue', 'conv', 'H', 'W', 'C', 'Ho', 'Wo', 'kh',
                                     'kw', 'stride', 'pad', 'math', 'out_f32', 'res_rows', 'res_gstride', 'kblock')] + \
-               [('splitk_ws', _fp), ('splitk_ws_floats', _i64)]
+               [('splitk_ws', _fp), ('splitk_ws_floats', _i64)] + \
+               [(n, _fp) for n in ('bn_z', 'bn_mean', 'bn_invstd', 'bn_mscale', 'bn_mbeta', 'bn_bits')]
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16S = 0, 1, 3, 2
@@ -75,6 +76,7 @@ _SIGNATURES = {
     'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_bn_bwd_finish': ([_fp] * 9 + [C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
     'grl_axpby': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
     'grl_axpy_strided': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),

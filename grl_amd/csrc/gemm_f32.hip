@@ -632,6 +632,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
             if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
             if (p.epilogue == GRL_EPI_EUCLID) cn = *reinterpret_cast<const f32x4*>(p.cnorm + n);
+            // BatchNorm-backward reduce (GrlGemm.bn_z): this GEMM's output is the gradient of relu?(bn(z) (+res)); it
+            // leaves here masked, with its two column sums -- the reduce pass of grl_bn_bwd without a second read
+            f32x4 bmu = sh, bis = sh, bms = sh, bmb = sh;
+            if constexpr (MATH != 2) {
+                if (p.bn_z) {
+                    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + n);
+                    bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + n);
+                    if (p.bn_mscale) bms = *reinterpret_cast<const f32x4*>(p.bn_mscale + n);
+                    if (p.bn_mbeta) bmb = *reinterpret_cast<const f32x4*>(p.bn_mbeta + n);
+                }
+            }
 #pragma unroll EPI_UNROLL
             for (int it = 0; it < WTM / RPI; ++it) {
                 const int row = wm * WTM + it * RPI + lrow;
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                         if (p.gbias)
                             v += *reinterpret_cast<const f32x4*>(
                                 p.gbias + (int64_t)(m / p.rows_per_group) * p.N + n);
-                        if (p.stats) { ssum += v; ssq += v * v; }
+                        if (p.stats && !p.bn_z) { ssum += v; ssq += v * v; }
                         v = v * sc + sh;
                         if (p.res) {
                             if constexpr (MATH == 2) {
@@ -660,6 +671,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                         if (p.relu) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                        if constexpr (MATH != 2) {
+                            if (p.bn_z) {
+                                const f32x4 zc = *reinterpret_cast<const f32x4*>(p.bn_z + (int64_t)m * p.N + n) - bmu;
+                                if (p.bn_bits) {
+                                    const uint32_t mk = p.bn_bits[((int64_t)m * p.N + n) >> 2];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = (mk >> e) & 1u ? v[e] : 0.f;
+                                } else if (p.bn_mscale) {          // the forward's (z - mean) * scale + beta, term for term
+                                    f32x4 t = zc * bms;
+                                    if (p.bn_mbeta) t += bmb;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+                                }
+                                ssum += v; ssq += v * (zc * bis);
+                            }
                         }
                     } else if (p.epilogue == GRL_EPI_NEGDOT) {
                         v = -v;
@@ -964,6 +991,15 @@ int validate(const GrlGemm& d) {
             return grl_fail(GRL_EINVAL, "gemm: SQDIFF needs M, N % 128 == 0, res_rows % 32 == 0, aligned operands");
     }
     if (d.kblock && d.math != GRL_MATH_F32) return grl_fail(GRL_EINVAL, "gemm: kblock needs GRL_MATH_F32");
+    if (d.bn_z) {
+        if (d.math == GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.kblock || !d.stats || !d.bn_mean || !d.bn_invstd)
+            return grl_fail(GRL_EINVAL, "gemm: bn_z needs fp32 storage, the AFFINE epilogue, no kblock, stats, bn_mean, bn_invstd");
+        if (d.N % 4 || d.ldy % 4 || (d.res && d.ldres % 4) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.res & 15) ||
+            ((uintptr_t)d.bn_z & 15) || ((uintptr_t)d.bn_mean & 15) || ((uintptr_t)d.bn_invstd & 15) ||
+            ((uintptr_t)d.bn_mscale & 15) || ((uintptr_t)d.bn_mbeta & 15) || ((uintptr_t)d.bn_bits & 3) ||
+            ((uintptr_t)d.scale & 15) || ((uintptr_t)d.shift & 15) || d.gbias || d.rowscale)
+            return grl_fail(GRL_EINVAL, "gemm: bn_z needs N, ldy, ldres % 4 == 0 and 16-byte aligned operands");
+    }
     return GRL_OK;
 }
 

@@ -1555,6 +1555,21 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     return grl_check_launch("grl_bn_bwd");
 }
 
+extern "C" int grl_bn_bwd_finish(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                 float* dz, float* dgamma, float* dbeta, const float* slab, int rows, float* coef_ws, int M,
+                                 int C, float* gres, int gres_accumulate, void* stream) {
+    GRL_REQUIRE(g && z && mean && invstd && dz && slab && coef_ws && rows > 0 && M > 0 && C % 4 == 0, "bn_bwd_finish: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
+    const int64_t total4 = (int64_t)M * C / 4;
+    // g is masked already: no activation, no mask recomputation; gres == g (the residual adopts the buffer) needs nothing
+    float* const gres2 = gres == g ? nullptr : gres;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, g, z, (const float*)nullptr, mean, invstd,
+                       gamma, coef_ws, dz, C, total4, gres2, gres2 ? gres_accumulate : 0, (const float*)nullptr,
+                       (const float*)nullptr, (const uint8_t*)nullptr);
+    return grl_check_launch("grl_bn_bwd_finish");
+}
+
 extern "C" int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream) {
     GRL_REQUIRE(dy && out && n > 0 && n % 4 == 0, "relu_bwd: bad args");
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, act, out, n / 4,

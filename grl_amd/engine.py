@@ -146,7 +146,7 @@ SPLITK = True       # tests / A-B only: False = never hand the library split-K s
 def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, res=None,
          ldres=0, gbias=None, rows_per_group=0, rowscale=None, relu=False,
          epilogue=EPI_AFFINE, rnorm=None, cnorm=None, stats=None, conv=None, math=None, out_f32=False,
-         kblock=False, res_rows=0, res_gstride=0):
+         kblock=False, res_rows=0, res_gstride=0, bn=None):
     """Y[M][N] = epilogue(A . W^T) through grl_conv_gemm_f32.  ``conv`` is
     (H, W, C, Ho, Wo, kh, kw, stride, pad) for an implicit-GEMM convolution.
     ``stats=True`` allocates and returns the per-channel partial-sum slab
@@ -171,6 +171,8 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     d.out_f32 = 1 if out_f32 else 0
     d.kblock = 1 if kblock else 0
     d.res_rows, d.res_gstride = res_rows, res_gstride
+    if bn is not None:                    # BatchNorm-backward reduce in the epilogue (GrlGemm.bn_z; with stats=True)
+        d.bn_z, d.bn_mean, d.bn_invstd, d.bn_mscale, d.bn_mbeta, d.bn_bits = (ptr(t) for t in bn)
     if conv is not None:
         d.conv = 1
         (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv

@@ -74,7 +74,7 @@ def gemm(a, w, *args, **kw):
         # with them the parameter gradients' agreement with the reference -- and for the skinny GEMMs of either pass
         # (M <= 256: K-blocked is what lets them split over K).  The data-gradient GEMMs of the backward keep the one
         # chain: no mask depends on them, and the K-blocked kernels cost ~4 % on K >= 1024 (round 3).
-        kw.setdefault('kblock', (not _in_backward[0]) or args[1] <= 256 or _BWD_KBLOCK)
+        kw.setdefault('kblock', ((not _in_backward[0]) or args[1] <= 256 or _BWD_KBLOCK) and kw.get('bn') is None)
     return engine.gemm(a, w, *args, **kw)
 
 
@@ -230,6 +230,8 @@ class Tape(object):
         self.b16 = False     # bf16-storage step: the packed / transposed weights below are handed out as bf16 copies
         self.prep = None     # WeightPrep being recorded (first step of a model in this storage mode), or None
         self.params_by_ptr = None
+        self.bnrec = {}         # id(activation of a conv_bn) -> _BNRec: what its BatchNorm backward needs (fused reduce)
+        self.fuse_ok = set()    # ids of activations whose ONLY consumers are conv_bn ops (as input or residual)
         self.prep_event = None  # WeightPrep launched on the side stream: the launch stream joins it before layer 1
 
     # gradients of activations -------------------------------------------------
@@ -427,6 +429,7 @@ class Tape(object):
 
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
+BN_REDUCE_FUSED = os.environ.get('GRL_BN_REDUCE_FUSED', '1') != '0'     # A/B and tests only
 PREP_ASYNC = os.environ.get('GRL_PREP_ASYNC', '1') != '0'               # A/B and tests only
 RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B and tests only
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
@@ -538,6 +541,23 @@ def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc
 # ----------------------------------------------------------------------------
 # ops (forward now, backward closure on the tape)
 # ----------------------------------------------------------------------------
+class _BNRec(object):
+    """What the data-gradient GEMM that completes grad(a), a = relu?(bn(z) (+res)), needs to run that BatchNorm's
+    backward reduce in its epilogue (GrlGemm.bn_z): ``uses`` counts the contributions still to come."""
+    __slots__ = ('z', 'st', 'bits', 'from_z', 'uses', 'slab')
+
+    def args(self):
+        return (self.z, self.st.mean, self.st.invstd, self.st.scale if self.from_z else None,
+                self.st.beta if self.from_z else None, self.bits)
+
+
+def _bn_use(tp, t, n=1):
+    r = tp.bnrec.get(id(t)) if t is not None else None
+    if r is not None:
+        r.uses += n
+    return r
+
+
 def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kcols=None, ldw=None):
     """Conv (1x1 / 3x3, stride 1 / 2) + train-mode BN (+residual) (+ReLU).
     x: channels-last [n_img*H*W][cin].  ``kcols``/``ldw``: use only the first kcols input
@@ -566,6 +586,15 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
     if relu and res is not None and RELU_BITS:
         bits = torch.empty(M * N // (8 if a.dtype == BF16 else 4), dtype=torch.uint8, device=tp.dev)
     bn_apply(z, st, res, a, M, N, relu, bits=bits)
+    # (fused BatchNorm-backward reduce, GrlGemm.bn_z: this op is one consumer of x and of res, and `a` gets a record
+    # that the data-gradient GEMM completing grad(a) can use)
+    _bn_use(tp, x)
+    _bn_use(tp, res)
+    rec = None
+    if relu and (res is None or bits is not None) and a.dtype != BF16:
+        rec = _BNRec()
+        rec.z, rec.st, rec.bits, rec.from_z, rec.uses, rec.slab = z, st, bits, res is None, 0, None
+        tp.bnrec[id(a)] = rec
 
     def bwd():
         da = tp.take(a)
@@ -580,8 +609,18 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
                 # first contribution to grad(res): it IS the masked da -- the reduce pass of grl_bn_bwd masks da in
                 # place (gres == dy) and this tape entry adopts the buffer (da was popped: nobody else reads it)
                 gres = tp.g[id(res)] = da if relu else _newl((M, N), da)
-        dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
-                         gres=gres, gres_acc=gacc, mask_from_z=relu and res is None, bits=bits)
+            _bn_use(tp, res, -1)
+        if rec is not None and rec.slab is not None:
+            # the GEMM that completed grad(a) masked it and left the two column sums (rec.slab): finalize + apply only
+            dz = _newl((M, N), da)
+            coef = _new((2, N), da)
+            _call('grl_bn_bwd_finish', ptr(da), ptr(z), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(dz),
+                  ptr(tp.pgrad(bn.weight)), ptr(tp.pgrad(bn.bias)), ptr(rec.slab), rec.slab.shape[0], ptr(coef), M, N,
+                  ptr(gres), gacc)
+            rec.slab = None
+        else:
+            dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
+                             gres=gres, gres_acc=gacc, mask_from_z=relu and res is None, bits=bits)
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
                                    kcols=kcols, ldw=ldw)
         if gbias is not None:
@@ -609,10 +648,18 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     # (res = y = that tensor: every element is read and written by the same lane)
     cur = tp.g.get(id(x))
     dx = cur if cur is not None else _newl((Min, cin), dz)
+    # this data gradient completes grad(x) and x = relu(bn(z') (+res')) of a conv_bn whose consumers are all known: run
+    # that BatchNorm's backward reduce in the GEMM epilogue (GrlGemm.bn_z) instead of re-reading the gradient
+    rec = tp.bnrec.get(id(x)) if (BN_REDUCE_FUSED and id(x) in tp.fuse_ok) else None
+    fuse = (rec is not None and rec.uses == 1 and stride == 1 and kcols is None and dz.dtype == torch.float32)
+    if rec is not None:
+        rec.uses -= 1
     if k == 1:
         w2d = w.detach().view(N, -1)
         wt = tp.w_t(w2d[:, :cin] if kcols else w2d, w, ld=w2d.shape[1], like=dz)
-        if stride != 1:
+        if fuse:
+            _, rec.slab = gemm(dz, wt, dx, Min, cin, N, res=cur, stats=True, bn=rec.args())
+        elif stride != 1:
             # a 1x1 stride-2 conv only reads the even pixels: its data gradient is a GEMM at OUTPUT
             # resolution scattered to them (a quarter of the zero-stuffed GEMM's FLOPs)
             small = _newl((M, cin), dz)
@@ -621,7 +668,11 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
         else:
             gemm(dz, wt, dx, Min, cin, N, res=cur)
     elif stride == 1:
-        gemm(dz, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
+        if fuse:
+            _, rec.slab = gemm(dz, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur,
+                               stats=True, bn=rec.args())
+        else:
+            gemm(dz, tp.w_dgrad(conv), dx, Min, cin, k * k * N, conv=(H, W, N, H, W, k, k, 1, k // 2), res=cur)
     elif k == 3 and stride == 2 and H == 2 * Ho and W == 2 * Wo:
         # 3x3 stride-2 pad-1: input pixel (2a+py, 2b+px) only meets the taps ky = 1 (py = 0) or
         # ky = 2, 0 (py = 1; output rows a, a+1), likewise in x -- four small stride-1 convolutions
@@ -817,6 +868,11 @@ def trunk_train(tp, model, x):
             else:
                 res = cur
             cur, _, _, _ = conv_bn(tp, o2, n, Ho, Wo, blk.conv3, blk.bn3, True, res=res)
+            # every consumer of o1, o2 and of a block's output is a conv_bn of this loop (the LAST block's output also
+            # feeds GCE: not marked) -- the premise of the fused BatchNorm-backward reduce
+            tp.fuse_ok.update((id(o1), id(o2)))
+            if not (li == 7 and blk is base[li][-1]):
+                tp.fuse_ok.add(id(cur))
             H, W = Ho, Wo
         if tp.taps is not None:
             tp.taps['layer%d' % (li - 3)] = engine._to_nchw(cur, n, H, W)

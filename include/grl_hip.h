@@ -34,8 +34,8 @@ extern "C" {
 const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
- * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits). */
-#define GRL_ABI_VERSION 4
+ * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*). */
+#define GRL_ABI_VERSION 5
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */
@@ -105,6 +105,20 @@ typedef struct GrlGemm {
      * fewer floats than grl_conv_gemm_f32_workspace_floats() asks for: the one-workgroup form runs. */
     float*  splitk_ws;
     int64_t splitk_ws_floats;
+    /* Optional BatchNorm-BACKWARD reduce in the epilogue (round 3; fp32 storage, AFFINE epilogue, 16-byte aligned
+     * rows): when this GEMM produces the last contribution to the gradient of y = relu?(bn(z) (+res)) -- a data-
+     * gradient GEMM whose output (+ `res`, the contributions so far) IS that gradient -- the epilogue masks it,
+     * g = v * mask, writes g to `y` and leaves the two column sums of the BatchNorm backward in `stats`:
+     * stats[tile][0][n] = sum_rows g, stats[tile][1][n] = sum_rows g * (z - mean) * invstd -- what
+     * grl_bn_bwd's reduce pass computes, without re-reading the gradient (grl_bn_bwd_finish does the rest).
+     * mask: bn_bits (the forward's recorded (y > 0) bytes, grl_bn_apply_centered) if given, else
+     * ((z - mean) * bn_mscale + bn_mbeta > 0) if bn_mscale is given, else none.  bn_z NULL = off. */
+    const float*   bn_z;       /* [M][N] (row stride N) */
+    const float*   bn_mean;    /* [N] */
+    const float*   bn_invstd;  /* [N] */
+    const float*   bn_mscale;  /* [N] or NULL */
+    const float*   bn_mbeta;   /* [N] or NULL */
+    const uint8_t* bn_bits;    /* [M * N / 4] or NULL */
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
@@ -305,6 +319,12 @@ int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* m
                const float* invstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
                float* slab_ws, float* coef_ws, int M, int C, float* gres, int gres_accumulate,
                const float* mask_scale, const float* mask_beta, const uint8_t* relu_bits, void* stream);
+/* The second half of grl_bn_bwd for a gradient that is ALREADY masked and reduced (GrlGemm.bn_z: the producing
+ * data-gradient GEMM's epilogue left g in `g` and the partial sums in `slab`, `rows` of them): finalize (dgamma,
+ * dbeta, the two means) and apply dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); gres (+)= g as in grl_bn_bwd. */
+int grl_bn_bwd_finish(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                      float* dz, float* dgamma, float* dbeta, const float* slab, int rows, float* coef_ws, int M, int C,
+                      float* gres, int gres_accumulate, void* stream);
 
 /* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
 int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);

@@ -512,3 +512,54 @@ def test_relu_mask_bits_equal_reading_the_activation(math):
         TE.set_math(old)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f32", "mixed"])
+def test_bn_backward_reduce_in_the_gemm_epilogue(golden, math):
+    """train_engine.BN_REDUCE_FUSED (GrlGemm.bn_z): the data-gradient GEMM that completes the gradient of a bottleneck
+    activation masks it and leaves the BatchNorm backward's two column sums in its epilogue; grl_bn_bwd_finish does the
+    rest.  Same mathematics as the separate reduce pass in another summation order: the forward is bit-identical,
+    every parameter gradient agrees to 2e-4 relative L2 (fp32 sums of 16384-262144 signed terms in two orders: measured
+    worst 3.5e-5, a BatchNorm bias; `mixed`: 1e-3, the split-bf16 products see differently rounded inputs), and the fused path is actually
+    taken (the reduce kernel runs less often)."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clip = synth_clips_structured(B, T, seed=97).cuda()
+    g = torch.Generator().manual_seed(8)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs, fused_calls = [], []
+    old = TE.set_math(math)
+    orig = TE._call
+    try:
+        for fused in (True, False):
+            TE.BN_REDUCE_FUSED = fused
+            n = [0]
+
+            def spy(name, *a, _n=n):
+                if name == 'grl_bn_bwd_finish':
+                    _n[0] += 1
+                return orig(name, *a)
+            TE._call = spy
+            cnn = _fresh()
+            xu, xc = cnn(clip)
+            ((xu * r1).sum() + (xc * r2).sum()).backward()
+            fused_calls.append(n[0])
+            outs.append(([xu.detach().clone(), xc.detach().clone()],
+                         {k: p.grad.clone() for k, p in cnn.named_parameters() if p.grad is not None}))
+    finally:
+        TE._call = orig
+        TE.BN_REDUCE_FUSED = True
+        TE.set_math(old)
+    torch.cuda.synchronize()
+    assert fused_calls[0] >= 30 and fused_calls[1] == 0, fused_calls     # 16 blocks x (bn1, bn2, bn3) minus stride-2 / last
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    worst = 0.0
+    live = [str(k) for k in golden('grl_train_cond_b8t4.npz')['meta.keys']]     # (not the analytically-zero gradients:
+    for k in live:                                                               #  rounding noise in either order)
+        ga, gb = outs[0][1][k], outs[1][1][k]
+        e = float((ga.double() - gb.double()).norm() / gb.double().norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < (1e-3 if math == 'mixed' else 2e-4), (k, e)
+    print('fused BN reduce: %d BatchNorms, worst gradient deviation %.1e' % (fused_calls[0], worst))

@@ -1035,6 +1035,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {               // two k-steps of 16 rows per 32-row stage
                 s16x4 ra[NPL][MT][2], rb[NPL][NT][2];
+                // the hi planes' fragments are requested first and the hi x hi products start as soon as THEY have
+                // arrived (counted wait), while the lo planes' reads are still in flight: half of the LDS latency of a
+                // k-step used to sit in front of all twelve MFMAs (one lgkmcnt(0) after sixteen reads)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -1054,21 +1057,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
                             if (ks == 1 && pl == 1) GRL_TR(rb[pl][j][rd], baddr[j][rd], PLANE + 4096);
                         }
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (MATH == 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 8 hi-plane reads (issued first)
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const bf16x8 ah = GRL_FRAG(ra[0][i][0], ra[0][i][1]), bh = GRL_FRAG(rb[0][j][0], rb[0][j][1]);
-                        if (MATH == 3) {                   // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                    }
+                if (MATH == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const bf16x8 ah = GRL_FRAG(ra[0][i][0], ra[0][i][1]), bh = GRL_FRAG(rb[0][j][0], rb[0][j][1]);
                             const bf16x8 al = GRL_FRAG(ra[NPL - 1][i][0], ra[NPL - 1][i][1]);
                             const bf16x8 bl = GRL_FRAG(rb[NPL - 1][j][0], rb[NPL - 1][j][1]);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
-                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef GRL_TR

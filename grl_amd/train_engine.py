@@ -1088,6 +1088,7 @@ def trl_train(tp, model, xu, xc, b, t):
                 o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
                 o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
                 memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
+                tp.fuse_ok.update((id(o), id(o2)))       # single conv_bn consumers: fused BatchNorm-backward reduce
                 tp.side = None
     mf, mb_ = memo
     fk.join(mb_, fc[1])

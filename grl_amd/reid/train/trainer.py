@@ -27,6 +27,39 @@ except Exception:                               # pragma: no cover
 
 criterion_triplet = TripletLoss('soft', True)
 
+HEAD_STREAMS = __import__('os').environ.get('GRL_HEAD_STREAMS', '1') != '0'
+_head_streams = {}
+
+
+class _HeadFork(object):
+    """``with _HeadFork(x) as fk:`` runs the block on a side HIP stream forked from the current one; ``fk.join()``
+    makes the launch stream wait for it (no-op on CPU tensors or with GRL_HEAD_STREAMS=0)."""
+
+    def __init__(self, x):
+        self.on = HEAD_STREAMS and x.is_cuda
+        if self.on:
+            key = x.device.index if x.device.index is not None else torch.cuda.current_device()
+            if key not in _head_streams:
+                _head_streams[key] = torch.cuda.Stream(x.device)
+            self.side, self.main = _head_streams[key], torch.cuda.current_stream(x.device)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        """The launch stream waits for the side stream (call before the first use of the block's results)."""
+        if self.on:
+            self.main.wait_stream(self.side)
+
 
 class BaseTrainer(object):
     def __init__(self, model, criterion):
@@ -158,12 +191,20 @@ class SEQTrainer(BaseTrainer):
             batch_size = x_corr.size(0)
         frame_corr = x_corr.reshape(batch_size * seq_len, -1)
         targetX = targets.unsqueeze(1).expand(batch_size, seq_len).reshape(-1)
-        corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)
-        corr_prec_id_frame = self._top1(output_id, targetX)
-
         pairs = targets.data.view(batch_size // 2, -1)
         tar_probe, tar_gallery = pairs[:, 0], pairs[:, 1]
         target = torch.cat((tar_probe, tar_gallery))
+        # The uncorrelated branch's head and id loss depend on nothing below: both heads are chains of small,
+        # latency-bound launches, so this one is issued on a side HIP stream next to the correlated branch's (autograd
+        # runs each node's backward on its forward stream, so the backward overlaps the same way); joined before the sum.
+        fk = _HeadFork(x_uncorr)
+        with fk:
+            encode_scores, siamese_out = self.siamese_model_uncorr(x_uncorr)
+            uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out, target)
+            uncorr_prec_id_vid = self._top1(output_id, target)
+        # (the reference also evaluates the uncorr verification loss but never adds it)
+        corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)
+        corr_prec_id_frame = self._top1(output_id, targetX)
 
         encode_scores, siamese_out = self.siamese_model(x_corr)
         corr_id_loss_vid, output_id = self.criterion_corr(siamese_out, target)
@@ -171,11 +212,7 @@ class SEQTrainer(BaseTrainer):
         corr_loss_tri = criterion_triplet(siamese_out, target).mean()
         corr_loss_ver, _ = self.criterion_ver(self._pair_prob(encode_scores), tar_probe, tar_gallery)
 
-        encode_scores, siamese_out = self.siamese_model_uncorr(x_uncorr)
-        uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out, target)
-        uncorr_prec_id_vid = self._top1(output_id, target)
-        # (the reference also evaluates the uncorr verification loss but never adds it)
-
+        fk.join()
         corr_loss = corr_id_loss_frame + corr_id_loss_vid + corr_loss_ver * 20 + corr_loss_tri
         all_loss = uncorr_id_loss_vid + corr_loss
         return all_loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame

@@ -1007,12 +1007,12 @@ int validate(const GrlGemm& d) {
 
 extern "C" int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc) {
     if (!desc) return grl_fail(GRL_EINVAL, "null desc");
-    if (desc->math == GRL_MATH_BF16S) {                 // the 256 x 256 kernel writes two slab rows per tile
-        GrlGemm probe = *desc;
-        if (!probe.stats) probe.stats = reinterpret_cast<float*>((uintptr_t)16);     // (asked before the slab exists)
-        if (grl_gemm_bf16_256_takes(probe)) return grl_gemm_bf16_256_stat_rows(probe);
+    GrlGemm probe = *desc;
+    if (!probe.stats) probe.stats = reinterpret_cast<float*>((uintptr_t)16);         // (asked before the slab exists; the
+    if (desc->math == GRL_MATH_BF16S) {                                               //  tile choice depends on `stats`)
+        if (grl_gemm_bf16_256_takes(probe)) return grl_gemm_bf16_256_stat_rows(probe);      // two slab rows per 256-row tile
     }
-    const TileChoice t = choose_tile(*desc);
+    const TileChoice t = choose_tile(probe);
     return (desc->M + t.bm - 1) / t.bm;
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One GEMM shape under each forced tile (child processes: GRL_GEMM_TILE is read once per process), fp32 or bf16
-storage, alone and with a twin of itself on a second stream (the two TRL directions run their memo-block GEMMs
+storage (`f32+stats` / `bf16s+stats`: the train-mode forward form), alone and with a twin of itself on a second stream (the two TRL directions run their memo-block GEMMs
 concurrently).   python tools/gemm_tile_ab.py bf16s 8192 512 2048 [8192 2048 512 ...]"""
 import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,17 +10,20 @@ if os.environ.get('GRL_TILE_AB_CHILD'):
     math = sys.argv[1]
     M, N, K = (int(v) for v in sys.argv[2:5])
     dev = torch.device('cuda:0')
+    stats = math.endswith('+stats')                       # the train-mode forward form: raw output + statistics slab
+    math = math.replace('+stats', '')
     dt = torch.bfloat16 if math == 'bf16s' else torch.float32
     mk = lambda: (torch.randn(M, K, device=dev).to(dt), (torch.randn(N, K, device=dev) * 0.05).to(dt), torch.empty(M, N, device=dev, dtype=dt))
     a, w, y = mk(); a2, w2, y2 = mk()
     sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
     m = engine.MATH_BF16S if math == 'bf16s' else engine.MATH_F32
     s2 = torch.cuda.Stream()
-    def one(): engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, relu=True, math=m)
+    kw = dict(stats=True) if stats else dict(scale=sc, shift=sh, relu=True)
+    def one(): engine.gemm(a, w, y, M, N, K, math=m, **kw)
     def two():
         s2.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s2): engine.gemm(a2, w2, y2, M, N, K, scale=sc, shift=sh, relu=True, math=m)
-        engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, relu=True, math=m)
+        with torch.cuda.stream(s2): engine.gemm(a2, w2, y2, M, N, K, math=m, **kw)
+        engine.gemm(a, w, y, M, N, K, math=m, **kw)
         torch.cuda.current_stream().wait_stream(s2)
     out = []
     for fn, mult in ((one, 1), (two, 2)):

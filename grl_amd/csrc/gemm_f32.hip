@@ -866,6 +866,18 @@ TileChoice choose_tile(const GrlGemm& d) {
         return (int64_t)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
     };
     if (d.N <= 64) return tiles(128, 64) >= 512 ? TileChoice{128, 64} : TileChoice{64, 64};
+    // Round 3 (tools/gemm_tile_ab.py, per shape in child processes): with LDS-DMA staging and the vectorized epilogue
+    // the 128 x 128 tile now wins on the SHORT-K layers too wherever it still gives every CU a tile -- 16384x1024x256
+    // (+res) 104 -> 100 us, 16384x2048x512 (+res) 357 -> 338, 65536x128x512 93 -> 88, 16384x256x2304 188 -> 179,
+    // 262144x256x64 157 -> 140 -- except the K <= 128 layers WITH a residual (its rows are not prefetched on this tile:
+    // 180 -> 218 us) and 128-tile grids (4096x512x2048: 87 -> 143 us).  Results do not depend on the tile (one k-ordered
+    // chain per output).  Not for the statistics GEMMs of the training forward: their partial sums would cover 128 rows
+    // instead of 64 and the 4 x 8 fixture's outputs leave the 1e-4 pin.
+    static const bool wide_on = [] { const char* e = getenv("GRL_GEMM_WIDE"); return !e || atoi(e) != 0; }();
+    static const bool wide3_on = [] { const char* e = getenv("GRL_GEMM_WIDE3"); return !e || atoi(e) != 0; }();   // split-bf16 / bf16 products too
+    if (wide_on && !d.stats && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
+        tiles(128, 128) >= 256 && !(d.res && d.K <= 128))
+        return {128, 128};
     if (d.K <= 128) return {64, 64};
     if (d.K <= 512) return tiles(128, 64) >= 448 ? TileChoice{128, 64} : TileChoice{64, 64};
     if (tiles(128, 128) >= 448) return {128, 128};

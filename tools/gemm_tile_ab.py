@@ -10,6 +10,8 @@ if os.environ.get('GRL_TILE_AB_CHILD'):
     math = sys.argv[1]
     M, N, K = (int(v) for v in sys.argv[2:5])
     dev = torch.device('cuda:0')
+    with_res = math.endswith('+res')                      # the eval form of the expansion layers: + residual, ReLU
+    math = math.replace('+res', '')
     stats = math.endswith('+stats')                       # the train-mode forward form: raw output + statistics slab
     math = math.replace('+stats', '')
     dt = torch.bfloat16 if math == 'bf16s' else torch.float32
@@ -19,6 +21,8 @@ if os.environ.get('GRL_TILE_AB_CHILD'):
     m = engine.MATH_BF16S if math == 'bf16s' else engine.MATH_F32
     s2 = torch.cuda.Stream()
     kw = dict(stats=True) if stats else dict(scale=sc, shift=sh, relu=True)
+    if with_res:
+        kw['res'] = torch.randn(M, N, device=dev).to(dt)
     def one(): engine.gemm(a, w, y, M, N, K, math=m, **kw)
     def two():
         s2.wait_stream(torch.cuda.current_stream())

@@ -43,7 +43,8 @@ if os.environ.get('GRL_TILE_AB_CHILD'):
 math = sys.argv[1]
 shapes = [tuple(sys.argv[i:i + 3]) for i in range(2, len(sys.argv), 3)]
 for shp in shapes:
-    for tile in ('', '128x128', '128x64', '64x64'):
-        env = dict(os.environ, GRL_TILE_AB_CHILD='1', GRL_GEMM_TILE=tile, GRL_GEMM_BF16_256='0' if tile else os.environ.get('GRL_GEMM_BF16_256', '-1'))
+    for tile in ('', '128x128', '128x64', '64x64') + (('256x256',) if math.startswith('bf16s') else ()):
+        env = dict(os.environ, GRL_TILE_AB_CHILD='1', GRL_GEMM_TILE='' if tile == '256x256' else tile,
+                   GRL_GEMM_BF16_256='1' if tile == '256x256' else ('0' if tile else os.environ.get('GRL_GEMM_BF16_256', '-1')))
         r = subprocess.run([sys.executable, __file__, math] + list(shp), env=env, capture_output=True, text=True)
         print('%s %-18s tile %-8s %s' % (math, 'x'.join(shp), tile or 'auto', r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-200:]))

@@ -40,5 +40,37 @@ for it in range(max(10, reps // 5)):
         n += 1
 print('train step: %d/%d runs differ from the first' % (n, max(10, reps // 5) - 1))
 bad += n
+# (c) the whole SEQTrainer step -- heads on two streams, weight table on the side stream, fused BatchNorm reduce,
+# gradient buffers adopted by autograd, fused SGD -- twice from the same start: every parameter, BatchNorm statistic and
+# OIM table equal after `nst` steps
+import contextlib, io
+from grl_amd.reid import models
+from grl_amd.reid.train import SEQTrainer
+from grl_amd.reid.loss import OIMLoss, PairLoss
+from grl_amd.synthetic import synth_state_dict
+nst = max(8, reps // 4)
+def run_trainer():
+    with contextlib.redirect_stdout(io.StringIO()):
+        c = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+    sm = models.create('siamese', input_num=2048, output_num=512, class_num=2)
+    sv = models.create('siamese_video', input_num=2048, output_num=512, class_num=2)
+    c.load_state_dict(synth_state_dict(c, seed=0, profile='conditioned'))
+    sm.load_state_dict(synth_state_dict(sm, seed=0, prefix='siamese.'))
+    sv.load_state_dict(synth_state_dict(sv, seed=0, prefix='siamese_video.'))
+    mods = [m.to(dev).train() for m in (c, sm, sv)]
+    crits = [OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev) for _ in range(2)]
+    tr = SEQTrainer(mods[0], mods[1], mods[2], PairLoss().to(dev), crits[0], crits[1], None)
+    opt = torch.optim.SGD(tr._all_params(), lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True, fused=True)
+    for i in range(nst):
+        cl = synth_clips_structured(8, 4, seed=100 + i).to(dev)
+        pid = ((torch.arange(8) // 2) * 7 + i).to(dev) % 625
+        loss = tr._forward([cl], pid, 0, 0)[0]
+        opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+    torch.cuda.synchronize()
+    return [v.detach().clone() for m in mods for v in m.state_dict().values()] + [cr.lut.clone() for cr in crits]
+a, b = run_trainer(), run_trainer()
+n = sum(0 if torch.equal(x, y) else 1 for x, y in zip(a, b))
+print('trainer, %d steps twice: %d/%d state tensors differ' % (nst, n, len(a)))
+bad += n
 print('SOAK', 'FAILED' if bad else 'ok')
 sys.exit(1 if bad else 0)

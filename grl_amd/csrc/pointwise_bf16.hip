@@ -190,53 +190,53 @@ constexpr int SB_CH = 22;                                      // 8-wide k chunk
 constexpr int SB_K = SB_CH * 8, SB_ROWB = SB_K * 2 + 16;       // 176 k; bytes per bf16 row (352 + 16 pad)
 constexpr int SB_PATCH = 3 * SB_PH * SB_PWP;                   // bf16 cells (column SB_PW of every row is a zero pad)
 
+constexpr int SB_TPW = 4;                             // y-tiles one workgroup walks (weights staged once, round 3)
+
 __global__ __launch_bounds__(256) void stem_b16_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
     const float* __restrict__ shift, __bf16* __restrict__ y, int H, int W, int relu,
     const __bf16* __restrict__ wp, const float* __restrict__ norm) {
     // norm != NULL: x holds raw u8 pixels, normalised here as (u/255 - mean[c]) / std[c]
+    // One workgroup walks SB_TPW tiles down its column strip: the 23.5 KB weight image is staged once (the epilogue's
+    // fp32 staging overlays the im2col tile only), and the NEXT tile's patch is requested before this tile's im2col /
+    // MFMA / epilogue phases, which used to wait for it with nothing else to do (two workgroups per CU).
     extern __shared__ __attribute__((aligned(16))) char smb[];
     char* At = smb;                                            // [128][368 B]
     char* Wt = At + 128 * SB_ROWB;                             // [64][368 B]
     __bf16* patch = reinterpret_cast<__bf16*>(Wt + 64 * SB_ROWB);   // [3][21][38]
     float* Cs = reinterpret_cast<float*>(smb);                 // epilogue staging [128][64] fp32 (32 KB < At)
     const int Ho = H >> 1, Wo = W >> 1;
-    const int img = blockIdx.z, oy0 = blockIdx.y * SB_TH, ox0 = blockIdx.x * SB_TW;
+    const int img = blockIdx.z, ox0 = blockIdx.x * SB_TW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const int ix0 = ox0 * 2 - 3;
     const float* xi = x + (int64_t)img * 3 * H * W;
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
-    // every global load of the staging phase is issued before the first one is waited for (written as loops
-    // over `tid + it * 256`, hipcc emitted load / s_waitcnt vmcnt(0) / ds_write per iteration: ten exposed
-    // HBM latencies per workgroup, which is what the kernel spent its time on)
     constexpr int P_IT = (SB_PATCH + 255) / 256, W_IT = (64 * SB_ROWB / 16 + 255) / 256;
     float pv[P_IT];
-    bf16x8 wv[W_IT];
+    auto load_patch = [&](const int oy0) {
+        const int iy0 = oy0 * 2 - 3;
 #pragma unroll
-    for (int it = 0; it < P_IT; ++it) {
-        const int i = tid + it * 256;
-        const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
-        const int iy = iy0 + r, ix = ix0 + q;
-        const bool ok = i < SB_PATCH && q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
-        pv[it] = norm ? (float)xu[o] : xi[o];
-        if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
-        if (!ok) pv[it] = 0.f;
-    }
+        for (int it = 0; it < P_IT; ++it) {
+            const int i = tid + it * 256;
+            const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
+            const int iy = iy0 + r, ix = ix0 + q;
+            const bool ok = i < SB_PATCH && q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
+            pv[it] = norm ? (float)xu[o] : xi[o];
+            if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
+            if (!ok) pv[it] = 0.f;
+        }
+    };
+    int oy0 = blockIdx.y * (SB_TPW * SB_TH);
+    load_patch(oy0);
+    // weights: the LDS image [64][368 B] made once by grl_stem_pack_weight_bf16, or converted here
     if (wp) {
+        bf16x8 wv[W_IT];
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * 256;
             wv[it] = reinterpret_cast<const bf16x8*>(wp)[i < 64 * SB_ROWB / 16 ? i : 0];
         }
-    }
-#pragma unroll
-    for (int it = 0; it < P_IT; ++it) {
-        const int i = tid + it * 256;
-        if (i < SB_PATCH) patch[i] = (__bf16)pv[it];
-    }
-    // weights: the LDS image [64][368 B] made once by grl_stem_pack_weight_bf16, or converted here
-    if (wp) {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * 256;
@@ -251,63 +251,73 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
             *reinterpret_cast<bf16x8*>(Wt + n * SB_ROWB + ch * 16) = o;
         }
     }
-    __syncthreads();
-    // im2col in LDS: item = (k chunk, pixel), pixels fastest: the chunk (channel, ky) is wave-uniform and a
-    // pixel's eight taps are eight consecutive bf16 of one patch row (4-byte aligned: four ds_read_b32)
-    for (int i = tid; i < SB_CH * 128; i += 256) {
-        const int ch = i >> 7, m = i & 127;
-        uint32_t o[4] = {0u, 0u, 0u, 0u};
-        if (ch < 21) {
-            const int c = ch / 7, ky = ch - 7 * c;
-            const uint32_t* s2 = reinterpret_cast<const uint32_t*>(
-                patch + ((c * SB_PH) + 2 * (m / SB_TW) + ky) * SB_PWP + 2 * (m % SB_TW));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = s2[e];
-        }
-        *reinterpret_cast<uint4*>(At + m * SB_ROWB + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    __syncthreads();
     const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, fhalf = lane >> 5;
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SB_K / 16; ++s) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Wt + (wn * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                           // At is dead: reuse as fp32 C staging
     const int col_l = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * 64 + wn * 32 + col_l] = acc[i][r];
-    __syncthreads();
-    // 128 pixels x 64 channels: 8 lanes x 8 channels per pixel row, 32 rows per pass
     const int c8 = (tid & 7) * 8;
     f32x8 sc, sh;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = scale[c8 + e]; sh[e] = shift[c8 + e]; }
+    for (int t = 0; t < SB_TPW && oy0 < Ho; ++t, oy0 += SB_TH) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int m = it * 32 + (tid >> 3);
-        const int oy = oy0 + m / SB_TW, ox = ox0 + m % SB_TW;
-        if (oy < Ho && ox < Wo) {
-            f32x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = Cs[m * 64 + c8 + e] * sc[e] + sh[e];
-                v[e] = (t > 0.f || !relu) ? t : 0.f;
-            }
-            st8(y + (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c8, v);
+        for (int it = 0; it < P_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < SB_PATCH) patch[i] = (__bf16)pv[it];
         }
+        __syncthreads();                                       // patch (and, first time, weights) visible; Cs readers of the previous tile done
+        if (t + 1 < SB_TPW && oy0 + SB_TH < Ho) load_patch(oy0 + SB_TH);      // in flight under everything below
+        // im2col in LDS: item = (k chunk, pixel), pixels fastest: the chunk (channel, ky) is wave-uniform and a
+        // pixel's eight taps are eight consecutive bf16 of one patch row (4-byte aligned: four ds_read_b32)
+        for (int i = tid; i < SB_CH * 128; i += 256) {
+            const int ch = i >> 7, m = i & 127;
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+            if (ch < 21) {
+                const int c = ch / 7, ky = ch - 7 * c;
+                const uint32_t* s2 = reinterpret_cast<const uint32_t*>(
+                    patch + ((c * SB_PH) + 2 * (m / SB_TW) + ky) * SB_PWP + 2 * (m % SB_TW));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = s2[e];
+            }
+            *reinterpret_cast<uint4*>(At + m * SB_ROWB + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SB_K / 16; ++s) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Wt + (wn * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                       // At is dead: reuse as fp32 C staging
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * 64 + wn * 32 + col_l] = acc[i][r];
+        __syncthreads();
+        // 128 pixels x 64 channels: 8 lanes x 8 channels per pixel row, 32 rows per pass
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = it * 32 + (tid >> 3);
+            const int oy = oy0 + m / SB_TW, ox = ox0 + m % SB_TW;
+            if (oy < Ho && ox < Wo) {
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float tv = Cs[m * 64 + c8 + e] * sc[e] + sh[e];
+                    v[e] = (tv > 0.f || !relu) ? tv : 0.f;
+                }
+                st8(y + (((int64_t)img * Ho + oy) * Wo + ox) * 64 + c8, v);
+            }
+        }
+        // (the next iteration's first barrier comes after its patch writes, which touch neither At / Cs nor Wt; the
+        // im2col that overwrites Cs follows that barrier)
     }
 }
 
@@ -366,7 +376,7 @@ static int stem_b16_launch(const float* x, const float* norm, const float* w, co
     const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)SB_PATCH * sizeof(__bf16);
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)stem_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH), n), dim3(256), lds,
+    hipLaunchKernelGGL(stem_b16_kernel, dim3(grl_ceil_div(Wo, SB_TW), grl_ceil_div(Ho, SB_TH * SB_TPW), n), dim3(256), lds,
                        (hipStream_t)stream, x, w, scale, shift, B16(y), H, W, relu, CB16(wp), norm);
     return grl_check_launch("grl_stem_conv7x7_bf16");
 }

@@ -55,7 +55,12 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 // bias) for train-mode BatchNorm, one partial per 128-row wave row: stats[2 * tile_m + wr][0|1][n].  A lane sums
 // its 16 rows, the 8 lanes that own the same 8 channels combine by xor-shuffles -- a fixed order, no cross-wave
 // step (each wave row writes its own slab row), so the epilogue keeps its one-barrier-per-tile structure.
-template <bool CONV, bool STATS = false>
+// SQD (GRL_EPI_SQDIFF, round 3): the TRL step's d = GAP((ReLU(conv_f1(memo)) - f2_t)^2) reduced in the epilogue --
+// v = bf16(relu(acc*scale + shift)) (the value the unfused pipeline stores), minus the hoisted conv_f2 output read through
+// `res` (row mapping res_rows / res_gstride), squared, summed per 32-row block in a fixed order (a lane over its 4 rows,
+// then the 8 lanes that own the same 8 channels by xor-shuffles) and written as fp32 partials y[M/32][N]: conv_f1's
+// output never reaches HBM (grl_model.py:146-149), as in the fp32 kernel.
+template <bool CONV, bool STATS = false, bool SQD = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
                                                                const int num_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,7 +269,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = cm0 + i * 32 + it * 8 + lrow;
-                    if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + cn);
+                    if constexpr (SQD) {
+                        const int64_t rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
+                        if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                    } else {
+                        if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + cn);
+                    }
                 }
             }
 #pragma unroll
@@ -275,6 +285,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                     Cs[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
                 }
             // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
+            if constexpr (SQD) {
+                f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + lrow;
+                    if (n_ok) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
+                            v = v * sc[u] + sh[u];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float f1v = (float)(__bf16)(v[e] > 0.f ? v[e] : 0.f);
+                                const float dd = f1v - (float)res8[it][4 * u + e];
+                                part[u][e] += dd * dd;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) part[u][e] += __shfl_xor(part[u][e], o);
+                if (lrow == 0 && n_ok) {
+                    float* const yq = p.y + (int64_t)((cm0 + i * 32) >> 5) * p.ldy + cn;
+                    *reinterpret_cast<f32x4*>(yq) = part[0];
+                    *reinterpret_cast<f32x4*>(yq + 4) = part[1];
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + lrow;
@@ -343,8 +385,17 @@ extern "C" int grl_gemm_bf16_tile_mode(int mode) {
 // 128 x 128 family (shape / feature not covered), < 0 on error.
 // Would grl_gemm_bf16_256 take this launch?  (grl_conv_gemm_f32_stat_rows asks too: the statistics slab then has
 // two rows per 256-row tile.)
+// GRL_EPI_SQDIFF on bf16 storage: only this kernel has it (whatever the tile count)
+static bool sqdiff_ok(const GrlGemm& d) {
+    return d.math == GRL_MATH_BF16S && d.epilogue == GRL_EPI_SQDIFF && !d.conv && !d.stats && !d.gbias && !d.rowscale && d.res &&
+           d.res_rows > 0 && d.res_rows % 32 == 0 && d.M % TB == 0 && d.N % TB == 0 && d.K % 64 == 0 && d.lda % 8 == 0 &&
+           d.ldw % 8 == 0 && d.ldres % 8 == 0 && d.ldy % 4 == 0 && al16(d.a) && al16(d.w) && al16(d.y) && al16(d.res) &&
+           al16(d.scale) && al16(d.shift) && (int64_t)d.M * d.lda * 2 < (1ll << 32) && (int64_t)d.N * d.ldw * 2 < (1ll << 32);
+}
+
 bool grl_gemm_bf16_256_takes(const GrlGemm& d) {
     const int mode = g_mode;
+    if (sqdiff_ok(d)) return true;
     if (mode == 0) return false;
     if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.rowscale || d.out_f32) return false;
     if (d.K % 64 || d.N % 8 || d.ldy % 8 || (d.res && d.ldres % 8) || d.lda % 8 || d.ldw % 8) return false;
@@ -362,6 +413,23 @@ int grl_gemm_bf16_256_stat_rows(const GrlGemm& d) { return 2 * ((d.M + TB - 1) /
 
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     const int mode = g_mode;
+    if (sqdiff_ok(d)) {
+        static const bool attr_sq = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+            return true;
+        }();
+        (void)attr_sq;
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount / 8 * 8 > 0 ? prop.multiProcessorCount / 8 * 8 : 8;
+        const int tiles_n = d.N / TB;
+        const int64_t num_tiles = (int64_t)(d.M / TB) * tiles_n;
+        hipLaunchKernelGGL((gemm_bf16_256_kernel<false, false, true>), dim3((unsigned)(num_tiles < cus ? num_tiles : cus)), dim3(512),
+                           2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        const int e = grl_check_launch("grl_conv_gemm_f32 (bf16 256x256, SQDIFF)");
+        return e ? e : 1;
+    }
     if (mode == 0) return 0;
     if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.rowscale || d.out_f32) return 0;
     if (d.K % 64 || d.N % 8 || d.ldy % 8 || (d.res && d.ldres % 8) || d.lda % 8 || d.ldw % 8) return 0;

@@ -985,7 +985,8 @@ int validate(const GrlGemm& d) {
         return grl_fail(GRL_EINVAL, "gemm: unknown math mode");
     if (d.math == GRL_MATH_BF16S) {
         if (d.K % 64 || (d.conv && d.C % 64)) return grl_fail(GRL_EINVAL, "gemm bf16s: K (and C) must be multiples of 64");
-        if (d.epilogue != GRL_EPI_AFFINE) return grl_fail(GRL_EINVAL, "gemm bf16s: affine epilogue only");
+        if (d.epilogue != GRL_EPI_AFFINE && !(d.epilogue == GRL_EPI_SQDIFF && grl_gemm_bf16_256_takes(d)))
+            return grl_fail(GRL_EINVAL, "gemm bf16s: affine epilogue (or SQDIFF with M, N % 256 == 0, K % 64 == 0, res_rows % 32 == 0)");
         if (d.stats && (d.N % 8 || d.out_f32 || d.rowscale))
             return grl_fail(GRL_EINVAL, "gemm bf16s: stats need N % 8 == 0, bf16 output, no rowscale");
         if (d.N % 4 || d.ldy % 4 || (d.res && d.ldres % 4) || d.lda % 8 || d.ldw % 8 ||
@@ -996,8 +997,9 @@ int validate(const GrlGemm& d) {
         return grl_fail(GRL_EINVAL, "gemm: EUCLID needs rnorm and cnorm");
     if (d.gbias && d.rows_per_group <= 0) return grl_fail(GRL_EINVAL, "gemm: rows_per_group");
     if (d.epilogue == GRL_EPI_SQDIFF) {
-        if (d.math == GRL_MATH_BF16S || d.conv || d.stats || d.rowscale || d.gbias || !d.res)
-            return grl_fail(GRL_EINVAL, "gemm: SQDIFF epilogue is fp32-storage, dense, with res = the f2 tensor");
+        if (d.conv || d.stats || d.rowscale || d.gbias || !d.res)
+            return grl_fail(GRL_EINVAL, "gemm: SQDIFF epilogue is dense, with res = the f2 tensor");
+        if (d.math == GRL_MATH_BF16S) return GRL_OK;          // (checked above: the 256 x 256 kernel takes it)
         if (d.M % 128 || d.N % 128 || d.res_rows <= 0 || d.res_rows % 32 || d.ldres % 4 || d.ldy % 4 ||
             ((uintptr_t)d.res & 15) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.scale & 15) || ((uintptr_t)d.shift & 15))
             return grl_fail(GRL_EINVAL, "gemm: SQDIFF needs M, N % 128 == 0, res_rows % 32 == 0, aligned operands");

@@ -700,9 +700,17 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             with fk.on(di):
                 ti = i if di == 0 else t - 1 - i
                 dvec, hid = scr[di]
-                f1 = _newb((Mb, Cc), x)
-                gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
-                _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+                if FUSE_TRL_SQDIFF and Mb % 256 == 0:
+                    # the squared difference reduced in the f1 GEMM's epilogue (32-row partial sums): conv_f1's output
+                    # never reaches HBM -- round 3: the bf16 256 x 256 kernel has the epilogue too
+                    dpart = _new((Mb // 32, Cc), x)
+                    gemm(memo[di], d['f1'].wb(), dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
+                         res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX, math=MATH_BF16S)
+                    _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
+                else:
+                    f1 = _newb((Mb, Cc), x)
+                    gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
+                    _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
                 _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
                       None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
                 s_ = _newb((Mb, Cc), x)

@@ -231,3 +231,24 @@ def test_bench_launcher_starts_n_fresh_ranks():
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and cmd[cmd.index('--nproc-per-node') + 1] == '8'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '8', '--steps', '3']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_trainer_helpers_on_cpu_tensors():
+    """SEQTrainer._top1 without the OIM criterion's read-out falls back to the reference's accuracy() (topk / eq /
+    sum, eva_functions.py:118-131), and with it uses the count; the head fork is a no-op on CPU tensors."""
+    import torch
+    from grl_amd.reid.train.trainer import SEQTrainer, _HeadFork
+    from grl_amd.reid.evaluator import accuracy
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(12, 7, generator=g)
+    y = torch.randint(0, 7, (12,), generator=g)
+    want = accuracy(logits, y)[0]
+    assert float(SEQTrainer._top1(logits, y)) == float(want)
+    logits.grl_top1 = (torch.tensor(5.0), 12)                     # what grl_amd.reid.loss.oim attaches
+    assert abs(float(SEQTrainer._top1(logits, y)) - 5.0 / 12) < 1e-7
+    fk = _HeadFork(logits)
+    assert fk.on is False
+    with fk:
+        z = logits + 1
+    fk.join()
+    assert torch.equal(z, logits + 1)

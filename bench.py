@@ -23,6 +23,7 @@ import io
 import json
 import os
 import sys
+import threading
 import time
 
 # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC); set before HIP initialises
@@ -505,9 +506,8 @@ def main():
     dt = max_over_ranks(dist, dev, time.perf_counter() - t0)
     assert bool(torch.isfinite(feat).all())
     train = None
-    if not args.no_train_block and (B, T, args.math) == (32, 4, 'f32'):
-        train = train_block(dev, rank, world, dist, backend)          # every rank: the step has collectives
-
+    want_train = not args.no_train_block and (B, T, args.math) == (32, 4, 'f32')
+    out, guard, done = None, None, []
     if rank == 0:
         n = max(world, 1)
         value = n * B * args.steps / dt
@@ -555,6 +555,27 @@ def main():
             out["dist_backend"] = dist.get_backend()
             out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == 'nccl' else None
             out["world_size"] = dist.get_world_size()
+    if want_train:
+        # Every rank: the training step has collectives (RCCL gradient all-reduce at N > 1).  The headline line must
+        # not depend on them: at N > 1 a watchdog prints it without the block if the block has not come back in time.
+        if world > 1:
+            limit = float(os.environ.get('GRL_BENCH_TRAIN_TIMEOUT', '300'))
+
+            def give_up():
+                if rank == 0 and not done:
+                    out["train"] = {"error": "train block (RCCL all-reduce step) did not finish within %.0f s" % limit}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            guard = threading.Timer(limit, give_up)
+            guard.daemon = True
+            guard.start()
+        try:
+            train = train_block(dev, rank, world, dist, backend)
+        except Exception as e:                                          # (the other ranks then run into the watchdog)
+            if world == 1:
+                raise
+            train = {"error": repr(e)[:300]}
+    if rank == 0:
         if train is not None:
             out["train"] = train
         if n == 1 and not args.no_alt:
@@ -600,10 +621,13 @@ def main():
             out["secondary"] = secondary_block(dev, cnn, siam, args.steps)
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        done.append(True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if guard is not None:
+        guard.cancel()
 
 
 if __name__ == '__main__':

@@ -508,9 +508,11 @@ def bn_apply(z, st, res, y, M, Cc, relu, bits=None):
           1 if relu else 0, ptr(bits))
 
 
-def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None, pivot=None):
+def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, rv=None, pivot=None, out=None):
+    """``out``: four length-Cc vectors (mean, invstd, scale, shift) to write instead of a fresh buffer -- e.g. one
+    half of a concatenated pair, so that no copy follows."""
     st = _BNState()
-    buf = torch.empty((4, Cc), dtype=torch.float32, device=dev)
+    buf = torch.empty((4, Cc), dtype=torch.float32, device=dev) if out is None else out
     st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
     gamma = bn.weight if gamma is None else gamma
     beta = bn.bias if beta is None else beta
@@ -1234,18 +1236,17 @@ def attn_train(tp, siam, x, b, t):
     z = _new((M, 2 * D), x)
     gemm(x, wqk, z, M, 2 * D, Cc, shift=bqk)
     rows = _lib.load().grl_col_stats_rows(M)
-    sts = []
+    # the two BatchNorms (featQ_bn | featK_bn) finalize straight into the halves of one (4, 2D) block: the apply and
+    # the backward below run over all 2D channels at once
+    cat4 = _new((4, 2 * D), x)
     both = _BNState()
-    both.mean, both.scale, both.beta = _new((2 * D,), x), _new((2 * D,), x), _new((2 * D,), x)
+    both.mean, both.invstd, both.scale = cat4[0], cat4[1], cat4[2]
+    both.beta = torch.cat((siam.featQ_bn.bias.detach(), siam.featK_bn.bias.detach()))
     for h, bn in enumerate((siam.featQ_bn, siam.featK_bn)):
         slab = _new((rows, 2, D), x)
         zh = z[:, h * D:]
         _call('grl_col_stats', ptr(zh), ptr(slab), M, D, 2 * D, ptr(zh))
-        st = bn_finalize(slab, rows, D, M, bn, tp.dev, pivot=zh)
-        both.mean[h * D:(h + 1) * D] = st.mean
-        both.scale[h * D:(h + 1) * D] = st.scale
-        both.beta[h * D:(h + 1) * D] = bn.bias.detach()
-        sts.append(st)
+        bn_finalize(slab, rows, D, M, bn, tp.dev, pivot=zh, out=cat4[:, h * D:(h + 1) * D])
     qk = _new((M, 2 * D), x)
     bn_apply(z, both, None, qk, M, 2 * D, False)
     out = _new((b, Cc), x)
@@ -1264,13 +1265,9 @@ def attn_train(tp, siam, x, b, t):
             acc = 0
         _call('grl_siamese_attn_bwd', ptr(qk), ptr(x), ptr(out), Cc, ptr(dout), Cc, ptr(dqk), ptr(cur), acc,
               b, t, D, Cc)
-        mean = torch.cat((sts[0].mean, sts[1].mean)).contiguous()
-        invstd = torch.cat((sts[0].invstd, sts[1].invstd)).contiguous()
-        gamma = torch.cat((siam.featQ_bn.weight.detach(), siam.featK_bn.weight.detach())).contiguous()
-        st = _BNState()
-        st.mean, st.invstd = mean, invstd
+        gamma = torch.cat((siam.featQ_bn.weight.detach(), siam.featK_bn.weight.detach()))
         dg, db = torch.zeros(2 * D, device=tp.dev), torch.zeros(2 * D, device=tp.dev)
-        dz = bn_backward(dqk, z, None, st, gamma, dg, db, M, 2 * D)
+        dz = bn_backward(dqk, z, None, both, gamma, dg, db, M, 2 * D)
         tp.pgrad(siam.featQ_bn.weight).add_(dg[:D]); tp.pgrad(siam.featK_bn.weight).add_(dg[D:])
         tp.pgrad(siam.featQ_bn.bias).add_(db[:D]); tp.pgrad(siam.featK_bn.bias).add_(db[D:])
         dbias = torch.zeros(2 * D, device=tp.dev)

@@ -456,3 +456,44 @@ def test_oim_top1_read_out_equals_reference_accuracy():
     got = SEQTrainer._top1(logits, y)
     assert float(got) == float(want), (float(got), float(want))
     assert 0.0 < float(got) < 1.0
+
+
+@pytest.mark.parametrize('M,N,K,conv', [(262144, 256, 64, None), (65536, 512, 128, None), (65536 + 64, 256, 64, None),
+                                        (65536 + 40, 256, 128, None), (65536, 1024, 256, None), (65536, 512, 512, None),
+                                        (65536 + 72, 512, 256, None),
+                                        (8 * 64 * 32, 256, 9 * 32, (64, 32, 32, 64, 32, 3, 3, 1, 1))])
+def test_statistics_gemm_on_the_wide_tile_keeps_the_small_tiles_bits(M, N, K, conv):
+    """The train-forward statistics GEMMs run on the 128 x 128 tile with their partial sums formed in the order of the
+    tile the rule used before (64 x 64: one slab row per 64 rows; 128 x 64): outputs AND statistics slabs bit for bit
+    those of GRL_GEMM_WIDE_STATS=0, including row counts that are not a multiple of 64 / 128 -- so no parity fixture
+    can move (any other summation order re-rolls the ReLU flips at B = 4)."""
+    import os
+    from grl_amd import engine
+    dev = torch.device('cuda:0')
+    g = torch.Generator(dev).manual_seed(M + N + K)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+    a = torch.randn(rows_in, cin, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.1
+    res = {}
+    was = os.environ.get('GRL_GEMM_WIDE_STATS')
+    try:
+        for mode in ('0', '1'):
+            os.environ['GRL_GEMM_WIDE_STATS'] = mode
+            y = torch.empty(M, N, device=dev)
+            _, slab = engine.gemm(a, w, y, M, N, K, stats=True, kblock=True, conv=conv)
+            torch.cuda.synchronize()
+            res[mode] = (y, slab.clone())
+    finally:
+        if was is None:
+            os.environ.pop('GRL_GEMM_WIDE_STATS', None)
+        else:
+            os.environ['GRL_GEMM_WIDE_STATS'] = was
+    assert res['0'][1].shape == res['1'][1].shape
+    assert torch.equal(res['0'][0], res['1'][0])
+    assert torch.equal(res['0'][1], res['1'][1])
+    ref = a.double() @ w.double().t() if conv is None else None
+    if ref is not None:
+        s = res['1'][1].double().sum(0)
+        assert float((s[0] - ref.sum(0)).norm() / ref.sum(0).norm()) < 1e-5
+        assert float((s[1] - (ref * ref).sum(0)).norm() / (ref * ref).sum(0).norm()) < 1e-5

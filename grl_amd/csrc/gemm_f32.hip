@@ -963,7 +963,9 @@ TileChoice legacy_tile(const GrlGemm& d) {
     // them to the wide tile with the small tile's summation order instead.
     static const bool wide_on = [] { const char* e = getenv("GRL_GEMM_WIDE"); return !e || atoi(e) != 0; }();
     static const bool wide3_on = [] { const char* e = getenv("GRL_GEMM_WIDE3"); return !e || atoi(e) != 0; }();   // split-bf16 / bf16 products too
-    if (wide_on && !d.stats && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
+    // (the data-gradient GEMMs that carry a BatchNorm-backward reduce -- stats + bn_z -- take it too: their column sums
+    // feed gradients, not ReLU masks, so their association is free; split-bf16 products: mixed 43.4 -> 43.05 ms, fp32 +-0)
+    if (wide_on && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
         tiles(128, 128) >= 256 && !(d.res && d.K <= 128))
         return {128, 128};
     if (d.K <= 128) return {64, 64};
@@ -994,7 +996,7 @@ TileChoice choose_tile(const GrlGemm& d) {
         !vec_epilogue_ok(d) || ((uintptr_t)d.stats & 15) != 0)
         return t;
     const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128);
-    if (tiles128 < 448) return t;
+    if (tiles128 < 448) return t;                    // (>= 256: measured, no gain)
     if (t.bm == 64 && t.bn == 64) return {128, 128, 1};
     if (t.bm == 128 && t.bn == 64) return {128, 128, 2};
     return t;

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                 return;
             }
         }
-        if constexpr (MATH == 0 && BM == 128 && BN == 128) {
+        if constexpr (MATH != 2 && BM == 128 && BN == 128) {
             // Statistics partials in the order of a SMALLER tile (vec_epi bits 1..2, host: choose_tile): the train-forward
             // statistics GEMMs run on this tile for its speed, but any change of the partial sums' association re-rolls
             // which near-zero pre-activations flip in the parity fixtures, so the sums are formed exactly as
@@ -983,7 +983,7 @@ bool vec_epilogue_ok(const GrlGemm& d) {
            al16(d.shift) && al16(d.gbias) && al16(d.cnorm);
 }
 
-// The tile a launch runs on.  The train-forward statistics GEMMs (fp32) that the rule above keeps on 64 x 64 / 128 x 64
+// The tile a launch runs on.  The train-forward statistics GEMMs (fp32 storage: exact and split-bf16 products) that the rule above keeps on 64 x 64 / 128 x 64
 // tiles for their statistics' sake take the 128 x 128 tile too wherever it fills the chip -- with the partial sums formed
 // in the smaller tile's order (TileChoice.smode -> the kernel's statistics epilogue), so outputs AND statistics slabs are
 // bit for bit the smaller tile's (tested), and the slab keeps the smaller tile's row count.  GRL_GEMM_WIDE_STATS=0: off.
@@ -992,7 +992,7 @@ TileChoice choose_tile(const GrlGemm& d) {
     const char* const ws_env = getenv("GRL_GEMM_WIDE_STATS");             // (read per call: the parity test toggles it)
     const bool wide_stats = !ws_env || atoi(ws_env) != 0;
     static const bool forced = getenv("GRL_GEMM_TILE") != nullptr;
-    if (!wide_stats || forced || !d.stats || d.bn_z || d.math != GRL_MATH_F32 || d.epilogue != GRL_EPI_AFFINE || d.N < 128 ||
+    if (!wide_stats || forced || !d.stats || d.bn_z || d.math == GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.N < 128 ||
         !vec_epilogue_ok(d) || ((uintptr_t)d.stats & 15) != 0)
         return t;
     const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -1074,8 +1074,8 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
 template <int BM, int BN>
 int launch(const GrlGemm& d, hipStream_t s, int smode = 0) {
     if (d.math == GRL_MATH_BF16S) return launch_math<BM, BN, 2>(d, s, 0);
-    if (d.math == GRL_MATH_BF16X3) return launch_math<BM, BN, 3>(d, s, 0);
-    if (d.math == GRL_MATH_BF16) return launch_math<BM, BN, 1>(d, s, 0);
+    if (d.math == GRL_MATH_BF16X3) return launch_math<BM, BN, 3>(d, s, smode);
+    if (d.math == GRL_MATH_BF16) return launch_math<BM, BN, 1>(d, s, smode);
     return launch_math<BM, BN, 0>(d, s, smode);
 }
 

@@ -983,8 +983,9 @@ bool vec_epilogue_ok(const GrlGemm& d) {
            al16(d.shift) && al16(d.gbias) && al16(d.cnorm);
 }
 
-// The tile a launch runs on.  The train-forward statistics GEMMs (fp32 storage: exact and split-bf16 products) that the rule above keeps on 64 x 64 / 128 x 64
-// tiles for their statistics' sake take the 128 x 128 tile too wherever it fills the chip -- with the partial sums formed
+// The tile a launch runs on.  The train-forward statistics GEMMs (fp32 storage: exact and split-bf16 products) that the
+// rule above keeps on 64 x 64 / 128 x 64 tiles for their statistics' sake take the 128 x 128 tile too wherever it fills
+// the chip (>= 448 tiles) -- with the partial sums formed
 // in the smaller tile's order (TileChoice.smode -> the kernel's statistics epilogue), so outputs AND statistics slabs are
 // bit for bit the smaller tile's (tested), and the slab keeps the smaller tile's row count.  GRL_GEMM_WIDE_STATS=0: off.
 TileChoice choose_tile(const GrlGemm& d) {

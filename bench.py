@@ -330,7 +330,7 @@ def train_bench(args, dev, dist, rank, world, backend):
             "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None,
             "gradsync": {k: v for k, v in r.items() if k not in ("ms_per_step", "clips_per_sec")},
             "end_to_end_tflops": round(r["clips_per_sec"] / n * 173.8 / 1e3, 2)}
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -385,7 +385,7 @@ def distmat_bench(args, dev, rank):
     del dqq, dgg, dqg, rr
     flops = 2.0 * 1980 * 11310 * 6144
     if rank == 0:
-        print(json.dumps({"metric": "distance-matrix ms (1980x11310x6144)", "value": round(dt * 1e3, 3), "unit": "ms",
+        emit(({"metric": "distance-matrix ms (1980x11310x6144)", "value": round(dt * 1e3, 3), "unit": "ms",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
                           "higher_is_better": False, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "cosin_dist at MARS size, BASELINE configs[4]",
@@ -416,6 +416,26 @@ def launch_ranks(n, argv):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
+
+
+_REAL_STDOUT = [None]
+
+
+def quiet_stdout():
+    """From here on file descriptor 1 is the process's stderr: RCCL prints a version banner on stdout when a communicator
+    comes up (seen: five lines before the result), and the contract is ONE JSON line there.  `emit` writes to the real one."""
+    if _REAL_STDOUT[0] is None:
+        sys.stdout.flush()
+        _REAL_STDOUT[0] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + '\n').encode()
+    if _REAL_STDOUT[0] is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT[0], line)
 
 
 def main():
@@ -459,6 +479,7 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "world_size": int(n.item()), "n_gpus": args.gpus}))
         return
+    quiet_stdout()
     dist = None
     # GRL_DIST_BACKEND=gloo + GRL_SINGLE_DEVICE=1: functional test of the N>1 path on a box with
     # one GPU (every rank on cuda:0, collectives through gloo); the real runs use nccl = RCCL.
@@ -564,7 +585,7 @@ def main():
             def give_up():
                 if rank == 0 and not done:
                     out["train"] = {"error": "train block (RCCL all-reduce step) did not finish within %.0f s" % limit}
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 os._exit(0)
             guard = threading.Timer(limit, give_up)
             guard.daemon = True
@@ -621,7 +642,7 @@ def main():
             out["secondary"] = secondary_block(dev, cnn, siam, args.steps)
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
-        print(json.dumps(out), flush=True)
+        emit(out)
         done.append(True)
     if dist is not None:
         dist.barrier()

@@ -18,7 +18,7 @@ if os.environ.get('GRL_TILE_AB_CHILD'):
     mk = lambda: (torch.randn(M, K, device=dev).to(dt), (torch.randn(N, K, device=dev) * 0.05).to(dt), torch.empty(M, N, device=dev, dtype=dt))
     a, w, y = mk(); a2, w2, y2 = mk()
     sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
-    m = engine.MATH_BF16S if math == 'bf16s' else engine.MATH_F32
+    m = {'bf16s': engine.MATH_BF16S, 'bf16x3': engine.MATH_BF16X3}.get(math, engine.MATH_F32)     # (bf16x3: the `mixed` backward's datapath)
     s2 = torch.cuda.Stream()
     kw = dict(stats=True) if stats else dict(scale=sc, shift=sh, relu=True)
     if with_res:

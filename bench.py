@@ -37,6 +37,13 @@ sys.path.insert(0, ROOT)
 B, T = 32, 4
 GFLOP_PER_FRAME = 14.485                # conv+linear forward, per frame (57.94 per clip at T=4)
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline figure is 2:1 sparse)
+TRAIN_FLOP_FACTOR = 3.0                 # one train step = 3 x the forward's conv + linear FLOPs
+# peak of the datapath that carries the series' GEMMs ('mixed': exact fp32 forward = a third of the FLOPs at the fp32
+# peak, two thirds on split-bf16 products at 2500/3: the time-weighted harmonic peak)
+SERIES_PEAK = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': PEAK_BF16_MFMA_TFLOPS, 'bf16s': PEAK_BF16_MFMA_TFLOPS,
+               'bf16x3': PEAK_BF16_MFMA_TFLOPS / 3,
+               'mixed': 3.0 / (1.0 / PEAK_FP32_MFMA_TFLOPS + 2.0 / (PEAK_BF16_MFMA_TFLOPS / 3))}
 
 
 def max_over_ranks(dist, dev, seconds):
@@ -106,6 +113,87 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     return flops, ms, launches
 
 
+def series_roofline(math, clips, frames_per_clip, ms_per_step, train=False, kernel=None):
+    """`roofline` object of a secondary series: achieved = ALGORITHMIC FLOPs of one step (14.485 GFLOP
+    per frame forward, x 3 for a train step) / the step's measured wall time, against the dense MFMA peak of the
+    datapath; `kernel` = the dominant kernel family of that step timed live with HIP events (one stream)."""
+    gflop = clips * frames_per_clip * GFLOP_PER_FRAME * (TRAIN_FLOP_FACTOR if train else 1.0)
+    achieved = gflop / ms_per_step          # GFLOP / ms = TFLOP/s
+    peak = SERIES_PEAK[math]
+    r = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(achieved / peak, 4), "algorithmic_gflop_per_step": round(gflop, 1), "traffic": None}
+    if kernel is not None:
+        r["kernel"] = kernel
+    return r
+
+
+def eval_kernel_timing(cnn, siam, clips, math):
+    """Dominant-kernel record of an eval series: every GEMM launch (engine.gemm) of one step, HIP events."""
+    from grl_amd import engine
+    with engine.math_mode(math):
+        flops, ms, launches = gemm_roofline(cnn, siam, clips)
+    return {"name": "gemm_bf16_256_kernel / gemm_f32_kernel<.., bf16 storage> (implicit-GEMM conv + linear)" if math == 'bf16s'
+            else "gemm_f32_kernel", "launches_per_step": launches, "ms_per_step": round(ms, 3),
+            "gflop_per_step": round(flops / 1e9, 1), "tflops": round(flops / ms / 1e9, 1),
+            "frac_of_peak": round(flops / ms / 1e9 / SERIES_PEAK[math], 4)}
+
+
+def train_kernel_timing(tr, clips, pids, math, iters=2):
+    """Dominant-kernel record of a train series: every forward / data-gradient GEMM (engine.gemm) and every weight
+    gradient (train_engine.wgrad) launch of one step, HIP events, with the weight-gradient and TRL side streams off so
+    that a launch's two events bracket that launch alone.  Outside any timed region."""
+    from grl_amd import engine, train_engine as TE
+    recs = []
+    og, ow = engine.gemm, TE.wgrad
+
+    def tg(a, w, y, M, N, K, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = og(a, w, y, M, N, K, *args, **kw); e1.record()
+        recs.append(('gemm', 2.0 * M * N * K, e0, e1))
+        return r
+
+    def tw(dz, x, dw, M, N, K, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = ow(dz, x, dw, M, N, K, *args, **kw); e1.record()
+        recs.append(('wgrad', 2.0 * M * N * K, e0, e1))
+        return r
+
+    def one():
+        loss, _, _, _ = tr._forward([clips], pids, 0, 0)
+        for p in tr._all_params():
+            p.grad = None
+        loss.backward()
+
+    saved = (engine.TRL_STREAMS, TE.WGRAD_STREAM)
+    engine.TRL_STREAMS, TE.WGRAD_STREAM = False, False
+    old = TE.set_math(math)
+    try:
+        one()                                   # untimed: allocator settles on one stream
+        torch.cuda.synchronize()
+        engine.gemm, TE.wgrad = tg, tw
+        for _ in range(iters):
+            one()
+        torch.cuda.synchronize()
+    finally:
+        engine.gemm, TE.wgrad = og, ow
+        engine.TRL_STREAMS, TE.WGRAD_STREAM = saved
+        TE.set_math(old)
+    out = {}
+    for kind in ('gemm', 'wgrad'):
+        sel = [r for r in recs if r[0] == kind]
+        ms = sum(r[2].elapsed_time(r[3]) for r in sel) / iters
+        fl = sum(r[1] for r in sel) / iters
+        out[kind] = {"launches_per_step": len(sel) // iters, "ms_per_step": round(ms, 3),
+                     "gflop_per_step": round(fl / 1e9, 1), "tflops": round(fl / max(ms, 1e-9) / 1e9, 1)}
+    tot_ms = out['gemm']['ms_per_step'] + out['wgrad']['ms_per_step']
+    tot_fl = out['gemm']['gflop_per_step'] + out['wgrad']['gflop_per_step']
+    return {"name": "forward + data-gradient GEMMs (gemm_f32_kernel / gemm_bf16_256_kernel) and weight gradients "
+                    "(wgrad_kernel / wgrad_b16in*), one stream",
+            "forward_and_dgrad": out['gemm'], "wgrad": out['wgrad'], "ms_per_step": round(tot_ms, 3),
+            "tflops": round(tot_fl / max(tot_ms, 1e-9), 1),
+            "frac_of_peak": round(tot_fl / max(tot_ms, 1e-9) / SERIES_PEAK[math], 4)}
+
+
 def cpu_baseline(sd, ssd):
     """The oracle (plain PyTorch-CPU restatement of the reference path) timed on this
     node's host cores on a bounded sample of the same workload."""
@@ -129,7 +217,8 @@ def cpu_baseline(sd, ssd):
                       "step, T=%d, %d timed passes (%.1f s)" % (cores, os.cpu_count() or 0, nb, T, passes, dt)}
 
 
-def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default', graph=False):
+def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default', graph=False,
+                 roofline=False):
     """One SEQTrainer step (forward + 5-term loss + HIP backward + bucketed gradient all-reduce when a process
     group is up + SGD) on b x t synthetic pair-interleaved clips per rank.  Timed with a barrier + device sync on
     both sides, MAX over ranks.  Returns a dict (ms_per_step, and the gradient-sync bookkeeping)."""
@@ -159,8 +248,9 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
     clips = synth_clips(b, t, seed=rank).to(dev)
     pids = (torch.arange(b, device=dev) // 2 * 7 + rank * 131) % 625
     sync = grl_dist.GradSync(params) if grl_dist.is_distributed() else None   # (GRL_SYNC_FORCE=1: also in a world of one)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    exposed = []
+    waits = []                     # per timed step: [(bucket label, event, event)] -- read AFTER the timed region
+    if sync is not None:
+        sync.timing = True
 
     def barrier():
         if dist is not None:
@@ -174,11 +264,9 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
             sync.begin()
         loss.backward()
         if sync is not None:
-            e0.record()
-            sync.finish()              # the launch stream waits here for whatever the backward did not cover
-            e1.record()
-            exposed.append((e0, e1))
-        opt.step()
+            sync.finish()              # the launch stream waits here for whatever the backward did not cover;
+            waits.append(sync._waits)  # HIP events around every bucket's wait -- nothing blocks the host (N = 1 and
+        opt.step()                     # N > 1 steps keep the same host run-ahead: one measurement regime)
         return loss
 
     old = train_engine.set_math(math)
@@ -193,13 +281,10 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
         for _ in range(warmup):
             loss = step()
         barrier()
-        del exposed[:]
+        del waits[:]
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
-            if exposed:                # (events are re-used: read them before the next step re-records)
-                torch.cuda.current_stream().synchronize()
-                exposed[-1] = exposed[-1][0].elapsed_time(exposed[-1][1])
         barrier()
         dt = time.perf_counter() - t0
         assert bool(torch.isfinite(loss).all())
@@ -208,17 +293,33 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
     dt = max_over_ranks(dist, dev, dt)
     ms = dt / steps * 1e3
     out = {"ms_per_step": round(ms, 2), "clips_per_sec": round(max(world, 1) * b / ms * 1e3, 1)}
+    if roofline:
+        # per GPU: algorithmic FLOPs of this rank's step / the step time; the dominant kernels timed live (N = 1 only:
+        # the timing pass runs extra steps, which at N > 1 would have to stay in lockstep over the collectives)
+        kern = train_kernel_timing(tr, clips, pids, math) if (sync is None and not graph) else None
+        out["roofline"] = series_roofline(math, b, t, ms, train=True, kernel=kern)
     if sync is not None:
+        per_bucket = {}
+        for w in waits:                                             # (the final barrier synchronised the device)
+            for lab, a, b2 in w:
+                per_bucket.setdefault(lab, []).append(a.elapsed_time(b2))
+        exposed = [[lab, round(sum(v) / len(v), 3)] for lab, v in per_bucket.items()]
         out.update({"allreduce_bytes_per_step": 4 * sum(n for _, n in sync.launched),
                     "allreduce_buckets": [[lab, 4 * n] for lab, n in sync.launched],
                     "gradsync_collectives_per_step": sync.collectives, "stray_reductions": sync.stray,
-                    "allreduce_exposed_ms": round(sum(exposed) / max(len(exposed), 1), 3),
+                    "allreduce_exposed_ms": round(sum(v for _, v in exposed), 3),
+                    "allreduce_exposed_ms_per_bucket": exposed,
                     "reduce_op": "AVG in the collective" if sync.avg_op else "SUM + scale pass"})
     return out
 
 
 def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4, graph=False):
     return train_series(dev, math, steps, warmup, b, t, graph=graph)["ms_per_step"]
+
+
+def train_step_record(dev, math, steps=6, warmup=3, b=32, t=4):
+    r = train_series(dev, math, steps, warmup, b, t, roofline=True)
+    return {"ms_per_step": r["ms_per_step"], "clips_per_sec": r["clips_per_sec"], "roofline": r["roofline"]}
 
 
 def train_block(dev, rank, world, dist, backend):
@@ -228,11 +329,20 @@ def train_block(dev, rank, world, dist, backend):
     out = {"workload": "BASELINE configs[3] per GPU: SEQTrainer step (fwd + 5-term loss + HIP bwd + bucketed "
                        "gradient all-reduce + SGD), 64 clips x 4 frames per GPU, global batch %d clips" % (64 * max(world, 1)),
            "n_gpus": max(world, 1), "dist_backend": backend if dist is not None else None,
-           "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None}
+           "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None,
+           "rccl_version": rccl_version()}
     for m in ('f32', 'mixed'):
         release_cached_blocks()
-        out[m] = train_series(dev, m, steps=5, warmup=2, b=64, t=4, rank=rank, world=world, dist=dist)
+        out[m] = train_series(dev, m, steps=5, warmup=2, b=64, t=4, rank=rank, world=world, dist=dist, roofline=True)
     return out
+
+
+def rccl_version():
+    """The RCCL build torch is linked against (torch.cuda.nccl.version() IS RCCL's on ROCm), e.g. '2.26.6'."""
+    try:
+        return '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:                                   # noqa: BLE001
+        return None
 
 
 def release_cached_blocks():
@@ -265,22 +375,21 @@ def secondary_block(dev, cnn, siam, steps):
             engine.extract_features(cnn, siam, c3)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-    out["configs[2] bf16s, 64 clips x 8 frames"] = {"clip_features_per_sec": round(64 / ms * 1e3, 1), "ms_per_step": round(ms, 3),
-                                                     "frames_per_sec": round(512 / ms * 1e3)}
+    out["configs[2] bf16s, 64 clips x 8 frames"] = {
+        "clip_features_per_sec": round(64 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "frames_per_sec": round(512 / ms * 1e3),
+        "roofline": series_roofline('bf16s', 64, 8, ms, kernel=eval_kernel_timing(cnn, siam, c3, 'bf16s'))}
     del c3
 
     def fresh(m, **kw):
         release_cached_blocks()
-        return train_step_ms(dev, m, **kw)
-    out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {
-        m: {"ms_per_step": round(v, 2), "clips_per_sec": round(32 / v * 1e3, 1)}
-        for m, v in ((m, fresh(m)) for m in ('f32', 'mixed', 'bf16x3', 'bf16s'))}
-    # (`--mode train --graph` replays the same step from a HIP graph -- grl_amd.train_graph, bit-identical; measured 4 %
-    # SLOWER than the eager step in every mode on this stack, DESIGN.md 4c, so it is not part of the default line)
+        return train_step_record(dev, m, **kw)
+    out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {m: fresh(m) for m in ('f32', 'mixed', 'bf16x3', 'bf16s')}
+    # (`--mode train --graph` replays the same step from a HIP graph -- grl_amd.train_graph, bit-identical; measured
+    # slower than the eager step on this stack, EXPERIMENTS.md, so it is not part of the default line)
     v = fresh('bf16s', b=64, t=8)
     release_cached_blocks()
-    out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = {
-        "ms_per_step": round(v, 2), "clips_per_sec": round(64 / v * 1e3, 1), "frames_per_sec": round(512 / v * 1e3)}
+    v["frames_per_sec"] = round(512 / v["ms_per_step"] * 1e3)
+    out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = v
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
     qd, gd = qf.to(dev), gf.to(dev)
     for _ in range(2):
@@ -299,7 +408,10 @@ def secondary_block(dev, cnn, siam, steps):
     torch.cuda.synchronize()
     out["configs[4] distance matrix 1980 x 11310 x 6144 (fp32)"] = {
         "ms": round(dms, 3), "tflops": round(2.0 * 1980 * 11310 * 6144 / dms / 1e9, 1),
-        "row_argsort_ms": round((time.perf_counter() - t0) / 3 * 1e3, 3)}
+        "row_argsort_ms": round((time.perf_counter() - t0) / 3 * 1e3, 3),
+        "roofline": {"bound": "mfma", "achieved": round(2.0 * 1980 * 11310 * 6144 / dms / 1e9, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(2.0 * 1980 * 11310 * 6144 / dms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "traffic": None, "kernel": "gemm_f32_kernel<128,128> NEGDOT epilogue, one launch"}}
     return out
 
 
@@ -311,7 +423,7 @@ def train_bench(args, dev, dist, rank, world, backend):
     if args.math not in ('f32', 'mixed', 'bf16x3', 'bf16', 'bf16s'):
         raise SystemExit('--mode train supports --math f32 | mixed | bf16x3 | bf16 | bf16s')
     r = train_series(dev, args.math, steps=args.steps, warmup=args.warmup, b=B, t=T, rank=rank, world=world, dist=dist,
-                     graph=args.graph)
+                     graph=args.graph, roofline=True)
     if rank == 0:
         n = max(world, 1)
         line = {
@@ -328,7 +440,8 @@ def train_bench(args, dev, dist, rank, world, backend):
                        "parallelism": "dp%d (4 gradient buckets all-reduced over RCCL under the backward)" % n},
             "dist_backend": backend if dist is not None else None,
             "rccl_ranks": dist.get_world_size() if (dist is not None and backend == 'nccl') else None,
-            "gradsync": {k: v for k, v in r.items() if k not in ("ms_per_step", "clips_per_sec")},
+            "roofline": r["roofline"],
+            "gradsync": {k: v for k, v in r.items() if k not in ("ms_per_step", "clips_per_sec", "roofline")},
             "end_to_end_tflops": round(r["clips_per_sec"] / n * 173.8 / 1e3, 2)}
         emit(line)
     if dist is not None:
@@ -398,6 +511,93 @@ def distmat_bench(args, dev, rank):
                           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2),
                                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": round(flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}}))
+
+
+EXIT_TRAIN_BLOCK_FAILED = 3
+
+
+class TrainBlockGuard(object):
+    """N > 1: the `train` block is the only part of the line with collectives in it.  The headline must not depend on
+    them, and a hung or failed all-reduce step must be VISIBLE in the launcher's exit code: rank 0 prints the line
+    with `train: {"error": ...}` and every rank then leaves with EXIT_TRAIN_BLOCK_FAILED (never 0, never a re-exec:
+    these processes have touched the GPU; a retry, if any, is a fresh `bench.py --gpus N` from the GPU-less parent).
+
+    The ranks of one node tell each other through two files in the temp directory (keyed by the rendezvous port):
+    `.err` = some rank's block raised or timed out (its text is the reason), `.out` = rank 0 has printed the line.
+    A watchdog thread per rank polls them, so a healthy rank that sits in a collective whose peer has failed leaves
+    within a second instead of waiting for the time limit -- but only after rank 0 has printed."""
+
+    def __init__(self, rank, world, limit, emit_error_line):
+        import tempfile
+        self.rank, self.world, self.limit, self.emit_error_line = rank, world, limit, emit_error_line
+        key = 'grl_bench_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'))
+        self.err = os.path.join(tempfile.gettempdir(), key + '.err')
+        self.out = os.path.join(tempfile.gettempdir(), key + '.out')
+        self.done = threading.Event()
+        self.lock = threading.Lock()
+        self.thread = None
+
+    def start(self):
+        if self.world > 1:
+            if self.rank == 0:
+                for f in (self.err, self.out):
+                    with contextlib.suppress(OSError):
+                        os.remove(f)
+            self.thread = threading.Thread(target=self._watch, daemon=True)
+            self.thread.start()
+
+    def _watch(self):
+        t0 = time.time()
+        while not self.done.wait(0.25):
+            if os.path.exists(self.err):
+                with contextlib.suppress(OSError):
+                    self.leave(open(self.err).read() or 'a rank failed')
+            if time.time() - t0 > self.limit:
+                self.leave("train block (RCCL all-reduce step) did not finish within %.0f s on rank %d" % (self.limit, self.rank))
+
+    def leave(self, reason):
+        """Publish the reason, let rank 0 print the line, exit non-zero.  Called from the watchdog thread (peer
+        failed / time limit) or from the main thread (this rank's block raised)."""
+        with self.lock:
+            if self.done.is_set():
+                return
+            if not os.path.exists(self.err):
+                with contextlib.suppress(OSError):
+                    with open(self.err, 'w') as fh:
+                        fh.write(reason)
+            if self.rank == 0:
+                self.emit_error_line(reason)
+                with contextlib.suppress(OSError):
+                    open(self.out, 'w').close()
+            else:
+                t0 = time.time()
+                while not os.path.exists(self.out) and time.time() - t0 < 20:
+                    time.sleep(0.1)
+            sys.stderr.write('bench.py rank %d: %s -- exit %d\n' % (self.rank, reason, EXIT_TRAIN_BLOCK_FAILED))
+            sys.stderr.flush()
+            os._exit(EXIT_TRAIN_BLOCK_FAILED)
+
+    def finished(self):
+        self.done.set()
+
+
+def run_guarded(guard, world, fn):
+    """fn() under the guard.  world == 1: exceptions propagate (nothing to hang).  world > 1: an exception on this
+    rank drops the step's gradient-sync state WITHOUT issuing a collective (the peers are elsewhere in the sequence),
+    skips every later barrier, and leaves through the guard."""
+    if world == 1:
+        return fn()
+    guard.start()
+    try:
+        r = fn()
+    except BaseException as e:                      # noqa: B902 (SystemExit from an assert helper included)
+        with contextlib.suppress(Exception):
+            from grl_amd import train_engine
+            train_engine.set_grad_sync(None)
+        guard.leave("train block raised on rank %d: %s" % (guard.rank, repr(e)[:300]))
+        raise
+    guard.finished()
+    return r
 
 
 def launch_ranks(n, argv):
@@ -475,9 +675,23 @@ def main():
         if world > 1:
             dist.init_process_group('gloo')
             dist.all_reduce(n)
+        line = {"dry_run": True, "world_size": int(n.item()), "n_gpus": args.gpus}
+        fault = os.environ.get('GRL_BENCH_DRY_TRAIN')        # tests: 'ok' | 'hang' | 'raise' (on rank 1)
+        if fault and world > 1:
+            def fake_train_block():
+                if rank == 1 and fault == 'hang':
+                    time.sleep(3600)
+                if rank == 1 and fault == 'raise':
+                    raise RuntimeError('injected failure')
+                dist.barrier()
+                return {"ok": True}
+            guard = TrainBlockGuard(rank, world, float(os.environ.get('GRL_BENCH_TRAIN_TIMEOUT', '300')),
+                                    lambda reason: print(json.dumps(dict(line, train={"error": reason})), flush=True))
+            line["train"] = run_guarded(guard, world, fake_train_block)
+        if world > 1:
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "world_size": int(n.item()), "n_gpus": args.gpus}))
+            print(json.dumps(line))
         return
     quiet_stdout()
     dist = None
@@ -528,7 +742,7 @@ def main():
     assert bool(torch.isfinite(feat).all())
     train = None
     want_train = not args.no_train_block and (B, T, args.math) == (32, 4, 'f32')
-    out, guard, done = None, None, []
+    out, guard = None, None
     if rank == 0:
         n = max(world, 1)
         value = n * B * args.steps / dt
@@ -538,7 +752,7 @@ def main():
         # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
         peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
         traffic, pmc_name = None, None
-        for pmc_name in ('r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
+        for pmc_name in ('r04_gemm_pmc.json', 'r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
             pmc = os.path.join(ROOT, 'profiles', pmc_name)
             if os.path.isfile(pmc):
                 traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
@@ -578,24 +792,13 @@ def main():
             out["world_size"] = dist.get_world_size()
     if want_train:
         # Every rank: the training step has collectives (RCCL gradient all-reduce at N > 1).  The headline line must
-        # not depend on them: at N > 1 a watchdog prints it without the block if the block has not come back in time.
-        if world > 1:
-            limit = float(os.environ.get('GRL_BENCH_TRAIN_TIMEOUT', '300'))
-
-            def give_up():
-                if rank == 0 and not done:
-                    out["train"] = {"error": "train block (RCCL all-reduce step) did not finish within %.0f s" % limit}
-                    emit(out)
-                os._exit(0)
-            guard = threading.Timer(limit, give_up)
-            guard.daemon = True
-            guard.start()
-        try:
-            train = train_block(dev, rank, world, dist, backend)
-        except Exception as e:                                          # (the other ranks then run into the watchdog)
-            if world == 1:
-                raise
-            train = {"error": repr(e)[:300]}
+        # not depend on them: at N > 1 a guard prints it with `train: {"error"}` if the block hangs or raises on any
+        # rank -- and every rank then exits NON-ZERO, so the launcher's return code is red (TrainBlockGuard).
+        def error_line(reason):
+            out["train"] = {"error": reason}
+            emit(out)
+        guard = TrainBlockGuard(rank, world, float(os.environ.get('GRL_BENCH_TRAIN_TIMEOUT', '300')), error_line)
+        train = run_guarded(guard, world, lambda: train_block(dev, rank, world, dist, backend))
     if rank == 0:
         if train is not None:
             out["train"] = train
@@ -643,12 +846,9 @@ def main():
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ssd)
         emit(out)
-        done.append(True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if guard is not None:
-        guard.cancel()
 
 
 if __name__ == '__main__':

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
 
-ABI_VERSION = 5       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+ABI_VERSION = 6       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
@@ -38,6 +38,11 @@ class GrlWgrad(C.Structure):
     _fields_ = [(n, _fp) for n in ('dz', 'x', 'dw', 'workspace')] + \
                [(n, _i32) for n in ('M', 'N', 'K', 'ldz', 'ldx', 'k_out', 'accumulate', 'conv', 'H', 'W',
                                     'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math', 'in_bf16')]
+
+
+class GrlBneckTail(C.Structure):
+    _fields_ = [(n, _fp) for n in ('t2', 'w3', 'scale3', 'shift3', 'res', 'y', 'w1n', 'scale1n', 'shift1n', 'u')] + \
+               [(n, _i32) for n in ('M', 'P', 'C4', 'Pn')]
 
 
 class GrlPrepEntry(C.Structure):
@@ -151,6 +156,10 @@ _SIGNATURES = {
     'grl_sqdiff_bwd_bf16': ([_fp] * 5 + [C.c_int, C.c_int, C.c_int, _i64, C.c_int, _fp], C.c_int),
     'grl_cast_f32': ([_fp, _fp, _i64, _fp], C.c_int),
     'grl_weight_prep': ([_fp, C.c_int, _fp], C.c_int),
+    # cross-layer fusion (fuse_bf16.hip)
+    'grl_bottleneck_tail_bf16': ([C.POINTER(GrlBneckTail), _fp], C.c_int),
+    'grl_bottleneck_tail_bf16_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
+    'grl_bneck_perm32': ([_fp, C.c_int, _fp, C.c_int, C.c_int, _fp], C.c_int),
 }
 
 _lib = None

@@ -215,11 +215,13 @@ __global__ void bn_apply_centered_kernel(const float* __restrict__ z, const floa
 // (the largest tensors of the step; one lane group per row left 48 of 64 lanes idle there).
 // Fixed summation order: per lane over its rows, then across the lane groups of the wave
 // (xor-shuffles), then the four waves through LDS.
+// dy and gout carry NO __restrict__: in the in-place form (grl_bn_bwd with gres == dy) they are the same buffer -- every
+// lane reads its element before it writes it.
 template <int LPR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ act,
+    const float* dy, const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab,
-    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta, float* __restrict__ gout,
+    int M, int C, const float* __restrict__ mscale, const float* __restrict__ mbeta, float* gout,
     const uint8_t* __restrict__ bits) {
     constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
     __shared__ f32x4 red[2][4][LPR];

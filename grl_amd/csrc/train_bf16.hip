@@ -133,10 +133,11 @@ __global__ __launch_bounds__(256) void col_stats_b16_kernel(const __bf16* __rest
 
 // BN backward pass 1: g = dy * mask ; slab[chunk][0][c] = sum g, [1][c] = sum g * xhat.  mask = (act > 0), or
 // recomputed from z with the forward's own (z - mean) * mscale + mbeta (y = relu(bn(z)) without a residual), or none.
+// (dy and gout carry no __restrict__: the in-place form passes the same buffer for both)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_b16_kernel(
-    const __bf16* __restrict__ dy, const __bf16* __restrict__ z, const __bf16* __restrict__ act,
+    const __bf16* dy, const __bf16* __restrict__ z, const __bf16* __restrict__ act,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ slab, int M, int C,
-    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR, __bf16* __restrict__ gout,
+    const float* __restrict__ mscale, const float* __restrict__ mbeta, int LPR, __bf16* gout,
     const uint8_t* __restrict__ bits) {
     __shared__ f32x8 red[2][256];
     const int chunk = blockIdx.y, sub = threadIdx.x % LPR, part = threadIdx.x / LPR, parts = 256 / LPR;

@@ -129,17 +129,30 @@ class _RankBatchSampler(object):
 def shard_loader_batches(loader, rank=None, world=None):
     """Iterable over batches ``rank, rank + world, ...`` of ``loader`` (evaluation: batch i belongs to rank
     i % world).  A torch DataLoader is re-built around a rank-filtered batch sampler -- same dataset, workers,
-    collate function -- so a rank's host side loads 1/world of the data; any other iterable is filtered."""
+    collate function, generator, multiprocessing context, pin-memory device -- so a rank's host side loads
+    1/world of the data; any other iterable is filtered.
+
+    "Batch i % world" partitions the data only if every rank enumerates the SAME batch list.  A sequential sampler
+    does; a shuffling one (RandomSampler, a weighted sampler) draws its own permutation per process unless all
+    ranks share a seeded generator -- such loaders are NOT re-built: their OUTPUT is filtered instead (every rank
+    then decodes every batch, but no clip is duplicated or lost only if the caller seeds them identically, which
+    is the caller's contract either way)."""
     rank, world = _rank_world(rank, world)
     if world == 1:
         return loader
     bs = getattr(loader, 'batch_sampler', None)
-    if isinstance(loader, torch.utils.data.DataLoader) and bs is not None:
+    sequential = isinstance(getattr(bs, 'sampler', None), torch.utils.data.SequentialSampler)
+    if isinstance(loader, torch.utils.data.DataLoader) and bs is not None and sequential:
         kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
-                  timeout=loader.timeout, worker_init_fn=loader.worker_init_fn)
+                  timeout=loader.timeout, worker_init_fn=loader.worker_init_fn, generator=loader.generator,
+                  multiprocessing_context=loader.multiprocessing_context if loader.num_workers > 0 else None,
+                  pin_memory_device=getattr(loader, 'pin_memory_device', ''))
         if loader.num_workers > 0:
             kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
-        return torch.utils.data.DataLoader(loader.dataset, batch_sampler=_RankBatchSampler(bs, rank, world), **kw)
+        mine = _RankBatchSampler(bs, rank, world)
+        out = torch.utils.data.DataLoader(loader.dataset, batch_sampler=mine, **kw)
+        assert len(out) == len(mine) == len(range(rank, len(bs), world))
+        return out
     return (b for i, b in enumerate(loader) if i % world == rank)
 
 
@@ -321,7 +334,9 @@ class GradSync(object):
         # RCCL call sequence (async all-reduce of flat-buffer slices under the backward) on a single-GPU box
         self.force = os.environ.get('GRL_SYNC_FORCE') == '1' and dist.is_available() and dist.is_initialized()
         self.avg_op = (self.world > 1 or self.force) and dist.get_backend(group) == 'nccl'
-        self._works = []          # (work, flat slice)
+        self._works = []          # (work, flat slice, label)
+        self.timing = False       # bench.py: HIP events around every bucket's wait in finish() -> exposed_ms()
+        self._waits = []          # (label, event before the wait, event after it) of the last finish()
         self._owned = []          # (param, flat, offset) of every tape-owned gradient of this step
         self._checked = False
         self.launched = []        # (label, numel) per collective of the last step (tests / logging)
@@ -346,10 +361,10 @@ class GradSync(object):
             return
         self.collectives += 1
         if _host_staged(piece, self.group):
-            self._works.append((_HostWork(piece, self.group), piece))
+            self._works.append((_HostWork(piece, self.group), piece, label))
         else:
             op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
-            self._works.append((dist.all_reduce(piece, op=op, group=self.group, async_op=True), piece))
+            self._works.append((dist.all_reduce(piece, op=op, group=self.group, async_op=True), piece, label))
 
     def abort(self):
         """Error path (the backward raised on this rank): forget the step WITHOUT issuing any collective -- the
@@ -358,12 +373,26 @@ class GradSync(object):
         train_engine.set_grad_sync(None)
         self._works, self._owned = [], []
 
+    def exposed_ms(self):
+        """[(bucket label, ms the launch stream waited for that bucket in the last finish())] -- what the backward
+        did not cover.  Needs ``timing = True``; call it after the stream has been synchronised (bench.py reads it
+        after the timed region: nothing here blocks the host inside a step)."""
+        return [(lab, e0.elapsed_time(e1)) for lab, e0, e1 in self._waits]
+
     def finish(self):
         from . import train_engine
         train_engine.set_grad_sync(None)
         inv = 1.0 / self.world
-        for work, piece in self._works:
+        self._waits = []
+        for work, piece, label in self._works:
+            timed = self.timing and piece.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             work.wait()
+            if timed:
+                e1.record()
+                self._waits.append((label, e0, e1))
             if not self.avg_op:
                 piece.mul_(inv)
         self._works = []
@@ -395,38 +424,3 @@ class GradSync(object):
                 raise RuntimeError('GradSync: the set of parameters that receive gradients differs across ranks')
             self._checked = True
         self._owned = []
-
-
-class GradBucket(object):
-    """NOT on the GRL path (SEQTrainer and bench.py use ``GradSync``).  Utility for modules whose gradients are not
-    produced by the GRL tapes: copies every ``p.grad`` into one flat buffer, ONE blocking all-reduce, copies back.  Parameters whose ``p.grad`` is None contribute
-    zeros (the layout is rank-invariant) and stay None."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        self.numel = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-
-    def allreduce_mean(self, group=None):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is not None:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            else:
-                self.flat[off:off + n].zero_()
-            off += n
-        if is_distributed():
-            if _host_staged(self.flat, group):
-                _HostWork(self.flat, group).wait()
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is not None:
-                p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
-            off += n
-        return self.flat

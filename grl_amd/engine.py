@@ -20,7 +20,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import GrlGemm, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF, check, ptr, require_device
+from ._lib import GrlGemm, GrlBneckTail, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF, check, ptr, require_device
 
 import contextlib
 import os
@@ -235,7 +235,7 @@ def _call(name, *args):
 # ----------------------------------------------------------------------------
 class _Conv(object):
     """A conv (or linear) with its eval-folded affine."""
-    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin', '_wb')
+    __slots__ = ('w', 'N', 'K', 'ldw', 'scale', 'shift', 'k', 'stride', 'cin', '_wb', '_wperm')
 
     def wb(self):
         """bf16 copy of the packed weight (bf16-storage pipeline), made on first use."""
@@ -244,6 +244,15 @@ class _Conv(object):
             self._wb = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
             _call('grl_cast_bf16', ptr(w), ptr(self._wb), w.numel())
         return self._wb
+
+    def wperm(self):
+        """bf16 copy of a 1x1 weight [N][K] in the k order the chained MFMA of grl_bottleneck_tail_bf16 consumes
+        (grl_bneck_perm32), made on first use."""
+        if getattr(self, '_wperm', None) is None:
+            w = self.w.contiguous()
+            self._wperm = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+            _call('grl_bneck_perm32', ptr(w), 0, ptr(self._wperm), w.shape[0], w.shape[1])
+        return self._wperm
 
 
 def _state_key(module):
@@ -288,6 +297,7 @@ class EvalPlan(object):
     def conv(self, conv, bn=None):
         c = _Conv()
         c._wb = None
+        c._wperm = None
         w = conv.weight.detach()
         c.N, c.cin = w.shape[0], w.shape[1]
         c.k = w.shape[2] if w.dim() == 4 else 1
@@ -625,6 +635,31 @@ def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     return y, Ho, Wo
 
 
+FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
+
+
+def _bneck_tail_ok(c3, c1n):
+    return (c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and
+            bool(_lib.load().grl_bottleneck_tail_bf16_supported(c3.K, c3.N, c1n.N)))
+
+
+def bneck_tail_bf16(t2, c3, res, c1n, M):
+    """y = relu(bn3(conv3(t2)) + res) [M][4P] and u = relu(bn1'(conv1'(y))) [M][P'] in one launch
+    (grl_bottleneck_tail_bf16; resnets1.py:86-91 + :76-78 of the next block).  c1n None: y only."""
+    d = GrlBneckTail()
+    y = _newb((M, c3.N), t2)
+    d.t2, d.w3, d.scale3, d.shift3, d.res, d.y = ptr(t2), ptr(c3.wb()), ptr(c3.scale), ptr(c3.shift), ptr(res), ptr(y)
+    d.M, d.P, d.C4, d.Pn = M, c3.K, c3.N, 0
+    u = None
+    if c1n is not None:
+        u = _newb((M, c1n.N), t2)
+        d.w1n, d.scale1n, d.shift1n, d.u, d.Pn = ptr(c1n.wperm()), ptr(c1n.scale), ptr(c1n.shift), ptr(u), c1n.N
+    check(_lib.load().grl_bottleneck_tail_bf16(C.byref(d), _lib.stream()), 'grl_bottleneck_tail_bf16')
+    if _DEBUG_SYNC:
+        _debug_sync('bneck_tail %s' % ((M, c3.K, c3.N, d.Pn),))
+    return y, u
+
+
 def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     """Same launch order as _grl_eval with bf16 activations in HBM: stem -> trunk -> GCE ->
     TRL memo are bf16 tensors, every GEMM is the bf16-storage datapath, reductions land in
@@ -647,12 +682,21 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     cur = _newb((n * H * W, 64), x)
     _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)
     del stem
-    for e in plan.blocks:
+    o1 = None
+    for bi, e in enumerate(plan.blocks):
         s = e['stride']
-        o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
+        if o1 is None:
+            o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
         o2, Ho, Wo = _conv_b16(o1, e['c2'], n, H, W, stride=s)
         res = _conv_b16(cur, e['down'], n, H, W, stride=s, relu=False)[0] if e['down'] is not None else cur
-        cur, _, _ = _conv_b16(o2, e['c3'], n, Ho, Wo, res=res)
+        nxt = plan.blocks[bi + 1]['c1'] if bi + 1 < len(plan.blocks) else None
+        o1 = None
+        if FUSE_BNECK and nxt is not None and _bneck_tail_ok(e['c3'], nxt):
+            # layers 1-2: conv3 + residual + ReLU AND the next block's conv1 in one launch -- the 4P-wide output is
+            # written once (the next block's residual) and never re-read (fuse_bf16.hip)
+            cur, o1 = bneck_tail_bf16(o2, e['c3'], res, nxt, n * Ho * Wo)
+        else:
+            cur, _, _ = _conv_b16(o2, e['c3'], n, Ho, Wo, res=res)
         H, W = Ho, Wo
     x4 = cur
     M = x4.shape[0]

@@ -32,33 +32,50 @@ _head_streams = {}
 
 
 class _HeadFork(object):
-    """``with _HeadFork(x) as fk:`` runs the block on a side HIP stream forked from the current one; ``fk.join()``
-    makes the launch stream wait for it (no-op on CPU tensors or with GRL_HEAD_STREAMS=0)."""
+    """``with _HeadFork(x) as fk:`` runs the block on a side HIP stream forked from the current one; ``fk.join(*results)``
+    makes the launch stream wait for it (no-op on CPU tensors or with GRL_HEAD_STREAMS=0).
+
+    Allocator hygiene: ``x`` was allocated on the launch stream and is read on the side stream, the block's results are
+    allocated on the side stream and consumed on the launch stream -- both are recorded on the other stream
+    (``record_stream``), so that an early free (a ``no_grad`` forward, an exception between fork and join) cannot
+    hand a block back to one stream's pool while the other still has work on it in flight.  An exception inside the
+    block still orders the streams: ``__exit__`` joins when it sees one."""
 
     def __init__(self, x):
         self.on = HEAD_STREAMS and x.is_cuda
+        self.joined = False
         if self.on:
             key = x.device.index if x.device.index is not None else torch.cuda.current_device()
             if key not in _head_streams:
                 _head_streams[key] = torch.cuda.Stream(x.device)
             self.side, self.main = _head_streams[key], torch.cuda.current_stream(x.device)
             self.ctx = torch.cuda.stream(self.side)
+            self.x = x
 
     def __enter__(self):
         if self.on:
             self.side.wait_stream(self.main)
+            self.x.record_stream(self.side)
             self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         if self.on:
             self.ctx.__exit__(*exc)
+            if exc[0] is not None:
+                self.join()
         return False
 
-    def join(self):
-        """The launch stream waits for the side stream (call before the first use of the block's results)."""
-        if self.on:
+    def join(self, *results):
+        """The launch stream waits for the side stream (call before the first use of the block's results and pass
+        them: tensors allocated on the side stream that the launch stream goes on to consume)."""
+        if self.on and not self.joined:
             self.main.wait_stream(self.side)
+            self.joined = True
+        if self.on:
+            for r in results:
+                if torch.is_tensor(r) and r.is_cuda:
+                    r.record_stream(self.main)
 
 
 class BaseTrainer(object):
@@ -199,8 +216,8 @@ class SEQTrainer(BaseTrainer):
         # runs each node's backward on its forward stream, so the backward overlaps the same way); joined before the sum.
         fk = _HeadFork(x_uncorr)
         with fk:
-            encode_scores, siamese_out = self.siamese_model_uncorr(x_uncorr)
-            uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out, target)
+            encode_scores_u, siamese_out_u = self.siamese_model_uncorr(x_uncorr)
+            uncorr_id_loss_vid, output_id = self.criterion_uncorr(siamese_out_u, target)
             uncorr_prec_id_vid = self._top1(output_id, target)
         # (the reference also evaluates the uncorr verification loss but never adds it)
         corr_id_loss_frame, output_id = self.criterion_corr(frame_corr, targetX)
@@ -212,7 +229,7 @@ class SEQTrainer(BaseTrainer):
         corr_loss_tri = criterion_triplet(siamese_out, target).mean()
         corr_loss_ver, _ = self.criterion_ver(self._pair_prob(encode_scores), tar_probe, tar_gallery)
 
-        fk.join()
+        fk.join(uncorr_id_loss_vid, uncorr_prec_id_vid, siamese_out_u, encode_scores_u)
         corr_loss = corr_id_loss_frame + corr_id_loss_vid + corr_loss_ver * 20 + corr_loss_tri
         all_loss = uncorr_id_loss_vid + corr_loss
         return all_loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame

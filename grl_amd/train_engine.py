@@ -233,12 +233,15 @@ class Tape(object):
         self.bnrec = {}         # id(activation of a conv_bn) -> _BNRec: what its BatchNorm backward needs (fused reduce)
         self.fuse_ok = set()    # ids of activations whose ONLY consumers are conv_bn ops (as input or residual)
         self.prep_event = None  # WeightPrep launched on the side stream: the launch stream joins it before layer 1
+        self.foreign = {}       # data_ptr -> tensor: gradient buffers the tape does NOT own exclusively (handed in by
+                                # autograd, or registered for more than one forward tensor): never masked / overwritten
+                                # in place.  The tensors are held so that the address cannot be recycled within the step.
 
     # gradients of activations -------------------------------------------------
     def add_grad(self, t, g):
         cur = self.g.get(id(t))
         if cur is None:
-            self.g[id(t)] = g
+            self.g[id(t)] = g                    # (adopted: every caller passes a buffer it allocated for this call)
         else:
             _call(_k('grl_axpby', cur), ptr(cur), ptr(g), ptr(cur), C.c_float(1.0), C.c_float(1.0), cur.numel())
 
@@ -261,6 +264,11 @@ class Tape(object):
 
     def take(self, t):
         return self.g.pop(id(t), None)
+
+    def owns(self, g):
+        """True if ``g`` is a gradient buffer a tape op allocated for exactly one forward tensor (so the op that
+        popped it may overwrite it in place)."""
+        return g.data_ptr() not in self.foreign
 
     # gradients of parameters --------------------------------------------------
     def reserve_param_grads(self, params, cuts=None):
@@ -610,7 +618,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             if gres is None:
                 # first contribution to grad(res): it IS the masked da -- the reduce pass of grl_bn_bwd masks da in
                 # place (gres == dy) and this tape entry adopts the buffer (da was popped: nobody else reads it)
-                gres = tp.g[id(res)] = da if relu else _newl((M, N), da)
+                gres = tp.g[id(res)] = da if (relu and tp.owns(da)) else _newl((M, N), da)
             _bn_use(tp, res, -1)
         if rec is not None and rec.slab is not None:
             # the GEMM that completed grad(a) masked it and left the two column sums (rec.slab): finalize + apply only
@@ -1107,6 +1115,7 @@ def trl_train(tp, model, xu, xc, b, t):
         dfc = tp.g.get(id(fcorr))
         if dfc is not None:         # f_corr = fc[0] + fc[1]: both directions read the same upstream gradient
             tp.g[id(fc[0])] = tp.g[id(fc[1])] = dfc
+            tp.foreign[dfc.data_ptr()] = dfc
         if d is not None:
             tp.held.append(d)
             for di, m in enumerate((mf, mb_)):
@@ -1172,8 +1181,10 @@ class _GrlTrainFn(torch.autograd.Function):
         xu_out, xc_out = ctx.outs
         if d_uncorr is not None:
             tp.g[id(xu_out)] = d_uncorr.contiguous()
+            tp.foreign[tp.g[id(xu_out)].data_ptr()] = tp.g[id(xu_out)]
         if d_corr is not None:
             tp.g[id(xc_out)] = d_corr.contiguous().view(xc_out.shape)
+            tp.foreign[tp.g[id(xc_out)].data_ptr()] = tp.g[id(xc_out)]
         tp.backward()
         tp.flush()                                   # (whatever no section mark has sent)
         if tp.prep is not None and not tp.prep.ready:

@@ -34,8 +34,9 @@ extern "C" {
 const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
- * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*). */
-#define GRL_ABI_VERSION 5
+ * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*;
+ * round 4: 6 with grl_bottleneck_tail_bf16). */
+#define GRL_ABI_VERSION 6
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */
@@ -544,6 +545,33 @@ int grl_sqdiff_bwd_bf16(const void* f1, const void* f2, const float* dd, void* d
                         int C, int64_t f2_clip_stride, int accumulate_df2, void* stream);
 /* bf16 -> fp32 (n % 8 == 0) */
 int grl_cast_f32(const void* x, float* y, int64_t n, void* stream);
+
+/* ---- cross-layer fusion of the bf16-storage trunk (round 4, fuse_bf16.hip) -------------------------------------
+ * END of one ResNet bottleneck + START of the next in one launch (layers 1-2, where both 1x1 convolutions are
+ * HBM-bound):   y = relu(bn3(conv3(t2)) + res)         reid/models/resnets1.py:86-91
+ *               u = relu(bn1'(conv1'(y)))               reid/models/resnets1.py:76-78 of the next block
+ * y (the widest tensor of the block) is written once and never re-read; a pixel's 4P outputs are contracted against
+ * conv1' in the registers of the wave that produced them.  All activations / weights bf16 (row-major, channels
+ * last), per-channel vectors fp32 (eval-folded BatchNorm: grl_bn_fold), fp32 accumulate, epilogues term for term
+ * those of grl_conv_gemm_f32's bf16-storage datapath.  w1n must be in the chained k order: grl_bneck_perm32.
+ * Shapes: (P, C4) = (64, 256) with Pn in {0, 64, 128}; (128, 512) with Pn in {0, 128, 256}; Pn = 0: no chain. */
+typedef struct GrlBneckTail {
+    const void*  t2;        /* [M][P]  bf16: conv2's output (after bn2 + ReLU)              */
+    const void*  w3;        /* [C4][P] bf16: conv3 weight                                   */
+    const float* scale3;    /* [C4] or NULL (= 1)                                           */
+    const float* shift3;    /* [C4] or NULL (= 0)                                           */
+    const void*  res;       /* [M][C4] bf16: the block's input (or its downsample branch)   */
+    void*        y;         /* [M][C4] bf16 out                                             */
+    const void*  w1n;       /* [Pn][C4] bf16, k-permuted (grl_bneck_perm32), or NULL        */
+    const float* scale1n;   /* [Pn] or NULL                                                 */
+    const float* shift1n;   /* [Pn] or NULL                                                 */
+    void*        u;         /* [M][Pn] bf16 out, or NULL                                    */
+    int32_t M, P, C4, Pn;
+} GrlBneckTail;
+int grl_bottleneck_tail_bf16(const GrlBneckTail* desc, void* stream);
+int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn);      /* 1 if the shape has a kernel */
+/* w [Pn][C4] (fp32 if !w_is_bf16) -> out [Pn][C4] bf16 in the k order the chained MFMA of grl_bottleneck_tail_bf16 consumes */
+int grl_bneck_perm32(const void* w, int w_is_bf16, void* out, int Pn, int C4, void* stream);
 
 #ifdef __cplusplus
 }

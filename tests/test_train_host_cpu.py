@@ -54,15 +54,9 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from grl_amd.dist import GradBucket, is_distributed, gather_rank_order, sharded_distmat
+    from grl_amd.dist import is_distributed, gather_rank_order, sharded_distmat
     assert is_distributed()
     torch.manual_seed(0)
-    a, b, c = (torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
-               torch.nn.Parameter(torch.zeros(2, 2)))
-    a.grad = torch.full((5, 3), float(rank + 1))
-    b.grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
-    # c never receives a gradient (like Siamese.featV): contributes zeros, stays None
-    GradBucket([a, b, c]).allreduce_mean()
     # the OIM look-up tables replay every rank's (feature, label) block in rank order
     x = torch.full((3, 8), float(rank))
     y = torch.tensor([rank, 2, 3])
@@ -115,7 +109,7 @@ def _worker(rank, world, port, out):
     # evaluation features sharded by batch: rank r owns batches r, r + world, ...
     feats = [(i, torch.full((2 + i, 3), float(i)), [i] * (2 + i), [7] * (2 + i)) for i in range(5) if i % world == rank]
     gf, gp, gc = gather_feature_batches(feats, 5)
-    out[rank] = (a.grad.clone(), b.grad.clone(), c.grad, (xs.clone(), ys.clone()), dm.clone(), sync_out,
+    out[rank] = (None, None, None, (xs.clone(), ys.clone()), dm.clone(), sync_out,
                  (gf.clone(), gp, gc), tape_out, gg_out)
     dist.destroy_process_group()
 
@@ -126,13 +120,10 @@ def test_gradient_allreduce_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
-        ga, gb, gc, _, dm = out[r][:5]
+        dm = out[r][4]
         g = torch.Generator().manual_seed(3)
         qf, gf = torch.randn(5, 16, generator=g), torch.randn(11, 16, generator=g)
         assert torch.equal(dm, -qf.mm(gf.t()))
-        assert torch.allclose(ga, torch.full((5, 3), 1.5))
-        assert torch.allclose(gb, torch.arange(7, dtype=torch.float32) * 1.5)
-        assert gc is None
     for r in range(world):
         xs, ys = out[r][3]
         assert torch.equal(xs, torch.cat((torch.zeros(3, 8), torch.ones(3, 8))))
@@ -200,6 +191,18 @@ def test_rank_batch_sampler_shards_the_loader_not_its_output():
         assert [got[i % world][i // world] for i in range(7)] == full
     assert shard_loader_batches('abc', 0, 1) == 'abc'
     assert list(shard_loader_batches(iter(range(7)), 1, 3)) == [1, 4]
+    # a shuffling sampler draws its own permutation per process: the loader is NOT re-built (batch i % world would
+    # not partition the data); its output is filtered and the generator the caller seeded is still the one in use
+    g = torch.Generator().manual_seed(5)
+    shuffled = DataLoader(Counting(), batch_size=4, shuffle=True, generator=g)
+    a = [b[0].view(-1).tolist() for b in shard_loader_batches(shuffled, 0, 2)]
+    g.manual_seed(5)
+    ref = [b[0].view(-1).tolist() for b in shuffled]
+    assert a == ref[0::2]
+    # the re-built loader keeps generator / pin-memory device of the original
+    g2 = torch.Generator().manual_seed(1)
+    rebuilt = shard_loader_batches(DataLoader(Counting(), batch_size=4, generator=g2), 1, 2)
+    assert rebuilt.generator is g2 and len(rebuilt) == 3
 
 
 def test_bench_launcher_starts_n_fresh_ranks():
@@ -231,6 +234,37 @@ def test_bench_launcher_starts_n_fresh_ranks():
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and cmd[cmd.index('--nproc-per-node') + 1] == '8'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '8', '--steps', '3']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+@pytest.mark.parametrize('fault', ['hang', 'raise'])
+def test_bench_train_block_failure_is_visible_in_the_exit_code(fault):
+    """N > 1: a hung or raising train block (the RCCL all-reduce step) must turn the launcher's exit code red while
+    stdout still carries ONE JSON line with `train.error` (VERDICT round 3 item 6 / ADVICE: the watchdog used to
+    os._exit(0)).  Two gloo ranks through the real launcher; rank 1 sleeps past the time limit / raises."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GRL_BENCH_DRY_TRAIN=fault, GRL_BENCH_TRAIN_TIMEOUT='4')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0, res.stdout
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line['dry_run'] and 'error' in line['train']
+    assert ('did not finish' in line['train']['error']) if fault == 'hang' else ('injected failure' in line['train']['error'])
+
+
+def test_bench_train_block_ok_path_exits_zero():
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GRL_BENCH_DRY_TRAIN='ok', GRL_BENCH_TRAIN_TIMEOUT='60')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['train'] == {"ok": True}
 
 
 def test_trainer_helpers_on_cpu_tensors():

@@ -76,7 +76,7 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     launch, counted by the host wrapper) / sum of their measured durations."""
     from grl_amd import engine
     recs = []
-    orig = engine.gemm
+    orig, orig_tail = engine.gemm, engine.bneck_tail_bf16
 
     def timed(a, w, y, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -86,16 +86,26 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         recs.append((2.0 * M * N * K, e0, e1, (M, N, K, kw.get('conv'))))
         return out
 
+    def timed_tail(t2, c3, res, c1n, M):
+        # the fused bottleneck tail (fuse_bf16.hip) carries two of the path's convolutions: conv3 and the next conv1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_tail(t2, c3, res, c1n, M)
+        e1.record()
+        pn = c1n.N if c1n is not None else 0
+        recs.append((2.0 * M * c3.N * (c3.K + pn), e0, e1, (M, c3.N, c3.K, 'fused tail + conv1 -> %d' % pn)))
+        return out
+
     streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
     engine.extract_features(cnn, siam, clips)                   # untimed: the caching allocator re-settles on one stream
     torch.cuda.synchronize()                                    # (a hipMalloc between two events would count as GEMM time)
-    engine.gemm = timed
+    engine.gemm, engine.bneck_tail_bf16 = timed, timed_tail
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)
         torch.cuda.synchronize()
     finally:
-        engine.gemm = orig
+        engine.gemm, engine.bneck_tail_bf16 = orig, orig_tail
         engine.TRL_STREAMS = streams
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
@@ -132,7 +142,7 @@ def eval_kernel_timing(cnn, siam, clips, math):
     from grl_amd import engine
     with engine.math_mode(math):
         flops, ms, launches = gemm_roofline(cnn, siam, clips)
-    return {"name": "gemm_bf16_256_kernel / gemm_f32_kernel<.., bf16 storage> (implicit-GEMM conv + linear)" if math == 'bf16s'
+    return {"name": "gemm_bf16_256_kernel / gemm_f32_kernel<.., bf16 storage> / bneck_tail_kernel (implicit-GEMM conv + linear, fused bottleneck tails)" if math == 'bf16s'
             else "gemm_f32_kernel", "launches_per_step": launches, "ms_per_step": round(ms, 3),
             "gflop_per_step": round(flops / 1e9, 1), "tflops": round(flops / ms / 1e9, 1),
             "frac_of_peak": round(flops / ms / 1e9 / SERIES_PEAK[math], 4)}

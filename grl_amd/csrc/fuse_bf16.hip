@@ -48,6 +48,15 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds, 16, 0, 0);
 }
 
+// The same instruction, invisible to hipcc's waitcnt pass: `sbase` + lane offset `voff` -> LDS byte address `lds` (+ 16*l).
+// While an LDS-DMA it knows about is pending hipcc treats the wave like one with a FLAT access in flight -- every vmcnt AND
+// lgkmcnt wait it inserts becomes (0), so a DMA issued inside the steady-state loop serialises the loop's residual-load
+// ring and its fragment reads.  Issued this way the compiler's counted waits only ever over-wait (the hidden pieces are
+// extra outstanding operations), and the kernel waits for the pieces itself in front of the chunk barrier.
+__device__ __forceinline__ void glds16_hidden(const char* sbase, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+
 // rows (16 lanes) 1 and 3 of `a` trade places with rows 0 and 2 of `b`
 __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
     auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -63,102 +72,144 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // round-t
     return *reinterpret_cast<uint32_t*>(&v);
 }
 
-constexpr int TILE_PX = 256;                  // 16 waves x 16 pixels
 
 // P: conv3 input channels, C4: its output channels (= conv1' input channels), PN: conv1' output channels (0: no chain),
-// CH: channels of y per LDS weight chunk (C4 / CH chunks; one chunk = resident weights, no barriers)
-template <int P, int C4, int PN, int CH, int GBMAX = 4>
-__global__ __launch_bounds__(1024) void bneck_tail_kernel(const GrlBneckTail p, const int num_tiles) {
+// CH: channels of y per LDS weight chunk (C4 / CH chunks; one chunk = resident weights, no barriers),
+// GB: 16-channel blocks per register group (16 * GB channels of accumulators live), PD: residual groups in flight,
+// NW: waves per workgroup (16 pixels each; 16 waves = 128 registers per lane, 8 waves = 256 for the widest conv1').
+//
+// Memory pipeline of a wave (the launch is latency-bound long before it is bandwidth-bound: a group's MFMAs take ~50 ns,
+// an HBM load ~2 us): the residual rows of the next PD groups -- across the chunk and the tile boundary -- and the NEXT
+// tile's conv3 operand are always in flight; vmcnt retires in order, so waiting for the oldest group leaves the younger
+// ones (and the stores issued since) outstanding.
+//
+// Streaming weights (NCH > 1): two STATIC LDS buffers, the chunk loop unrolled by two so that every LDS-DMA target and
+// every fragment read names its buffer at compile time -- hipcc then knows the DMA into buffer B cannot alias the
+// ds_reads of buffer A and does not put a vmcnt(0) between them (with one dynamic array it does, and the "prefetch" of
+// chunk c + 1 is waited for before chunk c computes).  Chunk boundary: this wave's DMA pieces are older than the
+// Chunk boundary: a counted vmcnt that leaves the youngest residual refills in flight + a raw s_barrier (no fence).
+template <int P, int C4, int PN, int CH, int GB, int PD, int NW>
+__global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail p, const int num_tiles) {
+    constexpr int TILE_PX = NW * 16;
     constexpr bool CHAIN = PN > 0;
     constexpr int NCH = C4 / CH;
     constexpr int KS3 = P / 32;               // k-steps of conv3
     constexpr int CB = CH / 16;               // 16-channel blocks of y per chunk
-    constexpr int GB = CB < GBMAX ? CB : GBMAX; // blocks per register group (16 * GB channels of accumulators live)
+    constexpr int GPC = CB / GB;              // register groups per chunk
     constexpr int OB = CHAIN ? PN / 16 : 0;   // 16-channel blocks of u
     constexpr int KS1 = CH / 32;              // conv1' k-steps per chunk
     constexpr int W3_FR = CB * KS3, W1_FR = OB * KS1;
     constexpr int BUF = (W3_FR + W1_FR) * 1024;
-    constexpr int VEC = (2 * C4 + 2 * (CHAIN ? PN : 0)) * 4;
+    constexpr bool PFN = NCH == 1;            // next tile's conv3 operand prefetched into its own registers at the tile top
     static_assert(P % 32 == 0 && CH % 32 == 0 && C4 % CH == 0 && CB % GB == 0 && GB % 2 == 0, "shape");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const sc3 = reinterpret_cast<float*>(smem);
-    float* const sh3 = sc3 + C4;
-    float* const sc1 = sh3 + C4;
-    float* const sh1 = sc1 + (CHAIN ? PN : 0);
-    char* const wbuf = smem + VEC;
+    static_assert(GPC % PD == 0 && (NCH == 1 || NCH % 2 == 0) && (W3_FR + W1_FR) % NW == 0, "pipeline");
+    __shared__ __attribute__((aligned(16))) char bufA[BUF];
+    __shared__ __attribute__((aligned(16))) char bufB[NCH > 1 ? BUF : 16];
+    __shared__ __attribute__((aligned(16))) float sc3[C4], sh3[C4], sc1[CHAIN ? PN : 4], sh1[CHAIN ? PN : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, q = lane >> 4;
     const char* const w3 = reinterpret_cast<const char*>(p.w3);
     const char* const w1 = reinterpret_cast<const char*>(p.w1n);
+    // per-lane source offsets of a fragment's 16 bytes: W3 rows are P, W1' rows C4 elements long
+    const uint32_t w3l = (uint32_t)(j * P + 8 * q) * 2, w1l = (uint32_t)(j * C4 + 8 * q) * 2;
 
-    // chunk c of the weights -> LDS buffer `buf`, fragment order; wave w issues fragments w, w+16, ...
-    auto stage = [&](int c, int buf) {
-        char* const dst = wbuf + buf * BUF;
+    // chunk c of the weights -> LDS buffer `dst`, fragment order; wave w issues fragments w, w + NW, ...
+    auto stage = [&](int c, char* dst) {
+        const uint32_t lds0 = (uint32_t)(size_t)((lptr_t)dst);
 #pragma unroll
-        for (int f = wave; f < W3_FR + W1_FR; f += 16) {
-            const char* src;
+        for (int k = 0; k < (W3_FR + W1_FR) / NW; ++k) {
+            const int f = wave + k * NW;
             if (f < W3_FR) {
                 const int cb = f / KS3, s = f - cb * KS3;
-                src = w3 + ((int64_t)(c * CH + 16 * cb + j) * P + 32 * s + 8 * q) * 2;
+                glds16_hidden(w3, w3l + (uint32_t)(((c * CH + 16 * cb) * P + 32 * s) * 2), lds0 + f * 1024);
             } else {
                 const int g = f - W3_FR, ob = g / KS1, s = g - ob * KS1;
-                src = w1 + ((int64_t)(16 * ob + j) * C4 + c * CH + 32 * s + 8 * q) * 2;
+                glds16_hidden(w1, w1l + (uint32_t)((16 * ob * C4 + c * CH + 32 * s) * 2), lds0 + f * 1024);
             }
-            glds16(src, dst + f * 1024);
         }
     };
 
-    for (int i = tid; i < C4; i += 1024) {
+    for (int i = tid; i < C4; i += NW * 64) {
         sc3[i] = p.scale3 ? p.scale3[i] : 1.f;
         sh3[i] = p.shift3 ? p.shift3[i] : 0.f;
     }
     if (CHAIN)
-        for (int i = tid; i < PN; i += 1024) {
+        for (int i = tid; i < PN; i += NW * 64) {
             sc1[i] = p.scale1n ? p.scale1n[i] : 1.f;
             sh1[i] = p.shift1n ? p.shift1n[i] : 0.f;
         }
-    stage(0, 0);
-    __syncthreads();                            // (drains the DMA: vmcnt(0) in front of the barrier)
+    stage(0, bufA);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     const char* const t2 = reinterpret_cast<const char*>(p.t2);
     const char* const res = reinterpret_cast<const char*>(p.res);
     char* const y = reinterpret_cast<char*>(p.y);
     char* const u = reinterpret_cast<char*>(p.u);
-    const int sw_ch = 16 * (q & 1) + 8 * (q >> 1);          // channel offset of a lane's 16 bytes in a block PAIR (swapped layout)
-    int it = 0;                                 // chunk iterations so far (buffer = it & 1 when streaming)
+    // 32-bit byte offsets from the wave-uniform bases (the dispatcher guarantees every operand is < 4 GiB)
+    const uint32_t sw_b = (uint32_t)(16 * (q & 1) + 8 * (q >> 1)) * 2;   // a lane's 16 bytes inside a block PAIR (swapped layout)
+    const uint32_t q16 = (uint32_t)q * 16;
 
-    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const int row = tile * TILE_PX + wave * 16 + j;
-        const bool live = row < p.M;
-        const int64_t rowc = live ? row : p.M - 1;
-        bf16x8 bfr[KS3];
+    int tile = blockIdx.x;
+    int row = tile * TILE_PX + wave * 16 + j;
+    uint32_t rowc = (uint32_t)(row < p.M ? row : p.M - 1);
+    bf16x8 bfr[KS3];
+    uint4 rr[PD][GB / 2];
+    if (tile < num_tiles) {
 #pragma unroll
-        for (int s = 0; s < KS3; ++s)
-            bfr[s] = *reinterpret_cast<const bf16x8*>(t2 + (rowc * P + 32 * s + 8 * q) * 2);
+        for (int s = 0; s < KS3; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(t2 + (size_t)(rowc * (uint32_t)(P * 2) + 64 * s + q16));
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int t = 0; t < GB / 2; ++t)
+                rr[k][t] = *reinterpret_cast<const uint4*>(res + (size_t)(rowc * (uint32_t)(C4 * 2) + (k * GB * 16 + 32 * t) * 2 + sw_b));
+    }
+    bool first = true;
+
+#pragma unroll 1
+    for (; tile < num_tiles;) {
+        const int ntile = tile + (int)gridDim.x;
+        const bool has_next = ntile < num_tiles;
+        const int rown = ntile * TILE_PX + wave * 16 + j;
+        const uint32_t rowcn = has_next ? (uint32_t)(rown < p.M ? rown : p.M - 1) : rowc;
+        const bool live = row < p.M;
+        bf16x8 bfn[PFN ? KS3 : 1];
+        if (PFN && has_next) {
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) bfn[s] = *reinterpret_cast<const bf16x8*>(t2 + (size_t)(rowcn * (uint32_t)(P * 2) + 64 * s + q16));
+        }
         f32x4 acc1[CHAIN ? OB : 1];
 #pragma unroll
         for (int ob = 0; ob < (CHAIN ? OB : 1); ++ob) acc1[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c, ++it) {
-            const char* wb = wbuf;
-            if (NCH > 1) {
-                wb += (it & 1) * BUF;
-                if (it > 0) __syncthreads();    // chunk `it` has landed (issued one iteration ago); buffer (it+1)&1 is free
-                const bool more = c + 1 < NCH || tile + (int)gridDim.x < num_tiles;
-                if (more) stage(c + 1 < NCH ? c + 1 : 0, (it + 1) & 1);
-            }
-            const char* const w3f = wb;
-            const char* const w1f = wb + W3_FR * 1024;
-#pragma unroll 1
-            for (int g = 0; g < CB / GB; ++g) {
-                const int ch0 = c * CH + 16 * g * GB;              // first channel of the group
-                uint4 rr[GB / 2];
+        const uint32_t yrow = (uint32_t)row * (uint32_t)(C4 * 2);
+        if (!PFN) {
 #pragma unroll
-                for (int t = 0; t < GB / 2; ++t)
-                    rr[t] = *reinterpret_cast<const uint4*>(res + (rowc * C4 + ch0 + 32 * t + sw_ch) * 2);
+            for (int s = 0; s < KS3; ++s) asm volatile("" ::"v"(bfr[s]));      // the operand's vmcnt wait happens HERE
+        }
+
+        // one chunk: `mine` holds its weights, the next chunk is DMA'd into `other` meanwhile
+        auto chunk = [&](const int c, const char* const mine, char* const other) {
+            if (NCH > 1) {
+                if (!(first && c == 0)) {
+                    // this wave's pieces of chunk c are the OLDEST operations it has in flight (issued at the top of the
+                    // previous chunk); behind them sit that chunk's stores and residual refills.  vmcnt retires in order:
+                    // leaving only the refills' count outstanding (GB / 2 per group, always issued when a next chunk exists)
+                    // covers the pieces whether or not dead lanes skipped their stores.  Then the barrier publishes every
+                    // wave's pieces and says `other` is no longer being read.
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPC * GB / 2) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                if (c + 1 < NCH || has_next) stage(c + 1 < NCH ? c + 1 : 0, other);
+            }
+            const char* const w3f = mine;
+            const char* const w1f = mine + W3_FR * 1024;
+#pragma unroll
+            for (int gi = 0; gi < GPC; ++gi) {
+                const int slot = gi % PD;                           // (compile-time: PD divides the groups of a chunk)
+                const int ch0 = (c * CB + gi * GB) * 16;            // first channel of the group
                 f32x4 acc3[GB];
 #pragma unroll
                 for (int b = 0; b < GB; ++b) acc3[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -166,12 +217,12 @@ __global__ __launch_bounds__(1024) void bneck_tail_kernel(const GrlBneckTail p, 
                 for (int s = 0; s < KS3; ++s)
 #pragma unroll
                     for (int b = 0; b < GB; ++b) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3f + ((g * GB + b) * KS3 + s) * 1024 + lane * 16);
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3f + ((gi * GB + b) * KS3 + s) * 1024 + lane * 16);
                         acc3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[s], acc3[b], 0, 0, 0);
                     }
 #pragma unroll
                 for (int t = 0; t < GB / 2; ++t) {
-                    uint32_t ax = rr[t].x, ay = rr[t].y, bx = rr[t].z, by = rr[t].w;
+                    uint32_t ax = rr[slot][t].x, ay = rr[slot][t].y, bx = rr[slot][t].z, by = rr[slot][t].w;
                     swap16(ax, bx);             // 16 contiguous bytes per lane -> this lane's 4 channels of block 2t | of block 2t+1
                     swap16(ay, by);
                     const int cA = ch0 + 32 * t + 4 * q, cB = cA + 16;
@@ -190,7 +241,7 @@ __global__ __launch_bounds__(1024) void bneck_tail_kernel(const GrlBneckTail p, 
                     if (CHAIN) {                // blocks (2t, 2t+1) of y ARE k-step ks of conv1' (k order: grl_bneck_perm32)
                         uint4 kv = {ax, ay, bx, by};
                         const bf16x8 bk = *reinterpret_cast<bf16x8*>(&kv);
-                        const int ks = (g * GB) / 2 + t;
+                        const int ks = (gi * GB) / 2 + t;
 #pragma unroll
                         for (int ob = 0; ob < OB; ++ob) {
                             const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1f + (ob * KS1 + ks) * 1024 + lane * 16);
@@ -199,12 +250,42 @@ __global__ __launch_bounds__(1024) void bneck_tail_kernel(const GrlBneckTail p, 
                     }
                     swap16(ax, bx);
                     swap16(ay, by);
-                    if (live) *reinterpret_cast<uint4*>(y + ((int64_t)row * C4 + ch0 + 32 * t + sw_ch) * 2) = uint4{ax, ay, bx, by};
+                    if (live) *reinterpret_cast<uint4*>(y + (size_t)(yrow + (ch0 + 32 * t) * 2 + sw_b)) = uint4{ax, ay, bx, by};
                     __builtin_amdgcn_sched_barrier(0);      // keep the block pairs in program order: hoisted A-fragment reads spill
                 }
+                // refill this slot: PD groups ahead -- same chunk, the next chunk, or chunk 0 of the next tile
+                {
+                    const int gn = gi + PD;                          // compile-time
+                    const bool wrap = gn >= GPC && c + 1 == NCH;     // ... of the next tile
+                    if (!wrap || has_next) {
+                        const uint32_t rbase = (wrap ? rowcn : rowc) * (uint32_t)(C4 * 2);
+                        const int chn = wrap ? (gn - GPC) * GB * 16 : ((c + (gn >= GPC ? 1 : 0)) * CB + (gn % GPC) * GB) * 16;
+#pragma unroll
+                        for (int t = 0; t < GB / 2; ++t)
+                            rr[slot][t] = *reinterpret_cast<const uint4*>(res + (size_t)(rbase + (uint32_t)((chn + 32 * t) * 2) + sw_b));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (NCH == 1) {
+            chunk(0, bufA, bufA);
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < NCH; c += 2) {
+                chunk(c, bufA, bufB);
+                chunk(c + 1, bufB, bufA);
             }
         }
+        first = false;
+        if (!PFN && has_next) {
+            // streaming variants have no registers to spare for a second operand: the next tile's is requested as soon as
+            // this tile's last conv3 MFMA has read the current one (its wait is pinned at the tile top, outside the chunk loop)
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(t2 + (size_t)(rowcn * (uint32_t)(P * 2) + 64 * s + q16));
+        }
         if (CHAIN) {
+            const uint32_t urow = (uint32_t)row * (uint32_t)(PN * 2);
 #pragma unroll
             for (int t = 0; t < OB / 2; ++t) {
                 const int cA = 32 * t + 4 * q, cB = cA + 16;
@@ -220,9 +301,16 @@ __global__ __launch_bounds__(1024) void bneck_tail_kernel(const GrlBneckTail p, 
                 uint32_t bx = pack2(vB[0], vB[1]), by = pack2(vB[2], vB[3]);
                 swap16(ax, bx);
                 swap16(ay, by);
-                if (live) *reinterpret_cast<uint4*>(u + ((int64_t)row * PN + 32 * t + sw_ch) * 2) = uint4{ax, ay, bx, by};
+                if (live) *reinterpret_cast<uint4*>(u + (size_t)(urow + 64 * t + sw_b)) = uint4{ax, ay, bx, by};
             }
         }
+        if (PFN && has_next) {
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) bfr[s] = bfn[s];
+        }
+        tile = ntile;
+        row = rown;
+        rowc = rowcn;
     }
 }
 
@@ -240,17 +328,12 @@ __global__ void bneck_perm_kernel(const T* __restrict__ w, __bf16* __restrict__ 
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <int P, int C4, int PN, int CH>
+template <int P, int C4, int PN, int CH, int GB = 4, int PD = 4, int NW = 16>
 int launch(const GrlBneckTail& d, hipStream_t s) {
     constexpr int NCH = C4 / CH;
     constexpr int FR = (CH / 16) * (P / 32) + (PN / 16) * (CH / 32);
-    constexpr int LDS = (2 * C4 + 2 * PN) * 4 + (NCH > 1 ? 2 : 1) * FR * 1024;
-    static_assert(LDS <= 160 * 1024, "LDS");
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)bneck_tail_kernel<P, C4, PN, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        return true;
-    }();
-    (void)attr;
+    constexpr int LDS = (2 * C4 + 2 * PN) * 4 + (NCH > 1 ? 2 : 1) * FR * 1024;      // static, in the kernel descriptor
+    static_assert(LDS <= 160 * 1024 - 64, "LDS");
     static const int cus = [] {
         int dev = 0, n = 256;
         hipDeviceProp_t prop;
@@ -258,9 +341,10 @@ int launch(const GrlBneckTail& d, hipStream_t s) {
             n = prop.multiProcessorCount;
         return n;
     }();
+    constexpr int TILE_PX = NW * 16;
     const int num_tiles = (d.M + TILE_PX - 1) / TILE_PX;
     const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
-    hipLaunchKernelGGL((bneck_tail_kernel<P, C4, PN, CH>), dim3(grid), dim3(1024), LDS, s, d, num_tiles);
+    hipLaunchKernelGGL((bneck_tail_kernel<P, C4, PN, CH, GB, PD, NW>), dim3(grid), dim3(NW * 64), 0, s, d, num_tiles);
     return grl_check_launch("grl_bottleneck_tail_bf16");
 }
 
@@ -288,6 +372,7 @@ extern "C" int grl_bottleneck_tail_bf16(const GrlBneckTail* dp, void* stream) {
     if (d.Pn > 0 && (!d.w1n || !d.u)) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: Pn > 0 needs w1n and u");
     if (!al16(d.t2) || !al16(d.w3) || !al16(d.res) || !al16(d.y) || !al16(d.w1n) || !al16(d.u))
         return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: operands must be 16-byte aligned");
+    if ((int64_t)d.M * d.C4 * 2 >= (1ll << 32)) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: M * C4 too large for 32-bit offsets");
     if (!grl_bottleneck_tail_bf16_supported(d.P, d.C4, d.Pn))
         return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: unsupported shape P %d, C4 %d, Pn %d", d.P, d.C4, d.Pn);
     hipStream_t s = (hipStream_t)stream;
@@ -296,7 +381,7 @@ extern "C" int grl_bottleneck_tail_bf16(const GrlBneckTail* dp, void* stream) {
         if (d.Pn == 128) return launch<64, 256, 128, 256>(d, s);
         return launch<64, 256, 0, 256>(d, s);
     }
-    if (d.Pn == 128) return launch<128, 512, 128, 128>(d, s);
-    if (d.Pn == 256) return launch<128, 512, 256, 64>(d, s);
-    return launch<128, 512, 0, 128>(d, s);
+    if (d.Pn == 128) return launch<128, 512, 128, 128, 4, 2>(d, s);
+    if (d.Pn == 256) return launch<128, 512, 256, 64, 2, 2, 16>(d, s);
+    return launch<128, 512, 0, 128, 4, 2>(d, s);
 }

@@ -1,0 +1,108 @@
+"""Cross-layer fusion of the bf16-storage trunk (grl_amd/csrc/fuse_bf16.hip) on a real MI355X, through the C ABI:
+conv3 + residual + ReLU and the next block's conv1 in one launch, against torch fp32 on the same bf16 inputs and against
+the unfused pipeline (two launches of the bf16-storage GEMM)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    from grl_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+class _C(object):
+    """Stand-in for engine._Conv (1x1 conv + folded BatchNorm) with seeded weights."""
+
+    def __init__(self, N, K, g, dev):
+        from grl_amd import engine
+        self.N, self.K, self.k, self.ldw, self.cin, self.stride = N, K, 1, K, K, 1
+        self.w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        self.scale = (torch.rand(N, generator=g) + 0.5).to(dev)
+        self.shift = (torch.randn(N, generator=g) * 0.3).to(dev)
+        self._wb = self._wperm = None
+        self.wb = engine._Conv.wb.__get__(self)
+        self.wperm = engine._Conv.wperm.__get__(self)
+
+
+def _close_bf16(got, ref, ulps=1.0):
+    """got (bf16 values as fp32) is `ref` (fp32) rounded to bf16, give or take fp32 summation-order noise: the error
+    is at most `ulps` bf16 half-spacings of |ref| plus 1e-4 absolute (a sum of O(1) terms that cancels to ~0 still
+    carries ~1e-6 of the terms' magnitude)."""
+    err = (got - ref).abs()
+    tol = ref.abs() * (ulps * 2.0 ** -8) + 1e-4
+    bad = err > tol
+    assert not bool(bad.any()), (float(err.max()), int(bad.sum()))
+
+
+@pytest.mark.parametrize('P,C4,Pn', [(64, 256, 64), (64, 256, 128), (128, 512, 128), (128, 512, 256), (64, 256, 0), (128, 512, 0)])
+@pytest.mark.parametrize('M', [256 * 9, 16 * 7 + 5, 70000])
+def test_bottleneck_tail_matches_torch_and_the_unfused_launches(dev, P, C4, Pn, M):
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(P + C4 + Pn + M)
+    c3 = _C(C4, P, g, dev)
+    c1 = _C(Pn, C4, g, dev) if Pn else None
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(dev).to(BF)
+    res = torch.randn(M, C4, generator=g).to(dev).to(BF)
+    y, u = engine.bneck_tail_bf16(t2, c3, res, c1, M)
+    torch.cuda.synchronize()
+    # torch fp32 on the same bf16 operands
+    w3 = c3.wb().float()
+    yr = torch.relu(t2.float() @ w3.t() * c3.scale + c3.shift + res.float())
+    _close_bf16(y.float(), yr)                                     # the fp32 value rounded once
+    assert float((y.float() - yr).abs().max() / yr.abs().max()) < 6e-3
+    # the unfused launches of the bf16-storage GEMM: conv3 (+res, ReLU), then conv1 on ITS output
+    y0 = torch.empty(M, C4, dtype=BF, device=dev)
+    engine.gemm(t2, c3.wb(), y0, M, C4, P, scale=c3.scale, shift=c3.shift, res=res, relu=True, math=engine.MATH_BF16S)
+    _close_bf16(y.float(), y0.float(), ulps=2.0)                   # two roundings of almost the same fp32 value
+    frac_equal = float((y == y0).float().mean())
+    assert frac_equal > 0.995, frac_equal                           # (different MFMA shape: the fp32 sums differ in the last bit)
+    if Pn:
+        ur = torch.relu(y.float() @ c1.wb().float().t() * c1.scale + c1.shift)      # from the kernel's own y (bf16)
+        _close_bf16(u.float(), ur)
+        assert float((u.float() - ur).abs().max() / ur.abs().max()) < 6e-3
+        u0 = torch.empty(M, Pn, dtype=BF, device=dev)
+        engine.gemm(y, c1.wb(), u0, M, Pn, C4, scale=c1.scale, shift=c1.shift, relu=True, math=engine.MATH_BF16S)
+        _close_bf16(u.float(), u0.float(), ulps=2.0)
+    else:
+        assert u is None
+
+
+def test_bottleneck_tail_rows_do_not_depend_on_the_batch(dev):
+    """A pixel's outputs are the same bits whatever tile / grid / batch it is computed in (each wave owns whole
+    pixels): rows [0, 300) of a 5000-row launch equal a 300-row launch."""
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(3)
+    c3, c1 = _C(512, 128, g, dev), _C(128, 512, g, dev)
+    t2 = torch.randn(5000, 128, generator=g).clamp_min(0).to(dev).to(BF)
+    res = torch.randn(5000, 512, generator=g).to(dev).to(BF)
+    y, u = engine.bneck_tail_bf16(t2, c3, res, c1, 5000)
+    ys, us = engine.bneck_tail_bf16(t2[:300].contiguous(), c3, res[:300].contiguous(), c1, 300)
+    assert torch.equal(y[:300], ys) and torch.equal(u[:300], us)
+
+
+def test_bf16s_eval_with_and_without_the_fused_trunk(dev, synth_models):
+    """End to end: the bf16-storage feature rows with the fused trunk agree with the one-launch-per-conv pipeline to
+    bf16 rounding noise (well inside the 3e-2 bf16-storage tolerance vs the fp32 oracle) and stay batch independent."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_clips
+    cnn, siam = synth_models[0], synth_models[1]
+    cnn, siam = cnn.to(dev).eval(), siam.to(dev).eval()
+    clips = synth_clips(4, 4, seed=5).to(dev)
+    with engine.math_mode('bf16s'):
+        f1 = engine.extract_features(cnn, siam, clips)
+        f1b = engine.extract_features(cnn, siam, clips[:2].contiguous())
+        old, engine.FUSE_BNECK = engine.FUSE_BNECK, False
+        try:
+            f0 = engine.extract_features(cnn, siam, clips)
+        finally:
+            engine.FUSE_BNECK = old
+    assert torch.equal(f1[:2], f1b)
+    rel = float((f1 - f0).norm() / f0.norm())
+    assert rel < 1e-2, rel

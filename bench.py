@@ -76,7 +76,7 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     launch, counted by the host wrapper) / sum of their measured durations."""
     from grl_amd import engine
     recs = []
-    orig, orig_tail = engine.gemm, engine.bneck_tail_bf16
+    orig, orig_tail, orig_tail32 = engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32
 
     def timed(a, w, y, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -86,26 +86,29 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         recs.append((2.0 * M * N * K, e0, e1, (M, N, K, kw.get('conv'))))
         return out
 
-    def timed_tail(t2, c3, res, c1n, M):
-        # the fused bottleneck tail (fuse_bf16.hip) carries two of the path's convolutions: conv3 and the next conv1
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_tail(t2, c3, res, c1n, M)
-        e1.record()
-        pn = c1n.N if c1n is not None else 0
-        recs.append((2.0 * M * c3.N * (c3.K + pn), e0, e1, (M, c3.N, c3.K, 'fused tail + conv1 -> %d' % pn)))
-        return out
+    def timed_tail_of(fn):
+        def timed_tail(t2, c3, res, c1n, M):
+            # a fused bottleneck tail (fuse_bf16.hip / fuse_f32.hip) carries two of the path's convolutions: conv3 and the
+            # next block's conv1 -- counted with the GEMM launches they replace (same algorithmic FLOPs, their own time)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(t2, c3, res, c1n, M)
+            e1.record()
+            pn = c1n.N if c1n is not None else 0
+            recs.append((2.0 * M * c3.N * (c3.K + pn), e0, e1, (M, c3.N, c3.K, 'fused tail + conv1 -> %d' % pn)))
+            return out
+        return timed_tail
 
     streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
     engine.extract_features(cnn, siam, clips)                   # untimed: the caching allocator re-settles on one stream
     torch.cuda.synchronize()                                    # (a hipMalloc between two events would count as GEMM time)
-    engine.gemm, engine.bneck_tail_bf16 = timed, timed_tail
+    engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32 = timed, timed_tail_of(orig_tail), timed_tail_of(orig_tail32)
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)
         torch.cuda.synchronize()
     finally:
-        engine.gemm, engine.bneck_tail_bf16 = orig, orig_tail
+        engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32 = orig, orig_tail, orig_tail32
         engine.TRL_STREAMS = streams
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
@@ -788,7 +791,7 @@ def main():
                          "traffic_note": "NOT measured by this run: read from profiles/%s (rocprofv3 FETCH_SIZE x2 + "
                                          "WRITE_SIZE, separate passes, summed over the kernel's launches of ONE "
                                          "step like the GFLOP figure)" % pmc_name,
-                         "kernel": "gemm_f32_kernel (%s MFMA implicit-GEMM conv), %d launches/step, "
+                         "kernel": "gemm_f32_kernel + fused bottleneck tails (%s MFMA implicit-GEMM conv), %d launches/step, "
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
                                        'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
             "end_to_end_tflops": round(value / n * GFLOP_PER_FRAME * T / 1e3, 2),

@@ -45,6 +45,10 @@ class GrlBneckTail(C.Structure):
                [(n, _i32) for n in ('M', 'P', 'C4', 'Pn')]
 
 
+class GrlBneckTailF32(C.Structure):
+    _fields_ = GrlBneckTail._fields_
+
+
 class GrlPrepEntry(C.Structure):
     _fields_ = [('src', _fp), ('dst', _fp), ('base', _i64), ('strides', _i64 * 4), ('dims', _i32 * 4),
                 ('tiled', _i32), ('out_bf16', _i32)]
@@ -160,6 +164,8 @@ _SIGNATURES = {
     'grl_bottleneck_tail_bf16': ([C.POINTER(GrlBneckTail), _fp], C.c_int),
     'grl_bottleneck_tail_bf16_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'grl_bneck_perm32': ([_fp, C.c_int, _fp, C.c_int, C.c_int, _fp], C.c_int),
+    'grl_bottleneck_tail_f32': ([C.POINTER(GrlBneckTailF32), _fp], C.c_int),
+    'grl_bottleneck_tail_f32_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
 }
 
 _lib = None

@@ -20,7 +20,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import GrlGemm, GrlBneckTail, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF, check, ptr, require_device
+from ._lib import GrlGemm, GrlBneckTail, GrlBneckTailF32, EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF, check, ptr, require_device
 
 import contextlib
 import os
@@ -140,6 +140,7 @@ def augment_normalize_u8(clips, params):
     return y
 
 
+FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
 SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
 
 
@@ -434,18 +435,27 @@ def trunk_eval(plan, x, taps=None):
     H, W = Hp, Wp
     counts = (3, 4, 6, 3)
     bi = 0
+    o1 = None
     for li, nb in enumerate(counts):
         for _ in range(nb):
             e = plan.blocks[bi]
             bi += 1
             s = e['stride']
-            o1, _, _ = _conv_layer(cur, e['c1'], n, H, W)
+            if o1 is None:
+                o1, _, _ = _conv_layer(cur, e['c1'], n, H, W)
             o2, Ho, Wo = _conv_layer(o1, e['c2'], n, H, W, stride=s)
             if e['down'] is not None:
                 res, _, _ = _conv_layer(cur, e['down'], n, H, W, stride=s, relu=False)
             else:
                 res = cur
-            cur, _, _ = _conv_layer(o2, e['c3'], n, Ho, Wo, res=res)
+            nxt = plan.blocks[bi]['c1'] if bi < len(plan.blocks) else None
+            o1 = None
+            if FUSE_BNECK and nxt is not None and _bneck_tail_f32_ok(e['c3'], nxt):
+                # layers 1-2: conv3 + residual + ReLU AND the next block's conv1 in one launch, bit-identical to the two
+                # GEMM launches (fuse_f32.hip) -- the 4P-wide output is written once and never re-read
+                cur, o1 = bneck_tail_f32(o2, e['c3'], res, nxt, n * Ho * Wo)
+            else:
+                cur, _, _ = _conv_layer(o2, e['c3'], n, Ho, Wo, res=res)
             H, W = Ho, Wo
         if taps is not None:
             taps['layer%d' % (li + 1)] = _to_nchw(cur, n, H, W)
@@ -635,9 +645,6 @@ def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     return y, Ho, Wo
 
 
-FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
-
-
 def _bneck_tail_ok(c3, c1n):
     return (c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and
             bool(_lib.load().grl_bottleneck_tail_bf16_supported(c3.K, c3.N, c1n.N)))
@@ -657,6 +664,28 @@ def bneck_tail_bf16(t2, c3, res, c1n, M):
     check(_lib.load().grl_bottleneck_tail_bf16(C.byref(d), _lib.stream()), 'grl_bottleneck_tail_bf16')
     if _DEBUG_SYNC:
         _debug_sync('bneck_tail %s' % ((M, c3.K, c3.N, d.Pn),))
+    return y, u
+
+
+def _bneck_tail_f32_ok(c3, c1n):
+    return (_math[0] == MATH_F32 and c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and
+            bool(_lib.load().grl_bottleneck_tail_f32_supported(c3.K, c3.N, c1n.N)))
+
+
+def bneck_tail_f32(t2, c3, res, c1n, M):
+    """The exact-fp32 twin (grl_bottleneck_tail_f32): bit-identical to conv3 (+res, ReLU) followed by conv1' on
+    grl_conv_gemm_f32's one-chain fp32 datapath."""
+    d = GrlBneckTailF32()
+    y = _new((M, c3.N), t2)
+    d.t2, d.w3, d.scale3, d.shift3, d.res, d.y = ptr(t2), ptr(c3.w), ptr(c3.scale), ptr(c3.shift), ptr(res), ptr(y)
+    d.M, d.P, d.C4, d.Pn = M, c3.K, c3.N, 0
+    u = None
+    if c1n is not None:
+        u = _new((M, c1n.N), t2)
+        d.w1n, d.scale1n, d.shift1n, d.u, d.Pn = ptr(c1n.w), ptr(c1n.scale), ptr(c1n.shift), ptr(u), c1n.N
+    check(_lib.load().grl_bottleneck_tail_f32(C.byref(d), _lib.stream()), 'grl_bottleneck_tail_f32')
+    if _DEBUG_SYNC:
+        _debug_sync('bneck_tail_f32 %s' % ((M, c3.K, c3.N, d.Pn),))
     return y, u
 
 

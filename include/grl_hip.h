@@ -573,6 +573,26 @@ int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn);      /* 1 if the 
 /* w [Pn][C4] (fp32 if !w_is_bf16) -> out [Pn][C4] bf16 in the k order the chained MFMA of grl_bottleneck_tail_bf16 consumes */
 int grl_bneck_perm32(const void* w, int w_is_bf16, void* out, int Pn, int C4, void* stream);
 
+/* The same fusion for the EXACT-fp32 trunk (BASELINE configs[1]; fuse_f32.hip): all operands fp32.  Results are BIT-IDENTICAL
+ * to grl_conv_gemm_f32 (GRL_MATH_F32, one chain) run on conv3 (+res, ReLU) and then on conv1' -- the transposed MFMA
+ * keeps that kernel's documented k-ordered fmaf chain.  w1n is the plain [Pn][C4] weight (no permutation).
+ * Shapes: (P, C4) = (64, 256) with Pn in {0, 64, 128}; (128, 512) with Pn in {0, 128}. */
+typedef struct GrlBneckTailF32 {
+    const float* t2;        /* [M][P]                                                       */
+    const float* w3;        /* [C4][P]                                                      */
+    const float* scale3;    /* [C4] or NULL (= 1)                                           */
+    const float* shift3;    /* [C4] or NULL (= 0)                                           */
+    const float* res;       /* [M][C4]                                                      */
+    float*       y;         /* [M][C4] out                                                  */
+    const float* w1n;       /* [Pn][C4] or NULL                                             */
+    const float* scale1n;   /* [Pn] or NULL                                                 */
+    const float* shift1n;   /* [Pn] or NULL                                                 */
+    float*       u;         /* [M][Pn] out, or NULL                                         */
+    int32_t M, P, C4, Pn;
+} GrlBneckTailF32;
+int grl_bottleneck_tail_f32(const GrlBneckTailF32* desc, void* stream);
+int grl_bottleneck_tail_f32_supported(int P, int C4, int Pn);
+
 #ifdef __cplusplus
 }
 #endif

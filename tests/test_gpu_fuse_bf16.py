@@ -106,3 +106,43 @@ def test_bf16s_eval_with_and_without_the_fused_trunk(dev, synth_models):
     assert torch.equal(f1[:2], f1b)
     rel = float((f1 - f0).norm() / f0.norm())
     assert rel < 1e-2, rel
+
+
+@pytest.mark.parametrize('P,C4,Pn', [(64, 256, 64), (64, 256, 128), (128, 512, 128), (64, 256, 0), (128, 512, 0)])
+@pytest.mark.parametrize('M', [256 * 5, 32 * 3 + 7, 40000])
+def test_bottleneck_tail_f32_is_bit_identical_to_the_two_gemm_launches(dev, P, C4, Pn, M):
+    """Exact-fp32 twin (fuse_f32.hip): the transposed MFMA keeps gemm_f32_kernel's documented k-ordered fmaf chain,
+    so y and u equal the unfused launches BIT FOR BIT (ragged M, every shape)."""
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(P + C4 + Pn + M)
+    c3 = _C(C4, P, g, dev)
+    c1 = _C(Pn, C4, g, dev) if Pn else None
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(dev)
+    res = torch.randn(M, C4, generator=g).to(dev)
+    with engine.math_mode('f32'):
+        y, u = engine.bneck_tail_f32(t2, c3, res, c1, M)
+        y0 = torch.empty(M, C4, device=dev)
+        engine.gemm(t2, c3.w, y0, M, C4, P, scale=c3.scale, shift=c3.shift, res=res, relu=True)
+        assert torch.equal(y, y0), float((y - y0).abs().max())
+        if Pn:
+            u0 = torch.empty(M, Pn, device=dev)
+            engine.gemm(y0, c1.w, u0, M, Pn, C4, scale=c1.scale, shift=c1.shift, relu=True)
+            assert torch.equal(u, u0), float((u - u0).abs().max())
+    yr = torch.relu((t2.double() @ c3.w.double().t()) * c3.scale.double() + c3.shift.double() + res.double())
+    assert float((y.double() - yr).abs().max() / yr.abs().max()) < 1e-5
+
+
+def test_f32_eval_features_identical_with_and_without_the_fused_trunk(dev, synth_models):
+    """End to end, exact fp32 (the headline datapath): the 6144-d feature rows do not change by one bit."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_clips
+    cnn, siam = synth_models[0].to(dev).eval(), synth_models[1].to(dev).eval()
+    clips = synth_clips(3, 4, seed=7).to(dev)
+    with engine.math_mode('f32'):
+        f1 = engine.extract_features(cnn, siam, clips)
+        old, engine.FUSE_BNECK = engine.FUSE_BNECK, False
+        try:
+            f0 = engine.extract_features(cnn, siam, clips)
+        finally:
+            engine.FUSE_BNECK = old
+    assert torch.equal(f1, f0)

@@ -11,6 +11,7 @@ from test_gpu_fuse_bf16 import _C
 dev = torch.device('cuda:0')
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 BF = torch.bfloat16
+F32 = len(sys.argv) > 2 and sys.argv[2] == 'f32'      # python tools/bneck_tail_ab.py 128 f32: the exact-fp32 twin at 32 x 4
 
 
 def timeit(fn, n=20):
@@ -30,10 +31,28 @@ for (P, C4, Pn, px) in ((64, 256, 64, 64 * 32), (64, 256, 128, 64 * 32), (128, 5
     M = frames * px
     g = torch.Generator().manual_seed(1)
     c3, c1 = _C(C4, P, g, dev), _C(Pn, C4, g, dev)
-    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(dev).to(BF)
-    res = torch.randn(M, C4, generator=g).to(dev).to(BF)
-    y0 = torch.empty(M, C4, dtype=BF, device=dev)
-    u0 = torch.empty(M, Pn, dtype=BF, device=dev)
+    if F32 and Pn == 256:
+        continue
+    dt = torch.float32 if F32 else BF
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(dev).to(dt)
+    res = torch.randn(M, C4, generator=g).to(dev).to(dt)
+    y0 = torch.empty(M, C4, dtype=dt, device=dev)
+    u0 = torch.empty(M, Pn, dtype=dt, device=dev)
+    if F32:
+        def unfused():
+            engine.gemm(t2, c3.w, y0, M, C4, P, scale=c3.scale, shift=c3.shift, res=res, relu=True)
+            engine.gemm(y0, c1.w, u0, M, Pn, C4, scale=c1.scale, shift=c1.shift, relu=True)
+
+        def conv3_only():
+            engine.gemm(t2, c3.w, y0, M, C4, P, scale=c3.scale, shift=c3.shift, res=res, relu=True)
+
+        def fused():
+            engine.bneck_tail_f32(t2, c3, res, c1, M)
+        a, b, c = timeit(unfused), timeit(conv3_only), timeit(fused)
+        fl = 2.0 * M * C4 * (P + Pn)
+        print('f32 P %3d C4 %3d Pn %3d M %8d: unfused %7.1f us (conv3 alone %7.1f)  fused %7.1f us = %.1f TFLOP/s, %.2f TB/s compulsory'
+              % (P, C4, Pn, M, a, b, c, fl / c / 1e6, M * (P + 2 * C4 + Pn) * 4 / c / 1e6), flush=True)
+        continue
 
     def unfused():
         engine.gemm(t2, c3.wb(), y0, M, C4, P, scale=c3.scale, shift=c3.shift, res=res, relu=True, math=engine.MATH_BF16S)

@@ -87,15 +87,17 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         return out
 
     def timed_tail_of(fn):
-        def timed_tail(t2, c3, res, c1n, M):
+        def timed_tail(t2, c3, res, c1n, M, **kw):
             # a fused bottleneck tail (fuse_bf16.hip / fuse_f32.hip) carries two of the path's convolutions: conv3 and the
             # next block's conv1 -- counted with the GEMM launches they replace (same algorithmic FLOPs, their own time)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = fn(t2, c3, res, c1n, M)
+            out = fn(t2, c3, res, c1n, M, **kw)
             e1.record()
             pn = c1n.N if c1n is not None else 0
-            recs.append((2.0 * M * c3.N * (c3.K + pn), e0, e1, (M, c3.N, c3.K, 'fused tail + conv1 -> %d' % pn)))
+            kd = kw['down'].K if kw.get('down') is not None else 0         # (+ the block's downsample conv)
+            recs.append((2.0 * M * c3.N * (c3.K + pn + kd), e0, e1,
+                         (M, c3.N, c3.K, 'fused tail + conv1 -> %d%s' % (pn, ' + downsample' if kd else ''))))
             return out
         return timed_tail
 

@@ -40,13 +40,16 @@ class GrlWgrad(C.Structure):
                                     'C', 'Ho', 'Wo', 'kh', 'kw', 'stride', 'pad', 'math', 'in_bf16')]
 
 
-class GrlBneckTail(C.Structure):
-    _fields_ = [(n, _fp) for n in ('t2', 'w3', 'scale3', 'shift3', 'res', 'y', 'w1n', 'scale1n', 'shift1n', 'u')] + \
+_TAIL_FIELDS = [(n, _fp) for n in ('t2', 'w3', 'scale3', 'shift3', 'res', 'y', 'w1n', 'scale1n', 'shift1n', 'u')] + \
                [(n, _i32) for n in ('M', 'P', 'C4', 'Pn')]
 
 
+class GrlBneckTail(C.Structure):
+    _fields_ = _TAIL_FIELDS + [(n, _fp) for n in ('x0', 'wd', 'scaled', 'shiftd')] + [('Kd', _i32), ('reserved', _i32)]
+
+
 class GrlBneckTailF32(C.Structure):
-    _fields_ = GrlBneckTail._fields_
+    _fields_ = _TAIL_FIELDS
 
 
 class GrlPrepEntry(C.Structure):

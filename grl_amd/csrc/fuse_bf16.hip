@@ -88,7 +88,8 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // round-t
 // ds_reads of buffer A and does not put a vmcnt(0) between them (with one dynamic array it does, and the "prefetch" of
 // chunk c + 1 is waited for before chunk c computes).  Chunk boundary: this wave's DMA pieces are older than the
 // Chunk boundary: a counted vmcnt that leaves the youngest residual refills in flight + a raw s_barrier (no fence).
-template <int P, int C4, int PN, int CH, int GB, int PD, int NW>
+// KD > 0: the residual is the block's DOWNSAMPLE branch, computed here: res = bf16(bnd(convd(x0))), x0 [M][KD] (resident variants).
+template <int P, int C4, int PN, int CH, int GB, int PD, int NW, int KD = 0>
 __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail p, const int num_tiles) {
     constexpr int TILE_PX = NW * 16;
     constexpr bool CHAIN = PN > 0;
@@ -98,18 +99,22 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
     constexpr int GPC = CB / GB;              // register groups per chunk
     constexpr int OB = CHAIN ? PN / 16 : 0;   // 16-channel blocks of u
     constexpr int KS1 = CH / 32;              // conv1' k-steps per chunk
-    constexpr int W3_FR = CB * KS3, W1_FR = OB * KS1;
-    constexpr int BUF = (W3_FR + W1_FR) * 1024;
+    constexpr bool DS = KD > 0;
+    constexpr int KSD = DS ? KD / 32 : 0;     // k-steps of the downsample conv
+    constexpr int W3_FR = CB * KS3, W1_FR = OB * KS1, WD_FR = CB * KSD;
+    constexpr int BUF = (W3_FR + W1_FR + WD_FR) * 1024;
     constexpr bool PFN = NCH == 1;            // next tile's conv3 operand prefetched into its own registers at the tile top
     static_assert(P % 32 == 0 && CH % 32 == 0 && C4 % CH == 0 && CB % GB == 0 && GB % 2 == 0, "shape");
-    static_assert(GPC % PD == 0 && (NCH == 1 || NCH % 2 == 0) && (W3_FR + W1_FR) % NW == 0, "pipeline");
+    static_assert(GPC % PD == 0 && (NCH == 1 || NCH % 2 == 0) && (W3_FR + W1_FR + WD_FR) % NW == 0 && (!DS || NCH == 1), "pipeline");
     __shared__ __attribute__((aligned(16))) char bufA[BUF];
     __shared__ __attribute__((aligned(16))) char bufB[NCH > 1 ? BUF : 16];
-    __shared__ __attribute__((aligned(16))) float sc3[C4], sh3[C4], sc1[CHAIN ? PN : 4], sh1[CHAIN ? PN : 4];
+    __shared__ __attribute__((aligned(16))) float sc3[C4], sh3[C4], sc1[CHAIN ? PN : 4], sh1[CHAIN ? PN : 4], scd[DS ? C4 : 4], shd[DS ? C4 : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, q = lane >> 4;
+    const char* const wd = reinterpret_cast<const char*>(p.wd);
+    const uint32_t wdl = (uint32_t)(j * (DS ? KD : 1) + 8 * q) * 2;
     const char* const w3 = reinterpret_cast<const char*>(p.w3);
     const char* const w1 = reinterpret_cast<const char*>(p.w1n);
     // per-lane source offsets of a fragment's 16 bytes: W3 rows are P, W1' rows C4 elements long
@@ -119,11 +124,14 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
     auto stage = [&](int c, char* dst) {
         const uint32_t lds0 = (uint32_t)(size_t)((lptr_t)dst);
 #pragma unroll
-        for (int k = 0; k < (W3_FR + W1_FR) / NW; ++k) {
+        for (int k = 0; k < (W3_FR + W1_FR + WD_FR) / NW; ++k) {
             const int f = wave + k * NW;
             if (f < W3_FR) {
                 const int cb = f / KS3, s = f - cb * KS3;
                 glds16_hidden(w3, w3l + (uint32_t)(((c * CH + 16 * cb) * P + 32 * s) * 2), lds0 + f * 1024);
+            } else if (DS && f >= W3_FR + W1_FR) {
+                const int g = f - W3_FR - W1_FR, cb = g / (DS ? KSD : 1), s = g - cb * (DS ? KSD : 1);
+                glds16_hidden(wd, wdl + (uint32_t)(((c * CH + 16 * cb) * KD + 32 * s) * 2), lds0 + f * 1024);
             } else {
                 const int g = f - W3_FR, ob = g / KS1, s = g - ob * KS1;
                 glds16_hidden(w1, w1l + (uint32_t)((16 * ob * C4 + c * CH + 32 * s) * 2), lds0 + f * 1024);
@@ -139,6 +147,11 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
         for (int i = tid; i < PN; i += NW * 64) {
             sc1[i] = p.scale1n ? p.scale1n[i] : 1.f;
             sh1[i] = p.shift1n ? p.shift1n[i] : 0.f;
+        }
+    if (DS)
+        for (int i = tid; i < C4; i += NW * 64) {
+            scd[i] = p.scaled ? p.scaled[i] : 1.f;
+            shd[i] = p.shiftd ? p.shiftd[i] : 0.f;
         }
     stage(0, bufA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,10 +169,17 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
     int row = tile * TILE_PX + wave * 16 + j;
     uint32_t rowc = (uint32_t)(row < p.M ? row : p.M - 1);
     bf16x8 bfr[KS3];
-    uint4 rr[PD][GB / 2];
+    bf16x8 xfr[DS ? KSD : 1];                   // the downsample conv's operand: this pixel's x0 row
+    const char* const x0 = reinterpret_cast<const char*>(p.x0);
+    uint4 rr[DS ? 1 : PD][GB / 2];
     if (tile < num_tiles) {
 #pragma unroll
         for (int s = 0; s < KS3; ++s) bfr[s] = *reinterpret_cast<const bf16x8*>(t2 + (size_t)(rowc * (uint32_t)(P * 2) + 64 * s + q16));
+        if (DS) {
+#pragma unroll
+            for (int s = 0; s < KSD; ++s) xfr[s] = *reinterpret_cast<const bf16x8*>(x0 + (size_t)(rowc * (uint32_t)(KD * 2) + 64 * s + q16));
+        }
+        if (!DS)
 #pragma unroll
         for (int k = 0; k < PD; ++k)
 #pragma unroll
@@ -176,9 +196,14 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
         const uint32_t rowcn = has_next ? (uint32_t)(rown < p.M ? rown : p.M - 1) : rowc;
         const bool live = row < p.M;
         bf16x8 bfn[PFN ? KS3 : 1];
+        bf16x8 xfn[DS ? KSD : 1];
         if (PFN && has_next) {
 #pragma unroll
             for (int s = 0; s < KS3; ++s) bfn[s] = *reinterpret_cast<const bf16x8*>(t2 + (size_t)(rowcn * (uint32_t)(P * 2) + 64 * s + q16));
+            if (DS) {
+#pragma unroll
+                for (int s = 0; s < KSD; ++s) xfn[s] = *reinterpret_cast<const bf16x8*>(x0 + (size_t)(rowcn * (uint32_t)(KD * 2) + 64 * s + q16));
+            }
         }
         f32x4 acc1[CHAIN ? OB : 1];
 #pragma unroll
@@ -206,9 +231,10 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
             }
             const char* const w3f = mine;
             const char* const w1f = mine + W3_FR * 1024;
+            const char* const wdf = mine + (W3_FR + W1_FR) * 1024;
 #pragma unroll
             for (int gi = 0; gi < GPC; ++gi) {
-                const int slot = gi % PD;                           // (compile-time: PD divides the groups of a chunk)
+                const int slot = DS ? 0 : gi % PD;                  // (compile-time: PD divides the groups of a chunk)
                 const int ch0 = (c * CB + gi * GB) * 16;            // first channel of the group
                 f32x4 acc3[GB];
 #pragma unroll
@@ -220,12 +246,32 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
                         const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3f + ((gi * GB + b) * KS3 + s) * 1024 + lane * 16);
                         acc3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[s], acc3[b], 0, 0, 0);
                     }
+                f32x4 accd[DS ? GB : 1];
+                if (DS) {                       // the downsample branch of the same pixels, same blocks
+#pragma unroll
+                    for (int b = 0; b < GB; ++b) accd[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KSD; ++s)
+#pragma unroll
+                        for (int b = 0; b < GB; ++b) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wdf + ((gi * GB + b) * KSD + s) * 1024 + lane * 16);
+                            accd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xfr[s], accd[b], 0, 0, 0);
+                        }
+                }
 #pragma unroll
                 for (int t = 0; t < GB / 2; ++t) {
-                    uint32_t ax = rr[slot][t].x, ay = rr[slot][t].y, bx = rr[slot][t].z, by = rr[slot][t].w;
-                    swap16(ax, bx);             // 16 contiguous bytes per lane -> this lane's 4 channels of block 2t | of block 2t+1
-                    swap16(ay, by);
+                    uint32_t ax, ay, bx, by;
                     const int cA = ch0 + 32 * t + 4 * q, cB = cA + 16;
+                    if (DS) {                   // res = bf16(acc * scale_d + shift_d): the value the unfused launch stores and conv3 re-reads
+                        const f32x4 dA = accd[2 * t] * *reinterpret_cast<const f32x4*>(scd + cA) + *reinterpret_cast<const f32x4*>(shd + cA);
+                        const f32x4 dB = accd[2 * t + 1] * *reinterpret_cast<const f32x4*>(scd + cB) + *reinterpret_cast<const f32x4*>(shd + cB);
+                        ax = pack2(dA[0], dA[1]); ay = pack2(dA[2], dA[3]);
+                        bx = pack2(dB[0], dB[1]); by = pack2(dB[2], dB[3]);
+                    } else {
+                        ax = rr[slot][t].x; ay = rr[slot][t].y; bx = rr[slot][t].z; by = rr[slot][t].w;
+                        swap16(ax, bx);         // 16 contiguous bytes per lane -> this lane's 4 channels of block 2t | of block 2t+1
+                        swap16(ay, by);
+                    }
                     const f32x4 sA = *reinterpret_cast<const f32x4*>(sc3 + cA), hA = *reinterpret_cast<const f32x4*>(sh3 + cA);
                     const f32x4 sB = *reinterpret_cast<const f32x4*>(sc3 + cB), hB = *reinterpret_cast<const f32x4*>(sh3 + cB);
                     f32x4 vA = acc3[2 * t] * sA + hA, vB = acc3[2 * t + 1] * sB + hB;
@@ -254,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
                     __builtin_amdgcn_sched_barrier(0);      // keep the block pairs in program order: hoisted A-fragment reads spill
                 }
                 // refill this slot: PD groups ahead -- same chunk, the next chunk, or chunk 0 of the next tile
-                {
+                if (!DS) {
                     const int gn = gi + PD;                          // compile-time
                     const bool wrap = gn >= GPC && c + 1 == NCH;     // ... of the next tile
                     if (!wrap || has_next) {
@@ -307,6 +353,10 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_kernel(const GrlBneckTail 
         if (PFN && has_next) {
 #pragma unroll
             for (int s = 0; s < KS3; ++s) bfr[s] = bfn[s];
+            if (DS) {
+#pragma unroll
+                for (int s = 0; s < KSD; ++s) xfr[s] = xfn[s];
+            }
         }
         tile = ntile;
         row = rown;
@@ -328,11 +378,11 @@ __global__ void bneck_perm_kernel(const T* __restrict__ w, __bf16* __restrict__ 
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <int P, int C4, int PN, int CH, int GB = 4, int PD = 4, int NW = 16>
+template <int P, int C4, int PN, int CH, int GB = 4, int PD = 4, int NW = 16, int KD = 0>
 int launch(const GrlBneckTail& d, hipStream_t s) {
     constexpr int NCH = C4 / CH;
-    constexpr int FR = (CH / 16) * (P / 32) + (PN / 16) * (CH / 32);
-    constexpr int LDS = (2 * C4 + 2 * PN) * 4 + (NCH > 1 ? 2 : 1) * FR * 1024;      // static, in the kernel descriptor
+    constexpr int FR = (CH / 16) * (P / 32) + (PN / 16) * (CH / 32) + (CH / 16) * (KD / 32);
+    constexpr int LDS = (2 * C4 + 2 * PN + (KD ? 2 * C4 : 0)) * 4 + (NCH > 1 ? 2 : 1) * FR * 1024;      // static, in the kernel descriptor
     static_assert(LDS <= 160 * 1024 - 64, "LDS");
     static const int cus = [] {
         int dev = 0, n = 256;
@@ -344,7 +394,7 @@ int launch(const GrlBneckTail& d, hipStream_t s) {
     constexpr int TILE_PX = NW * 16;
     const int num_tiles = (d.M + TILE_PX - 1) / TILE_PX;
     const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
-    hipLaunchKernelGGL((bneck_tail_kernel<P, C4, PN, CH, GB, PD, NW>), dim3(grid), dim3(NW * 64), 0, s, d, num_tiles);
+    hipLaunchKernelGGL((bneck_tail_kernel<P, C4, PN, CH, GB, PD, NW, KD>), dim3(grid), dim3(NW * 64), 0, s, d, num_tiles);
     return grl_check_launch("grl_bottleneck_tail_bf16");
 }
 
@@ -368,7 +418,11 @@ extern "C" int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn) {
 extern "C" int grl_bottleneck_tail_bf16(const GrlBneckTail* dp, void* stream) {
     if (!dp) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: null descriptor");
     const GrlBneckTail& d = *dp;
-    if (d.M <= 0 || !d.t2 || !d.w3 || !d.res || !d.y) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: null operand or M <= 0");
+    if (d.M <= 0 || !d.t2 || !d.w3 || !d.y) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: null operand or M <= 0");
+    if (d.Kd > 0 ? (!d.x0 || !d.wd || !al16(d.x0) || !al16(d.wd)) : !d.res)
+        return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: needs res, or (Kd > 0) x0 and wd, 16-byte aligned");
+    if (d.Kd > 0 && !(d.P == 64 && d.C4 == 256 && d.Pn == 64 && d.Kd == 64))
+        return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: the fused downsample branch exists for P 64, C4 256, Pn 64, Kd 64 only");
     if (d.Pn > 0 && (!d.w1n || !d.u)) return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: Pn > 0 needs w1n and u");
     if (!al16(d.t2) || !al16(d.w3) || !al16(d.res) || !al16(d.y) || !al16(d.w1n) || !al16(d.u))
         return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: operands must be 16-byte aligned");
@@ -377,6 +431,7 @@ extern "C" int grl_bottleneck_tail_bf16(const GrlBneckTail* dp, void* stream) {
         return grl_fail(GRL_EINVAL, "grl_bottleneck_tail_bf16: unsupported shape P %d, C4 %d, Pn %d", d.P, d.C4, d.Pn);
     hipStream_t s = (hipStream_t)stream;
     if (d.P == 64) {
+        if (d.Pn == 64 && d.Kd == 64) return launch<64, 256, 64, 256, 4, 4, 16, 64>(d, s);
         if (d.Pn == 64) return launch<64, 256, 64, 256>(d, s);
         if (d.Pn == 128) return launch<64, 256, 128, 256>(d, s);
         return launch<64, 256, 0, 256>(d, s);

@@ -141,6 +141,7 @@ def augment_normalize_u8(clips, params):
 
 
 FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
+FUSE_DOWN = os.environ.get('GRL_FUSE_DOWN', '1') != '0'         # A/B and tests: 0 = the downsample conv as its own launch
 SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
 
 
@@ -650,13 +651,23 @@ def _bneck_tail_ok(c3, c1n):
             bool(_lib.load().grl_bottleneck_tail_bf16_supported(c3.K, c3.N, c1n.N)))
 
 
-def bneck_tail_bf16(t2, c3, res, c1n, M):
+def _bneck_down_ok(c3, c1n, down, stride):
+    """The block's downsample branch (1x1, stride 1: layer 1's first block) can ride in the same launch."""
+    return (down is not None and stride == 1 and down.k == 1 and c1n is not None and
+            (c3.K, c3.N, c1n.N, down.K) == (64, 256, 64, 64))
+
+
+def bneck_tail_bf16(t2, c3, res, c1n, M, down=None, x0=None):
     """y = relu(bn3(conv3(t2)) + res) [M][4P] and u = relu(bn1'(conv1'(y))) [M][P'] in one launch
-    (grl_bottleneck_tail_bf16; resnets1.py:86-91 + :76-78 of the next block).  c1n None: y only."""
+    (grl_bottleneck_tail_bf16; resnets1.py:86-91 + :76-78 of the next block).  c1n None: y only.
+    ``down`` / ``x0``: the residual is the block's downsample branch bnd(convd(x0)) (resnets1.py:83-84), computed in
+    the same launch instead of being written by one launch and re-read by this one (``res`` is ignored)."""
     d = GrlBneckTail()
     y = _newb((M, c3.N), t2)
     d.t2, d.w3, d.scale3, d.shift3, d.res, d.y = ptr(t2), ptr(c3.wb()), ptr(c3.scale), ptr(c3.shift), ptr(res), ptr(y)
     d.M, d.P, d.C4, d.Pn = M, c3.K, c3.N, 0
+    if down is not None:
+        d.x0, d.wd, d.scaled, d.shiftd, d.Kd = ptr(x0), ptr(down.wb()), ptr(down.scale), ptr(down.shift), down.K
     u = None
     if c1n is not None:
         u = _newb((M, c1n.N), t2)
@@ -717,15 +728,20 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
         if o1 is None:
             o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
         o2, Ho, Wo = _conv_b16(o1, e['c2'], n, H, W, stride=s)
-        res = _conv_b16(cur, e['down'], n, H, W, stride=s, relu=False)[0] if e['down'] is not None else cur
         nxt = plan.blocks[bi + 1]['c1'] if bi + 1 < len(plan.blocks) else None
+        fuse = FUSE_BNECK and nxt is not None and _bneck_tail_ok(e['c3'], nxt)
         o1 = None
-        if FUSE_BNECK and nxt is not None and _bneck_tail_ok(e['c3'], nxt):
-            # layers 1-2: conv3 + residual + ReLU AND the next block's conv1 in one launch -- the 4P-wide output is
-            # written once (the next block's residual) and never re-read (fuse_bf16.hip)
-            cur, o1 = bneck_tail_bf16(o2, e['c3'], res, nxt, n * Ho * Wo)
+        if fuse and FUSE_DOWN and _bneck_down_ok(e['c3'], nxt, e['down'], s):
+            # layer 1's first block: the downsample branch too -- its 4P-wide output is neither written nor re-read
+            cur, o1 = bneck_tail_bf16(o2, e['c3'], None, nxt, n * Ho * Wo, down=e['down'], x0=cur)
         else:
-            cur, _, _ = _conv_b16(o2, e['c3'], n, Ho, Wo, res=res)
+            res = _conv_b16(cur, e['down'], n, H, W, stride=s, relu=False)[0] if e['down'] is not None else cur
+            if fuse:
+                # layers 1-2: conv3 + residual + ReLU AND the next block's conv1 in one launch -- the 4P-wide output is
+                # written once (the next block's residual) and never re-read (fuse_bf16.hip)
+                cur, o1 = bneck_tail_bf16(o2, e['c3'], res, nxt, n * Ho * Wo)
+            else:
+                cur, _, _ = _conv_b16(o2, e['c3'], n, Ho, Wo, res=res)
         H, W = Ho, Wo
     x4 = cur
     M = x4.shape[0]

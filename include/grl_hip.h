@@ -567,6 +567,13 @@ typedef struct GrlBneckTail {
     const float* shift1n;   /* [Pn] or NULL                                                 */
     void*        u;         /* [M][Pn] bf16 out, or NULL                                    */
     int32_t M, P, C4, Pn;
+    /* Kd > 0: the residual is the block's DOWNSAMPLE branch computed in the same launch (resnets1.py:83-84, the first
+     * block of a layer): res = bf16(scaled * (wd . x0) + shiftd); `res` is ignored.  (P, C4, Pn, Kd) = (64, 256, 64, 64). */
+    const void*  x0;        /* [M][Kd] bf16: the block's input                              */
+    const void*  wd;        /* [C4][Kd] bf16: downsample conv weight                        */
+    const float* scaled;    /* [C4] or NULL                                                 */
+    const float* shiftd;    /* [C4] or NULL                                                 */
+    int32_t Kd, reserved;
 } GrlBneckTail;
 int grl_bottleneck_tail_bf16(const GrlBneckTail* desc, void* stream);
 int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn);      /* 1 if the shape has a kernel */

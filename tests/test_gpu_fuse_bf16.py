@@ -74,6 +74,30 @@ def test_bottleneck_tail_matches_torch_and_the_unfused_launches(dev, P, C4, Pn, 
         assert u is None
 
 
+@pytest.mark.parametrize('M', [256 * 7, 16 * 5 + 3, 50000])
+def test_bottleneck_tail_with_the_downsample_branch_in_the_same_launch(dev, M):
+    """Layer 1's first block: res = bn_d(conv_d(x0)) is computed inside the launch -- against the unfused sequence
+    (downsample GEMM writes bf16 res, the tail reads it): same roundings, so the same values up to fp32 summation order."""
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(M)
+    c3, c1, dn = _C(256, 64, g, dev), _C(64, 256, g, dev), _C(256, 64, g, dev)
+    t2 = torch.randn(M, 64, generator=g).clamp_min(0).to(dev).to(BF)
+    x0 = torch.randn(M, 64, generator=g).clamp_min(0).to(dev).to(BF)
+    y, u = engine.bneck_tail_bf16(t2, c3, None, c1, M, down=dn, x0=x0)
+    res = torch.empty(M, 256, dtype=BF, device=dev)
+    engine.gemm(x0, dn.wb(), res, M, 256, 64, scale=dn.scale, shift=dn.shift, relu=False, math=engine.MATH_BF16S)
+    y0, u0 = engine.bneck_tail_bf16(t2, c3, res, c1, M)
+    # the residual is rounded to bf16 in both paths; where its fp32 value sits on a rounding boundary the two paths may
+    # round it apart by one bf16 step OF THE RESIDUAL -- which can exceed a step of y where the sum cancels
+    err = (y.float() - y0.float()).abs()
+    assert bool((err <= (y0.float().abs() + res.float().abs()) * 2.0 ** -7 + 1e-4).all()), float(err.max())
+    assert float((y == y0).float().mean()) > 0.99
+    assert float((u.float() - u0.float()).norm() / u0.float().norm()) < 1e-3
+    resr = ((x0.float() @ dn.wb().float().t()) * dn.scale + dn.shift)
+    yr = torch.relu(t2.float() @ c3.wb().float().t() * c3.scale + c3.shift + resr)
+    assert float((y.float() - yr).norm() / yr.norm()) < 4e-3
+
+
 def test_bottleneck_tail_rows_do_not_depend_on_the_batch(dev):
     """A pixel's outputs are the same bits whatever tile / grid / batch it is computed in (each wave owns whole
     pixels): rows [0, 300) of a 5000-row launch equal a 300-row launch."""

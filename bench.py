@@ -76,7 +76,7 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     launch, counted by the host wrapper) / sum of their measured durations."""
     from grl_amd import engine
     recs = []
-    orig, orig_tail, orig_tail32 = engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32
+    orig, orig_tail, orig_tail32, orig_c64 = engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32, engine.conv3x3_c64_bf16
 
     def timed(a, w, y, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -101,16 +101,25 @@ def gemm_roofline(cnn, siam, clips, iters=3):
             return out
         return timed_tail
 
+    def timed_c64(x, c, n_img, H, W, relu=True):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_c64(x, c, n_img, H, W, relu)
+        e1.record()
+        recs.append((2.0 * n_img * H * W * 64 * 576, e0, e1, (n_img * H * W, 64, 576, 'conv3x3_c64')))
+        return out
+
     streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
     engine.extract_features(cnn, siam, clips)                   # untimed: the caching allocator re-settles on one stream
     torch.cuda.synchronize()                                    # (a hipMalloc between two events would count as GEMM time)
     engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32 = timed, timed_tail_of(orig_tail), timed_tail_of(orig_tail32)
+    engine.conv3x3_c64_bf16 = timed_c64
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)
         torch.cuda.synchronize()
     finally:
-        engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32 = orig, orig_tail, orig_tail32
+        engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32, engine.conv3x3_c64_bf16 = orig, orig_tail, orig_tail32, orig_c64
         engine.TRL_STREAMS = streams
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters

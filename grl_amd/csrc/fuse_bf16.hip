@@ -376,6 +376,155 @@ __global__ void bneck_perm_kernel(const T* __restrict__ w, __bf16* __restrict__ 
     out[i] = (__bf16)(float)w[(i & ~(int64_t)31) + src];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 convolution of layer 1 (64 -> 64 channels on 64 x 32 maps; resnets1.py:79-81) + folded BatchNorm + ReLU.
+//
+// As an implicit GEMM on the generic kernel this shape moves 221 KB out of L2 per 128 x 64 tile for 9.4 MFLOP (every
+// input pixel is gathered nine times, the 74 KB weight matrix once per tile): it runs at the L2 -> CU limit, 17 % MFMA
+// busy, 3.5x its HBM time.  Here the persistent workgroup keeps ALL weights in LDS (72 fragments of 1 KiB, A operand of
+// the transposed 16x16x32 MFMA) and stages each tile's input patch ONCE -- 10 rows x 32 pixels x 128 B for 8 output
+// rows, double-buffered, filled by LDS-DMA with the 16-byte chunk index XOR-swizzled by the pixel on the SOURCE side
+// (conflict-free tap reads); out-of-frame rows come from a zero page, the two out-of-row taps are masked per lane.
+// A wave owns one output row (32 pixels = two MFMA column blocks sharing every weight fragment).
+__device__ uint4 g_zero_px[8];                 // 128 zero bytes
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_c64_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              __bf16* __restrict__ y, const int H, const int tiles_per_img,
+                                                              const int num_tiles, const int relu) {
+    constexpr int TH = NW;                    // output rows per tile (one per wave)
+    constexpr int PR = TH + 2;                // patch rows
+    constexpr int PATCH = PR * 32 * 128;      // bytes
+    constexpr int NFR = 4 * 18;               // weight fragments: 4 output blocks x (9 taps x 2 channel halves)
+    static_assert((PR * 4) % NW == 0 && NFR % NW == 0, "staging");
+    __shared__ __attribute__((aligned(16))) char wf[NFR * 1024];
+    __shared__ __attribute__((aligned(16))) char patA[PATCH];
+    __shared__ __attribute__((aligned(16))) char patB[PATCH];
+    __shared__ __attribute__((aligned(16))) float scs[64], shs[64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const char* const x8 = reinterpret_cast<const char*>(x);
+
+    if (tid < 64) {
+        scs[tid] = scale ? scale[tid] : 1.f;
+        shs[tid] = shift ? shift[tid] : 0.f;
+    }
+    {   // weights: fragment (ob, ks) lane (i, qq) = w[16ob + i][32ks + 8qq .. +7]; k = tap*64 + channel
+        const uint32_t wl = (uint32_t)(j * 576 + 8 * q) * 2;
+        const uint32_t lds0 = (uint32_t)(size_t)((lptr_t)wf);
+#pragma unroll
+        for (int k = 0; k < NFR / NW; ++k) {
+            const int f = wave + k * NW, ob = f / 18, ks = f - ob * 18;
+            glds16_hidden(reinterpret_cast<const char*>(w), wl + (uint32_t)((16 * ob * 576 + 32 * ks) * 2), lds0 + f * 1024);
+        }
+    }
+    // patch of tile t -> buffer: DMA piece d covers 8 pixels (row d / 4, pixels 8 (d % 4) ..): lane l = (pixel l / 8, LDS chunk
+    // l % 8); the chunk it fetches is (l % 8) ^ swz(pixel), so that LDS position c' of a pixel holds source chunk c' ^ swz
+    const int dpx = lane >> 3, dch = lane & 7;
+    auto swz = [](int px) { return (px ^ (px >> 3)) & 7; };
+    auto stage = [&](int t, char* dst) {
+        const int img = t / tiles_per_img, ty = t - img * tiles_per_img;
+        const uint32_t lds0 = (uint32_t)(size_t)((lptr_t)dst);
+        const char* const zero = reinterpret_cast<const char*>(g_zero_px);
+#pragma unroll
+        for (int k = 0; k < (PR * 4) / NW; ++k) {
+            const int d = wave + k * NW, r = d >> 2, px = 8 * (d & 3) + dpx;
+            const int iy = ty * TH - 1 + r;
+            const bool ok = iy >= 0 && iy < H;                      // wave-uniform
+            const uint32_t off = ok ? (uint32_t)((((img * H + iy) * 32 + px) * 64 + 8 * (dch ^ swz(px))) * 2) : (uint32_t)(dch * 16);
+            glds16_hidden(ok ? x8 : zero, off, lds0 + d * 1024);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < num_tiles) stage(tile, patA);
+    const uint32_t sw_b = (uint32_t)(16 * (q & 1) + 8 * (q >> 1)) * 2;
+
+    auto compute = [&](int t, const char* const pat) {
+        const int img = t / tiles_per_img, ty = t - img * tiles_per_img;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) acc[pb][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3 - 1;               // patch row = wave + dy
+            bf16x8 b[2][2];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int px = 16 * pb + j + dx;
+                const bool ok = px >= 0 && px < 32;
+                const int pc = ok ? px : (px < 0 ? 0 : 31);
+                const char* const row = pat + ((wave + dy) * 32 + pc) * 128;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    uint4 v = *reinterpret_cast<const uint4*>(row + (((4 * ch + q) ^ swz(pc)) << 4));
+                    if (!ok) v = uint4{0u, 0u, 0u, 0u};
+                    b[pb][ch] = *reinterpret_cast<bf16x8*>(&v);
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wf + (ob * 18 + 2 * tap + ch) * 1024 + lane * 16);
+                    acc[0][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0][ch], acc[0][ob], 0, 0, 0);
+                    acc[1][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1][ch], acc[1][ob], 0, 0, 0);
+                }
+        }
+        const int oy = ty * TH + wave;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const uint32_t orow = (uint32_t)((((img * H + oy) * 32) + 16 * pb + j) * 128);
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int cA = 32 * t2 + 4 * q, cB = cA + 16;
+                f32x4 vA = acc[pb][2 * t2] * *reinterpret_cast<const f32x4*>(scs + cA) + *reinterpret_cast<const f32x4*>(shs + cA);
+                f32x4 vB = acc[pb][2 * t2 + 1] * *reinterpret_cast<const f32x4*>(scs + cB) + *reinterpret_cast<const f32x4*>(shs + cB);
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vA[e] = vA[e] > 0.f ? vA[e] : 0.f;
+                        vB[e] = vB[e] > 0.f ? vB[e] : 0.f;
+                    }
+                }
+                uint32_t ax = pack2(vA[0], vA[1]), ay = pack2(vA[2], vA[3]);
+                uint32_t bx = pack2(vB[0], vB[1]), by = pack2(vB[2], vB[3]);
+                swap16(ax, bx);
+                swap16(ay, by);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (size_t)(orow + 64 * t2 + sw_b)) = uint4{ax, ay, bx, by};
+            }
+        }
+    };
+
+    // tile loop, two tiles per trip so that every LDS-DMA target and every tap read names its buffer at compile time.
+    // Per tile: this wave's patch pieces are the oldest operations it has in flight, the 4 output stores of the previous
+    // tile the only younger ones (every lane stores: the geometry has no ragged edge) -> vmcnt(4), barrier, next DMA.
+    bool first = true;
+#pragma unroll 1
+    for (; tile < num_tiles;) {
+        if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // weights, first patch, the scale / shift vectors
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        first = false;
+        const int t1 = tile + (int)gridDim.x;
+        if (t1 < num_tiles) stage(t1, patB);
+        compute(tile, patA);
+        if (t1 >= num_tiles) break;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int t2 = t1 + (int)gridDim.x;
+        if (t2 < num_tiles) stage(t2, patA);
+        compute(t1, patB);
+        tile = t2;
+    }
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <int P, int C4, int PN, int CH, int GB = 4, int PD = 4, int NW = 16, int KD = 0>
@@ -409,6 +558,26 @@ extern "C" int grl_bneck_perm32(const void* w, int w_is_bf16, void* out, int Pn,
     else
         hipLaunchKernelGGL(bneck_perm_kernel<float>, dim3(grl_ceil_div(total, 256)), dim3(256), 0, s, (const float*)w, (__bf16*)out, total);
     return grl_check_launch("grl_bneck_perm32");
+}
+
+extern "C" int grl_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int n_img,
+                                    int H, int W, int relu, void* stream) {
+    if (!x || !w || !y || n_img <= 0) return grl_fail(GRL_EINVAL, "grl_conv3x3_c64_bf16: null operand");
+    if (W != 32 || H % 8 || H <= 0) return grl_fail(GRL_EINVAL, "grl_conv3x3_c64_bf16: needs W == 32 and H %% 8 == 0 (got %d x %d)", H, W);
+    if (!al16(x) || !al16(w) || !al16(y)) return grl_fail(GRL_EINVAL, "grl_conv3x3_c64_bf16: operands must be 16-byte aligned");
+    if ((int64_t)n_img * H * W * 128 >= (1ll << 32)) return grl_fail(GRL_EINVAL, "grl_conv3x3_c64_bf16: tensor too large for 32-bit offsets");
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        return n;
+    }();
+    const int tiles_per_img = H / 8, num_tiles = n_img * tiles_per_img;
+    const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
+    hipLaunchKernelGGL((conv3x3_c64_kernel<8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)w,
+                       scale, shift, (__bf16*)y, H, tiles_per_img, num_tiles, relu);
+    return grl_check_launch("grl_conv3x3_c64_bf16");
 }
 
 extern "C" int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn) {

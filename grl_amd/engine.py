@@ -630,7 +630,21 @@ def _newb(shape, like):
     return torch.empty(shape, dtype=torch.bfloat16, device=like.device)
 
 
+FUSE_C64 = os.environ.get('GRL_CONV3X3_C64', '1') != '0'        # A/B and tests: 0 = layer 1's 3x3 convs on the generic kernel
+
+
+def conv3x3_c64_bf16(x, c, n_img, H, W, relu=True):
+    """Layer 1's 3x3 / stride 1, 64 -> 64 channels, W == 32 (resnets1.py:79-81): weights LDS-resident, each input pixel
+    staged once per tile (grl_conv3x3_c64_bf16)."""
+    y = _newb((n_img * H * W, 64), x)
+    _call('grl_conv3x3_c64_bf16', ptr(x), ptr(c.wb()), ptr(c.scale), ptr(c.shift), ptr(y), n_img, H, W, 1 if relu else 0)
+    return y
+
+
 def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
+    if (FUSE_C64 and c.k == 3 and stride == 1 and c.cin == 64 and c.N == 64 and W == 32 and H % 8 == 0 and res is None
+            and not kw):
+        return conv3x3_c64_bf16(x, c, n_img, H, W, relu), H, W
     if c.k == 1 and stride == 1:
         M = n_img * H * W
         y = _newb((M, c.N), x)

@@ -580,6 +580,12 @@ int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn);      /* 1 if the 
 /* w [Pn][C4] (fp32 if !w_is_bf16) -> out [Pn][C4] bf16 in the k order the chained MFMA of grl_bottleneck_tail_bf16 consumes */
 int grl_bneck_perm32(const void* w, int w_is_bf16, void* out, int Pn, int C4, void* stream);
 
+/* Layer 1's 3x3 / stride 1 convolution (64 -> 64 channels, maps W == 32 wide, H % 8 == 0; resnets1.py:79-81) + folded
+ * BatchNorm + optional ReLU, bf16 storage: weights LDS-resident, every input pixel staged once per tile (fuse_bf16.hip).
+ * x [n_img][H][W][64] bf16, w [64][9*64] bf16 packed tap-major (grl_pack_conv_weight + grl_cast_bf16), y [n_img*H*W][64]. */
+int grl_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift, void* y, int n_img, int H, int W,
+                         int relu, void* stream);
+
 /* The same fusion for the EXACT-fp32 trunk (BASELINE configs[1]; fuse_f32.hip): all operands fp32.  Results are BIT-IDENTICAL
  * to grl_conv_gemm_f32 (GRL_MATH_F32, one chain) run on conv3 (+res, ReLU) and then on conv1' -- the transposed MFMA
  * keeps that kernel's documented k-ordered fmaf chain.  w1n is the plain [Pn][C4] weight (no permutation).

@@ -170,3 +170,34 @@ def test_f32_eval_features_identical_with_and_without_the_fused_trunk(dev, synth
         finally:
             engine.FUSE_BNECK = old
     assert torch.equal(f1, f0)
+
+
+@pytest.mark.parametrize('n,H', [(3, 64), (1, 8), (5, 16)])
+def test_conv3x3_c64_matches_the_generic_kernel_and_torch(dev, n, H):
+    """Layer 1's 3x3 (64 -> 64, W = 32): the LDS-resident-weight kernel against the generic implicit-GEMM launch it
+    replaces and against torch conv2d in fp32 on the same bf16 operands (zero padding at the frame borders, tiles of 8
+    rows, frames of different heights)."""
+    import torch.nn.functional as F
+    from grl_amd import engine
+    g = torch.Generator().manual_seed(n * 100 + H)
+    W = 32
+    w4 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(dev)
+    wp = torch.empty(64, 576, device=dev)
+    engine._call('grl_pack_conv_weight', engine.ptr(w4), engine.ptr(wp), 64, 64, 3, 3)
+    c = _C(64, 576, g, dev)
+    c.w, c.k, c.cin = wp, 3, 64
+    x = torch.randn(n * H * W, 64, generator=g).to(dev).to(BF)
+    old, engine.FUSE_C64 = engine.FUSE_C64, True
+    try:
+        y, _, _ = engine._conv_b16(x, c, n, H, W)
+        engine.FUSE_C64 = False
+        y0, _, _ = engine._conv_b16(x, c, n, H, W)
+    finally:
+        engine.FUSE_C64 = old
+    xr = x.float().view(n, H, W, 64).permute(0, 3, 1, 2)
+    wr = c.wb().float().view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    yr = torch.relu(F.conv2d(xr, wr, padding=1) * c.scale.view(1, -1, 1, 1) + c.shift.view(1, -1, 1, 1))
+    yr = yr.permute(0, 2, 3, 1).reshape(-1, 64)
+    _close_bf16(y.float(), yr, ulps=1.0)
+    _close_bf16(y.float(), y0.float(), ulps=2.0)
+    assert float((y == y0).float().mean()) > 0.99

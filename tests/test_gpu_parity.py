@@ -283,6 +283,12 @@ def test_train_forward_backward_chaotic_weights_stress(golden, B, T, seed, fname
     assert not bad, bad
 
 
+# B = 4 clips = 2 pairs on the default (un-conditioned) weights: BatchNorm1d over TWO rows divides by a variance of a few
+# 1e-6, which amplifies fp32 summation-order noise by ~1/sqrt(eps + var) -- the 1e-3 pin of every Siamese gradient lives in
+# test_trainer_step_matches_reference_trainer_golden_1e3 (conditioned weights, B = 8); this fixture is the stress case.
+SIAMESE_B4T4_GRAD_TOL = 1e-3
+
+
 def test_siamese_train_matches_reference_golden(golden):
     g = golden('siamese_b4t4.npz')
     _, siam, _ = _fresh_models()
@@ -292,9 +298,10 @@ def test_siamese_train_matches_reference_golden(golden):
     assert _rel(cls.detach().cpu().numpy(), g['train.cls']) < 1e-3
     assert _rel(out.detach().cpu().numpy(), g['train.out']) < 1e-4
     ((out * torch.from_numpy(g['train.rr']).cuda()).sum() + (cls * torch.from_numpy(g['train.rc']).cuda()).sum()).backward()
-    assert _rel(x.grad.cpu().numpy(), g['train.grad_x']) < 2e-3
-    assert _rel(siam.featQ.weight.grad[:, ::64].cpu().numpy(), g['train.grad_featQ_w']) < 2e-3
-    assert _rel(siam.classifierlinear.weight.grad.cpu().numpy(), g['train.grad_cls_w']) < 2e-3
+    e = (_rel(x.grad.cpu().numpy(), g['train.grad_x']), _rel(siam.featQ.weight.grad[:, ::64].cpu().numpy(), g['train.grad_featQ_w']),
+         _rel(siam.classifierlinear.weight.grad.cpu().numpy(), g['train.grad_cls_w']))
+    print('siamese_b4t4 gradient errors (grad_x, featQ.weight, classifier.weight): %.2e %.2e %.2e' % e)
+    assert max(e) < SIAMESE_B4T4_GRAD_TOL
     assert _rel(siam.featQ_bn.running_mean.cpu().numpy(), g['train.featQ_bn_rm']) < 1e-4
 
 
@@ -724,8 +731,8 @@ def test_trainer_loss_composition_matches_cpu_restatement():
     _, vout = O.siamese_video_forward(svd, xu, train=True)
     l_unc, _ = O.oim_loss(vout, target, lut_u.clone(), 30.0, 0.5)
     ref = l_unc + l_frame + l_vid + 20 * l_ver + l_tri
-    print('trainer loss hip %.6f cpu %.6f' % (loss.item(), ref.item()))
-    assert abs(loss.item() - ref.item()) < 2e-3 * max(1.0, abs(ref.item()))
+    print('trainer loss hip %.6f cpu %.6f (rel %.2e)' % (loss.item(), ref.item(), abs(loss.item() - ref.item()) / abs(ref.item())))
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item()))
 
 
 def test_backward_is_linear_in_the_upstream_gradient():

@@ -21,12 +21,12 @@ from collections import defaultdict
 
 
 def short(name):
-    for tag in ('gemm_f32_kernel', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
+    for tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
                 'temporal_mean', 'add_strided', 'channel_hidden', 'channel_atte_out', 'affine_l2norm',
                 'siamese_attn', 'mean_T', 'row_sqnorm', 'pair_verify', 'bn_fold', 'pack_conv_weight'):
         if tag in name:
-            if tag == 'gemm_f32_kernel':
-                return name[name.index('gemm_f32_kernel'):].split('(')[0]
+            if tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel'):
+                return name[name.index(tag):].split('(')[0]
             return tag
     return 'other:' + name[:40]
 
@@ -83,13 +83,13 @@ def main():
         lines.append('| %s | %.1f | %.3f | %.1f | %.0f | %.0f | %.0f | %.1f |' % (
             k, calls[k] / steps, ms, dur[k] / calls[k] / 1e3, rd, wr, (rd + wr) / max(ms, 1e-9), pct))
         tot_ms += ms
-        if k.startswith('gemm_f32_kernel'):
+        if k.startswith('gemm_f32_kernel') or k.startswith('bneck_tail_f32_kernel'):      # (the fused tails carry conv3 + conv1)
             gem['ms'] += ms; gem['rd'] += rd; gem['wr'] += wr; gem['launches'] += calls[k] / steps
             gem['busy'] += busy; gem['active'] += active
     lines += ['', 'HBM GB/s = (FETCH_SIZE x2 + WRITE_SIZE bytes) / kernel time, against ~8000 GB/s HBM3E peak '
               '(MI355X_MICROARCH.md); MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.',
               '', 'sum of kernel time: %.3f ms/step over %d profiled steps' % (tot_ms, steps), '',
-              'gemm_f32_kernel (all instantiations): %.3f ms/step, %.0f launches/step, HBM read %.0f MB + write %.0f MB '
+              'gemm_f32_kernel + bneck_tail_f32_kernel (all instantiations): %.3f ms/step, %.0f launches/step, HBM read %.0f MB + write %.0f MB '
               'per step (FETCH_SIZE x2 gfx950 correction applied), MFMA busy %.1f %% of kernel-active cycles' % (
                   gem['ms'], gem['launches'], gem['rd'], gem['wr'],
                   100.0 * (gem['busy'] / 1024.0) / (gem['active'] / 8.0) if gem['active'] else 0.0)]

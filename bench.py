@@ -374,7 +374,7 @@ def release_cached_blocks():
     and hand its cached blocks back to the driver, so that every series starts from the allocator state of a fresh
     process.  (Round 3 found a later series up to 40 % slower than in a fresh process -- bf16x3 train 54-64 ms vs
     39.3; the cause was a Tape <-> closure-list reference cycle in train_engine that kept every finished step's flat
-    gradient buffer alive until a full garbage collection.  Fixed there; tools/train_mode_sequence.py)"""
+    gradient buffer alive until a full garbage collection.  Fixed there; EXPERIMENTS.md.)"""
     import gc
     gc.collect()
     torch.cuda.synchronize()

@@ -288,7 +288,7 @@ def test_bf16_storage_step_against_reference_fixture(golden, fname, med_tol, cos
 # Per-tap budget of the bf16-storage TRAINING forward against the exact-fp32 forward on the same clips and weights
 # (relative L2 of every stored activation the tape exposes).  One bf16 rounding is 2^-9 relative per element; every
 # train-mode layer adds one, BatchNorm re-centres, ReLU keeps the error relative -- measured on MI355X (round 3,
-# tools/bf16s_tap_check.py): stem 2e-3, layer 4 9e-3, pooled features 6-8e-3.  The budgets are 2x those: a SINGLE layer
+# a per-tap probe): stem 2e-3, layer 4 9e-3, pooled features 6-8e-3.  The budgets are 2x those: a SINGLE layer
 # that is wrong by a few percent (a dropped k-step, a misplaced scale) breaks its tap's budget and every later one, which
 # the end-to-end "median gradient error 0.2" tolerance of the step test could absorb.
 TAP_BUDGET = {'stem': 4e-3, 'pool': 4e-3, 'layer1': 8e-3, 'layer2': 1.2e-2, 'layer3': 1.6e-2, 'layer4': 2e-2,

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_f32_kernel(const GrlBneckT
                 fa[0] = *reinterpret_cast<const f32x4*>(w3f + (cb * KQ) * 1024 + lane * 16);
 #pragma unroll
                 for (int kq = 0; kq < KQ; ++kq) {
-                    if (kq + 1 < KQ) fa[(kq + 1) & 1] = *reinterpret_cast<const f32x4*>(w3f + (cb * KQ + kq + 1) * 1024 + lane * 16);
+                    if (kq + 1 < KQ && KO != 4) fa[(kq + 1) & 1] = *reinterpret_cast<const f32x4*>(w3f + (cb * KQ + kq + 1) * 1024 + lane * 16);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) { if (KO == 1) acc[s] += fa[kq & 1][s] * b3[kq][s]; else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kq & 1][s], b3[kq][s], acc, 0, 0, 0); }
@@ -202,18 +202,20 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_f32_kernel(const GrlBneckT
                     const int cg = ch0 + 8 * g + 4 * h;
                     const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc3 + cg), h4 = *reinterpret_cast<const f32x4*>(sh3 + cg);
                     f32x4 t = {acc3[4 * g], acc3[4 * g + 1], acc3[4 * g + 2], acc3[4 * g + 3]};
-                    t = t * s4 + h4;
-                    t += rr[slot][g];
+                    if (KO < 3) {
+                        t = t * s4 + h4;
+                        t += rr[slot][g];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : 0.f;
+                    }
                     v[g] = t;
-                    if (live && (KO != 2 || t[0] == 123.f)) *reinterpret_cast<f32x4*>(y + (size_t)(yrow + (uint32_t)((ch0 + 8 * g) * 4) + h16)) = t;
+                    if (live && ((KO != 2 && KO < 3) || t[0] == 123.f)) *reinterpret_cast<f32x4*>(y + (size_t)(yrow + (uint32_t)((ch0 + 8 * g) * 4) + h16)) = t;
                 }
                 // refill this slot: PD blocks ahead -- same chunk, the next chunk, or chunk 0 of the next tile
                 {
                     const int bn = cb + PD;
                     const bool wrap = bn >= CB && c + 1 == NCH;
-                    if ((!wrap || has_next) && KO != 2) {
+                    if ((!wrap || has_next) && KO != 2 && KO < 3) {
                         const uint32_t rbase = (wrap ? rowcn : rowc) * (uint32_t)(C4 * 4);
                         const int chn = wrap ? (bn - CB) * 32 : (c + (bn >= CB ? 1 : 0)) * CH + (bn % CB) * 32;
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void bneck_tail_f32_kernel(const GrlBneckT
 #pragma unroll
                         for (int ob = 0; ob < OB; ++ob) {
                             const int i = g * OB + ob;               // fragment (ob, cb, g); the next one is read ahead
-                            if (i + 1 < 4 * OB) {
+                            if (i + 1 < 4 * OB && KO != 4) {
                                 const int gn = (i + 1) / OB, obn = (i + 1) % OB;
                                 fc[(i + 1) & 1] = *reinterpret_cast<const f32x4*>(w1f + ((obn * CB + cb) * 4 + gn) * 1024 + lane * 16);
                             }
@@ -321,6 +323,8 @@ extern "C" int grl_bottleneck_tail_f32(const GrlBneckTailF32* dp, void* stream) 
     if (d.P == 64) {
         if (d.Pn == 64 && cfg == 11) return launch<64, 256, 64, 256, 8, 2, 1>(d, s);
         if (d.Pn == 64 && cfg == 12) return launch<64, 256, 64, 256, 8, 2, 2>(d, s);
+        if (d.Pn == 64 && cfg == 13) return launch<64, 256, 64, 256, 8, 2, 3>(d, s);
+        if (d.Pn == 64 && cfg == 14) return launch<64, 256, 64, 256, 8, 2, 4>(d, s);
         if (d.Pn == 64) return launch<64, 256, 64, 256>(d, s);
         if (d.Pn == 128) return launch<64, 256, 128, 64>(d, s);
         return launch<64, 256, 0, 256>(d, s);

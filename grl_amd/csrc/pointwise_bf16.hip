@@ -381,6 +381,168 @@ static int stem_b16_launch(const float* x, const float* norm, const float* w, co
     return grl_check_launch("grl_stem_conv7x7_bf16");
 }
 
+// ---------------------------------------------------------------------------------
+// Stem + 3x3 / stride-2 max-pool in ONE launch (round 4; eval, bf16 storage; resnets1.py:101-104, basebranch.py:27-36):
+// the post-ReLU stem map (537 MB per 512 frames) is never written nor re-read.  Same MFMA core as stem_b16_kernel with a
+// tile of 2 stem rows x 64 columns = the FULL width of a 256 x 128 frame's stem map, so a pooling window never crosses a
+// tile's left / right edge; a workgroup walks SP_TPW tiles DOWN its strip and every tile yields exactly one pooled row
+// from (the previous tile's last row -- kept in REGISTERS by the lane that will need it --, row 0, row 1).  A strip that
+// does not start at the top of the image first runs one warm-up tile (the two rows above it) that only fills the carry.
+// Rounding commutes with max (round-to-nearest is monotonic), so the result equals max-pooling the bf16 stem map bit for bit.
+constexpr int SP_TH = 2, SP_TW = 64, SP_PH = 2 * SP_TH + 5, SP_PW = 2 * SP_TW + 5, SP_PWP = SP_PW + 1;
+constexpr int SP_PATCH = 3 * SP_PH * SP_PWP;
+constexpr int SP_TPW = 16;                            // tiles (= pooled rows) per workgroup
+
+__global__ __launch_bounds__(256) void stem_pool_b16_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ y,
+    int H, int W, const __bf16* __restrict__ wp, const float* __restrict__ norm) {
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    char* At = smb;                                            // [128][368 B]
+    char* Wt = At + 128 * SB_ROWB;                             // [64][368 B]
+    __bf16* patch = reinterpret_cast<__bf16*>(Wt + 64 * SB_ROWB);   // [3][9][134]
+    float* Cs = reinterpret_cast<float*>(smb);                 // epilogue staging [128][64] fp32 (32 KB < At)
+    const int Ho = H >> 1, Hp = Ho >> 1, Wp = SP_TW / 2;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
+    constexpr int P_IT = (SP_PATCH + 255) / 256, W_IT = (64 * SB_ROWB / 16 + 255) / 256;
+    float pv[P_IT];
+    auto load_patch = [&](const int oy0) {
+        const int iy0 = oy0 * 2 - 3;
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int i = tid + it * 256;
+            const int cr = i / SP_PWP, q = i - cr * SP_PWP, c = cr / SP_PH, r = cr - c * SP_PH;
+            const int iy = iy0 + r, ix = q - 3;
+            const bool ok = i < SP_PATCH && q < SP_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
+            pv[it] = norm ? (float)xu[o] : xi[o];
+            if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
+            if (!ok) pv[it] = 0.f;
+        }
+    };
+    const int strip0 = blockIdx.x * (SP_TPW * SP_TH);           // first stem row whose pooled row this workgroup emits
+    int oy0 = strip0 > 0 ? strip0 - SP_TH : 0;                  // (warm-up tile above the strip)
+    load_patch(oy0);
+    {
+        bf16x8 wv[W_IT];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            wv[it] = reinterpret_cast<const bf16x8*>(wp)[i < 64 * SB_ROWB / 16 ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < 64 * SB_ROWB / 16) reinterpret_cast<bf16x8*>(Wt)[i] = wv[it];
+        }
+    }
+    const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, fhalf = lane >> 5;
+    const int col_l = lane & 31;
+    const int c8 = (tid & 7) * 8, ppx = tid >> 3;              // pooling: this thread's pooled column and 8 channels
+    f32x8 sc, sh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[c8 + e]; sh[e] = shift[c8 + e]; }
+    f32x8 carry[3];                                             // previous tile's row 1 at stem columns 2 ppx - 1, 2 ppx, 2 ppx + 1
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) carry[jx][e] = 0.f;        // (post-ReLU values are >= 0: a zero never wins over a real element)
+    const int oy_end = min(Ho, strip0 + SP_TPW * SP_TH);
+    for (; oy0 < oy_end; oy0 += SP_TH) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < SP_PATCH) patch[i] = (__bf16)pv[it];
+        }
+        __syncthreads();                                       // patch (and, first time, weights) visible; Cs readers of the previous tile done
+        if (oy0 + SP_TH < oy_end) load_patch(oy0 + SP_TH);     // in flight under everything below
+        for (int i = tid; i < SB_CH * 128; i += 256) {
+            const int ch = i >> 7, m = i & 127;
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+            if (ch < 21) {
+                const int c = ch / 7, ky = ch - 7 * c;
+                const uint32_t* s2 = reinterpret_cast<const uint32_t*>(
+                    patch + ((c * SP_PH) + 2 * (m / SP_TW) + ky) * SP_PWP + 2 * (m % SP_TW));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = s2[e];
+            }
+            *reinterpret_cast<uint4*>(At + m * SB_ROWB + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SB_K / 16; ++s) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Wt + (wn * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + frow) * SB_ROWB + (2 * s + fhalf) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                       // At is dead: reuse as fp32 C staging
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * 64 + wn * 32 + col_l] = acc[i][r];
+        __syncthreads();
+        // folded BatchNorm + ReLU in place (a thread rewrites exactly the cells it read)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = it * 32 + (tid >> 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float tv = Cs[m * 64 + c8 + e] * sc[e] + sh[e];
+                Cs[m * 64 + c8 + e] = tv > 0.f ? tv : 0.f;
+            }
+        }
+        __syncthreads();
+        // pooled row oy0 / 2: max over (carry = stem row oy0 - 1, row 0, row 1) x stem columns 2 ppx - 1 .. 2 ppx + 1
+        f32x8 mx = carry[0];
+#pragma unroll
+        for (int jx = 1; jx < 3; ++jx)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = carry[jx][e] > mx[e] ? carry[jx][e] : mx[e];
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx) {
+            const int cx = 2 * ppx - 1 + jx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r0 = cx >= 0 ? Cs[cx * 64 + c8 + e] : 0.f;
+                const float r1 = cx >= 0 ? Cs[(SP_TW + cx) * 64 + c8 + e] : 0.f;
+                const float m2 = r0 > r1 ? r0 : r1;
+                mx[e] = m2 > mx[e] ? m2 : mx[e];
+                carry[jx][e] = r1;
+            }
+        }
+        if (oy0 >= strip0) st8(y + (((int64_t)img * Hp + (oy0 >> 1)) * Wp + ppx) * 64 + c8, mx);
+        // (the next iteration's first barrier comes after its patch writes, which touch neither At / Cs nor Wt)
+    }
+}
+
+extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_std, const float* scale, const float* shift,
+                                  void* y, int n, int H, int W, const void* wp, void* stream) {
+    GRL_REQUIRE(x && scale && shift && y && wp && n > 0, "stem_pool_bf16: null/empty");
+    GRL_REQUIRE(W == 2 * SP_TW && H % 4 == 0, "stem_pool_bf16: needs W == 128 and H % 4 == 0");
+    GRL_REQUIRE(!x_is_u8 || mean_std, "stem_pool_bf16: u8 input needs mean_std");
+    const int Ho = H / 2;
+    const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)SP_PATCH * sizeof(__bf16);
+    static const bool attr = [lds] {
+        (void)hipFuncSetAttribute((const void*)stem_pool_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(stem_pool_b16_kernel, dim3(grl_ceil_div(Ho, SP_TPW * SP_TH), n), dim3(256), lds, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(x), scale, shift, B16(y), H, W, CB16(wp), x_is_u8 ? mean_std : nullptr);
+    return grl_check_launch("grl_stem_pool_bf16");
+}
+
 extern "C" int grl_maxpool3x3s2_bf16(const void* x, void* y, int n, int H, int W, int C, void* stream) {
     GRL_REQUIRE(x && y && n > 0 && C % 8 == 0, "maxpool_bf16: bad args");
     const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);

@@ -141,6 +141,7 @@ def augment_normalize_u8(clips, params):
 
 
 FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
+FUSE_STEM_POOL = os.environ.get('GRL_FUSE_STEM_POOL', '1') != '0'   # A/B and tests: 0 = stem and max-pool as two launches (bf16 storage)
 FUSE_DOWN = os.environ.get('GRL_FUSE_DOWN', '1') != '0'         # A/B and tests: 0 = the downsample conv as its own launch
 SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
 
@@ -725,17 +726,23 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     x = inputs.contiguous().view(b * t, c, h, w)
     n = b * t
     Hs, Ws = h // 2, w // 2
-    stem = _newb((n * Hs * Ws, 64), x)
-    if x.dtype == torch.uint8:
-        _call('grl_stem_conv7x7_u8_bf16', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
-              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
-    else:
-        _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-              ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
     H, W = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _newb((n * H * W, 64), x)
-    _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)
-    del stem
+    if FUSE_STEM_POOL and taps is None and w == 128 and h % 4 == 0:
+        # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_bf16)
+        u8 = x.dtype == torch.uint8
+        _call('grl_stem_pool_bf16', ptr(x), 1 if u8 else 0, ptr(input_mean_std(x.device)) if u8 else None,
+              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(cur), n, h, w, ptr(plan.stem_wpb))
+    else:
+        stem = _newb((n * Hs * Ws, 64), x)
+        if x.dtype == torch.uint8:
+            _call('grl_stem_conv7x7_u8_bf16', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
+                  ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
+        else:
+            _call('grl_stem_conv7x7_bf16', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+                  ptr(stem), n, h, w, 1, ptr(plan.stem_wpb))
+        _call('grl_maxpool3x3s2_bf16', ptr(stem), ptr(cur), n, Hs, Ws, 64)
+        del stem
     o1 = None
     for bi, e in enumerate(plan.blocks):
         s = e['stride']

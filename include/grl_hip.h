@@ -580,6 +580,12 @@ int grl_bottleneck_tail_bf16_supported(int P, int C4, int Pn);      /* 1 if the 
 /* w [Pn][C4] (fp32 if !w_is_bf16) -> out [Pn][C4] bf16 in the k order the chained MFMA of grl_bottleneck_tail_bf16 consumes */
 int grl_bneck_perm32(const void* w, int w_is_bf16, void* out, int Pn, int C4, void* stream);
 
+/* Stem + max-pool in ONE launch (eval, bf16 storage; resnets1.py:101-104: conv 7x7/s2 + folded bn1 + ReLU + MaxPool2d(3, 2, 1)):
+ * x [n][3][H][W] fp32 (or raw uint8 with mean_std, normalised while the patch is staged), W == 128, H % 4 == 0;
+ * y [n*(H/4)*(W/4)][64] bf16 = the POOLED map; the stem map itself never reaches HBM.  wp: grl_stem_pack_weight_bf16. */
+int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_std, const float* scale, const float* shift, void* y,
+                       int n, int H, int W, const void* wp, void* stream);
+
 /* Layer 1's 3x3 / stride 1 convolution (64 -> 64 channels, maps W == 32 wide, H % 8 == 0; resnets1.py:79-81) + folded
  * BatchNorm + optional ReLU, bf16 storage: weights LDS-resident, every input pixel staged once per tile (fuse_bf16.hip).
  * x [n_img][H][W][64] bf16, w [64][9*64] bf16 packed tap-major (grl_pack_conv_weight + grl_cast_bf16), y [n_img*H*W][64]. */

@@ -201,3 +201,29 @@ def test_conv3x3_c64_matches_the_generic_kernel_and_torch(dev, n, H):
     _close_bf16(y.float(), yr, ulps=1.0)
     _close_bf16(y.float(), y0.float(), ulps=2.0)
     assert float((y == y0).float().mean()) > 0.99
+
+
+@pytest.mark.parametrize('n,u8', [(3, False), (5, True)])
+def test_stem_with_the_max_pool_in_the_same_launch_is_bit_identical(dev, synth_models, n, u8):
+    """grl_stem_pool_bf16 (stem 7x7/s2 + folded BN + ReLU + 3x3/s2 max-pool, one launch, the stem map never written)
+    against the two launches it replaces: rounding commutes with max, so the pooled map is the same bits -- float and raw
+    uint8 inputs, every strip (top strip without / lower strips with a warm-up tile)."""
+    from grl_amd import engine
+    from grl_amd.synthetic import synth_clips
+    cnn = synth_models[0].to(dev).eval()
+    plan = engine._plan(cnn, engine.GrlEvalPlan)
+    x = synth_clips(1, n, seed=11, raw=u8)[0].to(dev).contiguous()
+    H, W = 256, 128
+    stem = torch.empty(n * 128 * 64, 64, dtype=BF, device=dev)
+    if u8:
+        engine._call('grl_stem_conv7x7_u8_bf16', engine.ptr(x), engine.ptr(engine.input_mean_std(dev)), engine.ptr(plan.stem_w),
+                     engine.ptr(plan.stem_scale), engine.ptr(plan.stem_shift), engine.ptr(stem), n, H, W, 1, engine.ptr(plan.stem_wpb))
+    else:
+        engine._call('grl_stem_conv7x7_bf16', engine.ptr(x), engine.ptr(plan.stem_w), engine.ptr(plan.stem_scale),
+                     engine.ptr(plan.stem_shift), engine.ptr(stem), n, H, W, 1, engine.ptr(plan.stem_wpb))
+    ref = torch.empty(n * 64 * 32, 64, dtype=BF, device=dev)
+    engine._call('grl_maxpool3x3s2_bf16', engine.ptr(stem), engine.ptr(ref), n, 128, 64, 64)
+    got = torch.full((n * 64 * 32, 64), -1.0, dtype=BF, device=dev)
+    engine._call('grl_stem_pool_bf16', engine.ptr(x), 1 if u8 else 0, engine.ptr(engine.input_mean_std(dev)) if u8 else None,
+                 engine.ptr(plan.stem_scale), engine.ptr(plan.stem_shift), engine.ptr(got), n, H, W, engine.ptr(plan.stem_wpb))
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgrl_hip.so')
+LIB_PATH = os.environ.get('GRL_HIP_LIB') or os.path.join(_HERE, 'libgrl_hip.so')     # (override: A/B builds, tools/gemm_ko.sh)
 
 ABI_VERSION = 6       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 

@@ -42,7 +42,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BK = 32;
+#ifndef GRL_GEMM_KO
+#define GRL_GEMM_KO 0     // tools/gemm_ko.sh: timing-only knock-outs (1 no in-loop staging, 2 no stage barrier, 4 no epilogue, 8 all stages from k = 0); wrong results
+#endif
 constexpr int SEG_STAGES = 16;     // fp32 path: accumulator segment = 16 stages = 512 k
+#ifndef GRL_GEMM_PIPE
+#define GRL_GEMM_PIPE 1   // hand-scheduled stage loop of the dense fp32 LDS-DMA kernels (0: the compiler-scheduled loop)
+#endif
+
+typedef __attribute__((address_space(3))) char* lds_cptr_t;
+// LDS-DMA piece the compiler does not see (wave-uniform 64-bit base in SGPRs + per-lane 32-bit offset).  While a
+// compiler-VISIBLE global_load_lds is outstanding hipcc waits vmcnt(0) in front of every LDS read that follows (it cannot
+// tell the DMA's destination from the buffer being read), which forces all of a stage's pieces to the top of the stage
+// and every fragment read behind a drained queue.  Hidden, the pieces sit between the MFMAs and the loop waits for them
+// itself (`s_waitcnt vmcnt(0)` in front of the stage barrier); counted waits the compiler emits for its own loads only
+// ever over-wait.
+__device__ __forceinline__ void dma16_hidden(const char* sbase, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) {       // per-lane 64-bit address (the conv gather)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
 
 __device__ uint4 g_zero_chunks[8];        // 128 zero bytes: LDS-DMA source of out-of-image conv taps
 
@@ -101,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     char* const Ah = reinterpret_cast<char*>(smem);                // [2][PL][BM][64 B]
     char* const Bh = Ah + 2 * PL * BM * 64;                        // [2][PL][BN][64 B]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool PIPE = GRL_GEMM_PIPE && DMA && MATH == 0 && BM == 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = PIPE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
     const int d_row = lane >> 3, d_chunk = lane & 7;          // LDS-DMA staging: lane = (row of an 8-row block, chunk)
@@ -119,6 +140,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     const char* dma_a[DMA ? BM / 32 : 1];
     const char* dma_b[DMA ? BN / 32 : 1];
     int dma_iy0[DMA && CONV ? BM / 32 : 1], dma_ix0[DMA && CONV ? BM / 32 : 1];      // conv: window origin of the row
+    uint32_t pv_a[PIPE ? BM / 32 : 1], pv_b[PIPE ? BN / 32 : 1];                      // PIPE: per-lane byte offsets from the tile's row 0
+    const char *pbase_a = nullptr, *pbase_b = nullptr;                                // PIPE: the tile's A / W row 0 (wave-uniform)
     int m0, n0, tile_m;
     auto setup_tile = [&](int t) {
         int bid = t;
@@ -153,7 +176,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
             n = n < p.N ? n : p.N - 1;
             bofs[i] = (int64_t)n * p.ldw;
         }
-        if constexpr (DMA) {
+        if constexpr (PIPE) {
+            pbase_b = reinterpret_cast<const char*>(p.w) + ((int64_t)n0 * p.ldw) * ESZ;
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int r = (wave + 4 * i) * 8 + d_row;
+                const int n = n0 + r < p.N ? r : p.N - 1 - n0;             // clamp: edge rows are never stored
+                pv_b[i] = (uint32_t)(n * p.ldw * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4));
+            }
+        }
+        if constexpr (PIPE && !CONV) {
+            pbase_a = reinterpret_cast<const char*>(p.a) + ((int64_t)m0 * p.lda) * ESZ;
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) {
+                const int r = (wave + 4 * i) * 8 + d_row;
+                const int m = m0 + r < p.M ? r : p.M - 1 - m0;
+                pv_a[i] = (uint32_t)(m * p.lda * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4));
+            }
+        } else if constexpr (DMA) {
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) {
                 const int r = (wave + 4 * i) * 8 + d_row;
@@ -184,8 +224,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     // (`global_load_lds_dwordx4`): no staging VGPRs, no ds_write, no vmcnt wait in front of them.  A
     // wave-instruction fills 8 rows x 128 B linearly; the chunk swizzle moves to the per-lane SOURCE.
     // Wave w owns the 8-row blocks w, w+4, ... of both tiles; lane l is (row l>>3, chunk l&7).
+    // PIPE: piece i of a stage (0..3: A row blocks wave, wave+4, ..; 4..7: W row blocks)
+    const uint32_t lds_base = (uint32_t)(size_t)((lds_cptr_t) reinterpret_cast<char*>(smem));
+    // conv: the tap (ky, kx) and channel offset of the NEXT stage to request, advanced by one stage per call instead of
+    // two integer divisions per stage; the per-lane gather addresses of a stage are computed one chunk ahead of their
+    // pieces (pn_src), so the address arithmetic interleaves with MFMAs instead of sitting in front of the DMA issue
+    int pky = 0, pkx = 0, pc0 = 0;
+    const char* pn_src[PIPE && CONV ? BM / 32 : 1];
+    auto conv_tap_reset = [&]() { pky = pkx = pc0 = 0; };
+    auto conv_tap_advance = [&]() {
+        pc0 += KST;
+        if (pc0 >= p.C) {
+            pc0 = 0;
+            if (++pkx == p.kw) { pkx = 0; ++pky; }
+        }
+    };
+    auto conv_addrs = [&]() {
+        if constexpr (PIPE && CONV) {
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) {
+                const int iy = dma_iy0[i] + pky, ix = dma_ix0[i] + pkx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                pn_src[i] = ok ? dma_a[i] + ((int64_t)(iy * p.W + ix) * p.C + pc0) * ESZ
+                               : reinterpret_cast<const char*>(g_zero_chunks) + (d_chunk << 4);
+            }
+        }
+    };
+    auto dma_piece = [&](int buf, int ks, int i) {
+        if constexpr (PIPE) {
+            const int64_t kb = (int64_t)ks * KST * ESZ;
+            if (i < BM / 32) {
+                const uint32_t dst = lds_base + (uint32_t)((buf * BM * BK) * 4 + (wave + 4 * i) * 1024);
+                if constexpr (CONV) dma16_hidden_v(pn_src[i], dst);
+                else dma16_hidden(pbase_a + kb, pv_a[i], dst);
+            } else
+                dma16_hidden(pbase_b + kb, pv_b[i - BM / 32],
+                             lds_base + (uint32_t)((2 * BM * BK + buf * BN * BK) * 4 + (wave + 4 * (i - BM / 32)) * 1024));
+        }
+    };
     auto dma_stage = [&](int buf, int ks) {
-        if constexpr (DMA) {
+        if constexpr (PIPE) {          // (a tile's first stage: ks == 0)
+            if constexpr (CONV) { conv_tap_reset(); conv_addrs(); }
+#pragma unroll
+            for (int i = 0; i < BM / 32 + BN / 32; ++i) dma_piece(buf, ks, i);
+        } else if constexpr (DMA) {
+            if (GRL_GEMM_KO & 8) ks = 0;            // every stage re-reads the tile's first (cache-resident) k block
             char* const Asb = reinterpret_cast<char*>(As + buf * BM * BK);
             char* const Bsb = reinterpret_cast<char*>(Bs + buf * BN * BK);
             const int64_t kb = (int64_t)ks * KST * ESZ;
@@ -314,12 +397,74 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     }
 
     store_stage(0);
+    if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    // PIPE: fragments double-buffered in registers ACROSS the stage boundary.  Stage ks (buffer b): chunk q's 16 MFMAs run
+    // while chunk q+1's four ds_read_b128 are in flight; the eight LDS-DMA pieces of stage ks+1 go out two at a time
+    // between the MFMA groups of chunk 0 (buffer b^1 was released by the previous stage's barrier); the stage barrier
+    // sits in front of the LAST chunk's MFMAs -- its fragments have landed, so nobody reads b again -- and the first
+    // fragments of stage ks+1 are requested right behind it, under those 16 MFMAs.  Same MFMA order as the plain loop:
+    // bit-identical results.
+    f32x4 paf[PIPE ? 2 : 1][MT], pbf[PIPE ? 2 : 1][NT];
+    auto prd = [&](int set, int buf, int q) {
+        if constexpr (PIPE) {
+            const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
+            const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = i * 32 + frow;
+                paf[set][i] = *reinterpret_cast<const f32x4*>(Ab + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int row = j * 32 + frow;
+                pbf[set][j] = *reinterpret_cast<const f32x4*>(Bb + row * BK + (((2 * q + fhalf) ^ ((row >> 1) & 7)) << 2));
+            }
+        }
+    };
+    if constexpr (PIPE) prd(0, 0, 0);
 
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) { load_stage(ks + 1); dma_stage(buf ^ 1, ks + 1); }
-        if constexpr (MATH == 2) {
+        if constexpr (!PIPE)
+            if (!(GRL_GEMM_KO & 1) && ks + 1 < nk) { load_stage(ks + 1); dma_stage(buf ^ 1, ks + 1); }
+        if constexpr (PIPE) {
+            const bool more = ks + 1 < nk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+                    prd((q + 1) & 1, buf, q + 1);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (more) prd(0, buf ^ 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(paf[q & 1][i][s], pbf[q & 1][j][s], acc[i][j], 0, 0, 0);
+                    // stage ks+1's pieces, two per MFMA group.  Dense: A then W, all inside chunk 0.  Conv: the W pieces in
+                    // chunk 0 while the gather addresses are computed (plain VALU work the compiler interleaves with the
+                    // rest of the chunk's MFMAs), the A pieces in chunk 1.
+                    constexpr int NA = BM / 32, NB = BN / 32;
+                    const int first = CONV ? (q == 0 ? NA + 2 * s : q == 1 ? 2 * s : -1) : (q == 0 ? 2 * s : -1);
+                    const int last = CONV ? (q == 0 ? NA + NB : NA) : NA + NB;
+                    if (more && first >= 0 && first < last) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece(buf ^ 1, ks + 1, first);
+                        dma_piece(buf ^ 1, ks + 1, first + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (CONV && q == 0 && s == 1 && more) { conv_tap_advance(); conv_addrs(); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (MATH == 2) {
             const float* Ab = As + buf * BM * BK + (wm * WTM) * BK;
             const float* Bb = Bs + buf * BN * BK + (wn * WTN) * BK;
 #pragma unroll
@@ -450,8 +595,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                     }
             }
         }
-        if (ks + 1 < nk) store_stage(buf ^ 1);
-        __syncthreads();
+        if constexpr (!PIPE) {
+            if (!(GRL_GEMM_KO & 1) && ks + 1 < nk) store_stage(buf ^ 1);
+            if (!(GRL_GEMM_KO & 2)) __syncthreads();
+        }
     }
     if constexpr (SEG) {
         if (nk > SEG_STAGES) {
@@ -889,7 +1036,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         }
     }
     };
-    epilogue(cur_m0, cur_n0, cur_tile_m);
+    if constexpr ((GRL_GEMM_KO & 4) != 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1.2345e-30f) p.y[0] = s;
+    } else {
+        epilogue(cur_m0, cur_n0, cur_tile_m);
+    }
     if (next_t >= num_tiles) break;
     t = next_t;
     __syncthreads();          // every wave is done with the C staging before the stages are rewritten

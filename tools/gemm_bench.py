@@ -22,7 +22,7 @@ SHAPES = [  # (M, N, K, conv, calls per step, epilogue: res?)
 ]
 
 
-def bench(tile, iters=5):
+def bench(tile, iters=20):
     math = 0
     if ':' in tile:                       # e.g. bf16x3:256x128
         m, tile = tile.split(':')

@@ -859,6 +859,16 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 // m is the ROW of both tiles, so the MFMA fragments (8 consecutive m of one output column) are read
 // with the hardware transpose read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16-lane group,
 // conflict-free with that swizzle) and feed v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi.
+__device__ uint4 g_wgrad_zero_chunk;       // 16 zero bytes: LDS-DMA source of rows past the pixel range / columns past N or K / out-of-image taps
+typedef __attribute__((address_space(3))) char* lds_cptr_t;
+// LDS-DMA piece hipcc does not see (see gemm_f32.hip: a VISIBLE global_load_lds makes every later LDS read wait vmcnt(0));
+// the loop waits for its pieces itself in front of the stage barrier
+__device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+}
+#ifndef GRL_WGRAD_KO
+#define GRL_WGRAD_KO 0      // timing-only knock-outs (1: no in-loop staging, 2: no slab store, 4: every stage re-reads the first 32 pixels); wrong results
+#endif
 template <int BM, int BN, bool CONV, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
     static_assert(MATH == 0 || (BM == 128 && BN == 128), "the bf16 datapaths are written for 128 x 128 tiles");
@@ -883,6 +893,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     // and stage (they sat in front of every stage's MFMAs)
     int pimg[B_ITEMS], poy[B_ITEMS], pox[B_ITEMS];
     const int adv_y = 32 / p.Wo, adv_x = 32 - adv_y * p.Wo;
+    const bool small_img = CONV && p.Ho * p.Wo < 64;
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < B_ITEMS; ++i) {
@@ -894,36 +905,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
             pox[i] = rem - poy[i] * p.Wo;
         }
     }
+    // The loads are UNCONDITIONAL (an out-of-range item reads the tensor's first element instead) and the zeroing moves to
+    // the item's LDS store: with a branch around every load hipcc cannot count them and waits vmcnt(0) in front of the first
+    // ds_write of the stage; counted, each store waits for its own load only.
+    bool aok[A_ITEMS], bok[B_ITEMS];
     auto load_stage = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < A_ITEMS; ++i) {
             const int e = tid + 256 * i, row = e / A_TPR, col = (e - row * A_TPR) * 4;
             const int m = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && n0 + col < p.N)
-                v = *reinterpret_cast<const f32x4*>(p.dz + (int64_t)m * p.ldz + n0 + col);
-            areg[i] = v;
+            aok[i] = m < m_end && n0 + col < p.N;
+            const float* src = aok[i] ? p.dz + (int64_t)m * p.ldz + n0 + col : p.dz;
+            areg[i] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
         for (int i = 0; i < B_ITEMS; ++i) {
             const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
             const int m = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const float* src = p.x;
             if (CONV) {
                 const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
-                if (m < m_end && k0 + col < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(
-                        p.x + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + c0 + col);
+                bok[i] = m < m_end && k0 + col < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                if (bok[i]) src = p.x + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + c0 + col;
                 // advance this row's pixel by the 32 rows of a stage (stages are loaded in order)
                 pox[i] += adv_x;
                 if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
                 poy[i] += adv_y;
                 while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
-            } else if (m < m_end && k0 + col < p.K) {
-                v = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + k0 + col);
+            } else {
+                bok[i] = m < m_end && k0 + col < p.K;
+                if (bok[i]) src = p.x + (int64_t)m * p.ldx + k0 + col;
             }
-            breg[i] = v;
+            breg[i] = *reinterpret_cast<const f32x4*>(src);
         }
+    };
+    auto item_a = [&](int i) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; return aok[i] ? areg[i] : z; };
+    auto item_b = [&](int i) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; return bok[i] ? breg[i] : z; };
+    // MATH == 0: the stage goes global -> LDS by LDS-DMA, item by item (item = one 16-byte element per thread, the same
+    // thread -> element map as the register path: element e = tid + 256 it lands at byte 16 e of its operand's stage, so
+    // a wave's piece is 1 KB of consecutive LDS); whatever must read as zero comes from a zero chunk.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_cptr_t) reinterpret_cast<char*>(smem);
+    const char* zsrc = reinterpret_cast<const char*>(&g_wgrad_zero_chunk);
+    asm volatile("" : "+s"(zsrc));      // keep the pointer in SGPRs: rematerialised, it is a GOT load (and an lgkmcnt(0) wait) per item
+    auto dma_item = [&](int buf, int m0, int it) {
+        const char* src = zsrc;
+        unsigned dst;
+        if (it < A_ITEMS) {
+            const int e = tid + 256 * it, row = e / A_TPR, col = (e - row * A_TPR) * 4;
+            const int m = m0 + row;
+            if (m < m_end && n0 + col < p.N) src = reinterpret_cast<const char*>(p.dz + (int64_t)m * p.ldz + n0 + col);
+            dst = lds0 + (unsigned)((buf * 32 * BM) * 4 + wave_u * 1024 + 4096 * it);
+        } else {
+            const int i = it - A_ITEMS;
+            const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
+            const int m = m0 + row;
+            if (CONV) {
+                const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
+                if (m < m_end && k0 + col < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    src = reinterpret_cast<const char*>(p.x + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + c0 + col);
+                pox[i] += adv_x;                                   // this row's pixel 32 rows on (stages are requested in order)
+                if (pox[i] >= p.Wo) { pox[i] -= p.Wo; ++poy[i]; }
+                poy[i] += adv_y;
+                if (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
+                if (small_img)                                     // (images of fewer than 64 pixels: 32 rows can span several)
+                    while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
+            } else if (m < m_end && k0 + col < p.K) {
+                src = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + k0 + col);
+            }
+            dst = lds0 + (unsigned)((2 * 32 * BM + buf * 32 * BN) * 4 + wave_u * 1024 + 4096 * i);
+        }
+        dma16_hidden_v(src, dst);
     };
     constexpr int PLANE = 32 * 256;                       // bytes of one bf16 plane: 32 rows x 128 columns
     constexpr int NPL = MATH == 3 ? 2 : 1;                // planes per operand (hi, lo)
@@ -947,19 +999,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #pragma unroll
             for (int i = 0; i < A_ITEMS; ++i) {
                 const int e = tid + 256 * i;
-                *reinterpret_cast<f32x4*>(As + buf * 32 * BM + e * 4) = areg[i];
+                *reinterpret_cast<f32x4*>(As + buf * 32 * BM + e * 4) = item_a(i);
             }
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i) {
                 const int e = tid + 256 * i;
-                *reinterpret_cast<f32x4*>(Bs + buf * 32 * BN + e * 4) = breg[i];
+                *reinterpret_cast<f32x4*>(Bs + buf * 32 * BN + e * 4) = item_b(i);
             }
         } else {
             char* const base = sm8 + buf * (2 * NPL * PLANE);
 #pragma unroll
-            for (int i = 0; i < A_ITEMS; ++i) split_store(base, tid + 256 * i, areg[i]);
+            for (int i = 0; i < A_ITEMS; ++i) split_store(base, tid + 256 * i, item_a(i));
 #pragma unroll
-            for (int i = 0; i < B_ITEMS; ++i) split_store(base + NPL * PLANE, tid + 256 * i, breg[i]);
+            for (int i = 0; i < B_ITEMS; ++i) split_store(base + NPL * PLANE, tid + 256 * i, item_b(i));
         }
     };
 
@@ -974,33 +1026,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     const int nst = (m_end - m_begin + 31) / 32;
     const int frow = lane & 31, fhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    if (nst > 0) {
-        load_stage(m_begin);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) load_stage(m_begin + (st + 1) * 32);
-        if constexpr (MATH == 0) {
+    float af[2][MT], bf[2][NT];                                  // MATH == 0: MFMA fragments of two k-steps
+    auto rdf = [&](int set, int buf, int s) {
         const float* Ab = As + buf * 32 * BM + wm * WTM;
         const float* Bb = Bs + buf * 32 * BN + wn * WTN;
-        // fragments double-buffered in registers: the reads of k-step s+1 are issued BEFORE the MFMAs of step s and
-        // fenced there (left to itself hipcc issues read, s_waitcnt lgkmcnt(0), 4 MFMAs per step: the LDS latency of
-        // every step in front of 256 cycles of matrix work -- 66 % MFMA busy)
-        float af[2][MT], bf[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[0][i] = Ab[fhalf * BM + i * 32 + frow];
+        for (int i = 0; i < MT; ++i) af[set][i] = Ab[(2 * s + fhalf) * BM + i * 32 + frow];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[0][j] = Bb[fhalf * BN + j * 32 + frow];
+        for (int j = 0; j < NT; ++j) bf[set][j] = Bb[(2 * s + fhalf) * BN + j * 32 + frow];
+    };
+    if (nst > 0) {
+        if constexpr (MATH == 0) {
+#pragma unroll
+            for (int it = 0; it < A_ITEMS + B_ITEMS; ++it) dma_item(0, m_begin, it);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_stage(m_begin);
+            store_stage(0);
+        }
+    }
+    __syncthreads();
+    if constexpr (MATH == 0)
+        if (nst > 0) rdf(0, 0, 0);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if constexpr (MATH != 0)
+            if (st + 1 < nst) load_stage(m_begin + (st + 1) * 32);
+        if constexpr (MATH == 0) {
+        // One stage = 16 k-steps of MT x NT MFMAs.  Fragments are double-buffered in registers ACROSS the stage boundary and
+        // the next stage's LDS-DMA items go out two per k-step under the MFMAs of the first steps (their address arithmetic
+        // -- the conv gather's pixel walk included -- interleaves with matrix work instead of sitting in front of it); the
+        // stage barrier (after `vmcnt(0)`: this wave's items have landed) sits in front of the LAST step's MFMAs -- its
+        // fragments have arrived, so nobody reads this buffer again -- and the next stage's first fragments are requested
+        // right behind it, under those MFMAs.  History: hipcc's own schedule (read, lgkmcnt(0), 4 MFMAs per step) 66 %
+        // MFMA busy; reads of step s+1 fenced in front of the MFMAs of step s, register staging 71 %; a timing-only build
+        // without any staging (GRL_WGRAD_KO=1) runs 15 % (dense) to 24 % (conv) faster than that.  Same MFMA order:
+        // bit-identical.
+        constexpr int NI = A_ITEMS + B_ITEMS;
+        const bool more = !(GRL_WGRAD_KO & 1) && st + 1 < nst;
+        const bool more_rd = st + 1 < nst;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
             if (s + 1 < 16) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) af[nxt][i] = Ab[(2 * s + 2 + fhalf) * BM + i * 32 + frow];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bf[nxt][j] = Bb[(2 * s + 2 + fhalf) * BN + j * 32 + frow];
+                rdf(nxt, buf, s + 1);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (more_rd) rdf(0, buf ^ 1, 0);
+            }
+            if (more && 2 * s < NI) {
+                const int mnext = (GRL_WGRAD_KO & 4) ? m_begin : m_begin + (st + 1) * 32;
+                dma_item(buf ^ 1, mnext, 2 * s);
+                dma_item(buf ^ 1, mnext, 2 * s + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1089,8 +1167,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #undef GRL_TR
 #undef GRL_FRAG
         }
-        if (st + 1 < nst) store_stage(buf ^ 1);
-        __syncthreads();
+        if constexpr (MATH != 0) {
+            if (st + 1 < nst) store_stage(buf ^ 1);
+            __syncthreads();
+        }
     }
     float* out = p.slab + (int64_t)blockIdx.y * p.slab_stride;
     const int col_l = lane & 31;
@@ -1103,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (n < p.N) out[(int64_t)n * p.K + k] = acc[i][j][r];
+                if (n < p.N && (!(GRL_WGRAD_KO & 2) || acc[i][j][r] == 1.2345e-30f)) out[(int64_t)n * p.K + k] = acc[i][j][r];
             }
     }
 }
@@ -1277,8 +1357,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16in_kernel(const WgradArgs p, 
 //     the per-lane SOURCE; rows past the pixel range / columns past N or K read a zero chunk), THREE stage buffers
 //     (96 KiB): the DMA of stage t + 2 is issued when stage t starts, waits are counted (`vmcnt(4)`: this wave's
 //     four pieces of the stage about to be read) in front of a raw barrier.
-__device__ uint4 g_wgrad_zero_chunk;
-
 template <bool CONV>
 __global__ __launch_bounds__(512) void wgrad_b16in_256_kernel(const WgradArgs p, const int tiles_k) {
     constexpr int TBW = 256, PLANE = 32 * 512, STG = 2 * PLANE, NBUF = 3;

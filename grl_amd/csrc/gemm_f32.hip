@@ -1212,7 +1212,7 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
     static const bool dma_conv_on = [] { const char* e = getenv("GRL_GEMM_DMA_CONV"); return !e || atoi(e) != 0; }();
     if (d.conv) {
         constexpr bool CAN_DMA_CONV = (MATH == 0 || MATH == 2) && BM == 128;
-        if (CAN_DMA_CONV && dma_conv_on) {
+        if (CAN_DMA_CONV && dma_conv_on && d.ldw < (1 << 22)) {
             if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
             else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);
@@ -1221,7 +1221,8 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
         // dense fp32 with a long K loop: LDS-DMA staging (GRL_GEMM_DMA=0 switches it off: tuning only)
         static const bool dma_on = [] { const char* e = getenv("GRL_GEMM_DMA"); return !e || atoi(e) != 0; }();
         constexpr bool CAN_DMA = (MATH == 0 || MATH == 2) && BM == 128;     // 128-byte operand rows (fp32 x 32 / bf16 x 64)
-        if (CAN_DMA && dma_on && d.K >= 256) {
+        // (the hand-scheduled loop addresses a tile's rows with 32-bit byte offsets from its first row: 127 rows x ld x 4 B)
+        if (CAN_DMA && dma_on && d.K >= 256 && d.lda < (1 << 22) && d.ldw < (1 << 22)) {
             if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
             else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);

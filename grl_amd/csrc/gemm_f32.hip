@@ -636,14 +636,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         constexpr bool RES_PREFETCH = MATH != 2 && !SEG && !(BM == 128 && BN == 128);     // (16 rows x 4 VGPRs would spill there)
         constexpr int EPI_UNROLL = RES_PREFETCH ? EPI_ROWS : 4;
         f32x4 rpre[RES_PREFETCH ? EPI_ROWS : 1];
+        // ... and the rows of z (+ ReLU mask words) of a fused BatchNorm-backward reduce (GrlGemm.bn_z): the data-gradient
+        // GEMMs into the 4P-wide tensors are short-K, output-heavy launches whose epilogue was a chain of dependent loads
+        f32x4 zpre[RES_PREFETCH ? EPI_ROWS : 1];
+        uint32_t bpre[RES_PREFETCH ? EPI_ROWS : 1];
         if constexpr (RES_PREFETCH) {
+            constexpr int LPRp = WTN / 4, RPIp = 64 / LPRp;
+            const int np = n0 + wn * WTN + (lane % LPRp) * 4;
             if (p.res && p.epilogue == GRL_EPI_AFFINE) {
-                constexpr int LPRp = WTN / 4, RPIp = 64 / LPRp;
-                const int np = n0 + wn * WTN + (lane % LPRp) * 4;
 #pragma unroll
                 for (int it = 0; it < EPI_ROWS; ++it) {
                     const int m = m0 + wm * WTM + it * RPIp + lane / LPRp;
                     if (m < p.M && np < p.N) rpre[it] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + np);
+                }
+            }
+            if (p.bn_z && p.epilogue == GRL_EPI_AFFINE) {
+#pragma unroll
+                for (int it = 0; it < EPI_ROWS; ++it) {
+                    const int m = m0 + wm * WTM + it * RPIp + lane / LPRp;
+                    if (m < p.M && np < p.N) {
+                        zpre[it] = *reinterpret_cast<const f32x4*>(p.bn_z + (int64_t)m * p.N + np);
+                        if (p.bn_bits) bpre[it] = p.bn_bits[((int64_t)m * p.N + np) >> 2];
+                    }
                 }
             }
         }
@@ -908,9 +922,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                         }
                         if constexpr (MATH != 2) {
                             if (p.bn_z) {
-                                const f32x4 zc = *reinterpret_cast<const f32x4*>(p.bn_z + (int64_t)m * p.N + n) - bmu;
+                                f32x4 zraw;
+                                if constexpr (RES_PREFETCH) zraw = zpre[it];
+                                else zraw = *reinterpret_cast<const f32x4*>(p.bn_z + (int64_t)m * p.N + n);
+                                const f32x4 zc = zraw - bmu;
                                 if (p.bn_bits) {
-                                    const uint32_t mk = p.bn_bits[((int64_t)m * p.N + n) >> 2];
+                                    uint32_t mk;
+                                    if constexpr (RES_PREFETCH) mk = bpre[it];
+                                    else mk = p.bn_bits[((int64_t)m * p.N + n) >> 2];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = (mk >> e) & 1u ? v[e] : 0.f;
                                 } else if (p.bn_mscale) {          // the forward's (z - mean) * scale + beta, term for term
@@ -1123,7 +1142,12 @@ TileChoice legacy_tile(const GrlGemm& d) {
     static const bool wide3_on = [] { const char* e = getenv("GRL_GEMM_WIDE3"); return !e || atoi(e) != 0; }();   // split-bf16 / bf16 products too
     // (the data-gradient GEMMs that carry a BatchNorm-backward reduce -- stats + bn_z -- take it too: their column sums
     // feed gradients, not ReLU masks, so their association is free; split-bf16 products: mixed 43.4 -> 43.05 ms, fp32 +-0)
-    if (wide_on && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
+    // (round 4: a fused BatchNorm-backward reduce reads a row of z (+ mask word) per output row; the 64-wide tiles request
+    // those rows before the accumulators' LDS round trip (zpre), the 128 x 128 tile has no registers for that -- the
+    // short-K, output-heavy data-gradient GEMMs that carry one go back to the narrow tiles.  GRL_GEMM_BNZ_NARROW=0: off)
+    static const int bnz_narrow_k = [] { const char* e = getenv("GRL_GEMM_BNZ_NARROW"); return e ? atoi(e) : 512; }();
+    const bool bnz_narrow = d.bn_z && d.math == GRL_MATH_F32 && d.K <= bnz_narrow_k;
+    if (wide_on && !bnz_narrow && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
         tiles(128, 128) >= 256 && !(d.res && d.K <= 128))
         return {128, 128};
     if (d.K <= 128) return {64, 64};

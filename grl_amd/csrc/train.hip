@@ -867,7 +867,7 @@ __device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
 }
 #ifndef GRL_WGRAD_KO
-#define GRL_WGRAD_KO 0      // timing-only knock-outs (1: no in-loop staging, 2: no slab store, 4: every stage re-reads the first 32 pixels); wrong results
+#define GRL_WGRAD_KO 0      // timing-only knock-outs (1: no in-loop staging, 2: no slab store); wrong results
 #endif
 template <int BM, int BN, bool CONV, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
@@ -948,19 +948,64 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_cptr_t) reinterpret_cast<char*>(smem);
     const char* zsrc = reinterpret_cast<const char*>(&g_wgrad_zero_chunk);
     asm volatile("" : "+s"(zsrc));      // keep the pointer in SGPRs: rematerialised, it is a GOT load (and an lgkmcnt(0) wait) per item
-    auto dma_item = [&](int buf, int m0, int it) {
-        const char* src = zsrc;
+    // Dense operands: every item carries its source pointer and advances it by 32 rows per stage (a pointer that must read
+    // zeros for its column stays on the zero chunk with stride 0), so a stage costs one 64-bit add per item -- plus, in
+    // the one stage of a pixel range that is not full, a compare and a select.  Counters (tools/wgrad_vs_gemm_probe.py)
+    // showed what separates this kernel from the forward GEMM on the same product: not TLB or L2 behaviour but 1.7x the
+    // VALU-active cycles and 2.1x the LDS instructions -- per-item 64-bit multiply-adds, a v_add per fragment read.
+    const char* pa[A_ITEMS];
+    const char* pb[B_ITEMS];
+    unsigned sa[A_ITEMS], sb[B_ITEMS];
+    int ra[A_ITEMS], rb[B_ITEMS];
+#pragma unroll
+    for (int i = 0; i < A_ITEMS; ++i) {
+        const int e = tid + 256 * i, row = e / A_TPR, col = (e - row * A_TPR) * 4;
+        const bool ok = n0 + col < p.N;
+        ra[i] = row;
+        pa[i] = ok ? reinterpret_cast<const char*>(p.dz + (int64_t)(m_begin + row) * p.ldz + n0 + col) : zsrc;
+        sa[i] = ok ? (unsigned)(32 * p.ldz * 4) : 0u;
+    }
+    const bool lin = CONV && !small_img && p.stride == 1 && p.Ho == p.H && p.Wo == p.W && 32 % p.Wo == 0;
+#pragma unroll
+    for (int i = 0; i < B_ITEMS; ++i) {
+        const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
+        rb[i] = row;
+        if (CONV) {
+            // lin: pox is this item's column for every stage; its tap column must lie inside the image
+            const bool ok = lin && k0 + col < p.K && (unsigned)(pox[i] + kx - p.pad) < (unsigned)p.W;
+            const int64_t pix = (int64_t)(m_begin + row) + (int64_t)(ky - p.pad) * p.W + (kx - p.pad);
+            pb[i] = ok ? reinterpret_cast<const char*>(p.x + pix * p.C + c0 + col) : zsrc;
+            sb[i] = ok ? (unsigned)(32 * p.C * 4) : 0u;
+        } else {
+            const bool ok = k0 + col < p.K;
+            pb[i] = ok ? reinterpret_cast<const char*>(p.x + (int64_t)(m_begin + row) * p.ldx + k0 + col) : zsrc;
+            sb[i] = ok ? (unsigned)(32 * p.ldx * 4) : 0u;
+        }
+    }
+    // (items are requested stage by stage in order, starting at m_begin: the pointers are always those of stage `m0`)
+    auto dma_item = [&](int buf, int m0, int it, bool full) {
+        const char* src;
         unsigned dst;
         if (it < A_ITEMS) {
-            const int e = tid + 256 * it, row = e / A_TPR, col = (e - row * A_TPR) * 4;
-            const int m = m0 + row;
-            if (m < m_end && n0 + col < p.N) src = reinterpret_cast<const char*>(p.dz + (int64_t)m * p.ldz + n0 + col);
+            src = pa[it];
+            if (!full && !(m0 + ra[it] < m_end)) src = zsrc;
+            pa[it] += sa[it];
             dst = lds0 + (unsigned)((buf * 32 * BM) * 4 + wave_u * 1024 + 4096 * it);
         } else {
             const int i = it - A_ITEMS;
-            const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
-            const int m = m0 + row;
-            if (CONV) {
+            if (CONV && lin) {
+                // same-size stride-1 window: the tap's input pixel is the output pixel shifted by a constant, so the source
+                // is LINEAR in the pixel index (pointer + 32 rows per stage); the column test is fixed per item (Wo divides
+                // 32), only the row test follows the pixel's oy
+                src = pb[i];
+                if (!((unsigned)(poy[i] + ky - p.pad) < (unsigned)p.H) || (!full && !(m0 + rb[i] < m_end))) src = zsrc;
+                pb[i] += sb[i];
+                poy[i] += adv_y;
+                if (poy[i] >= p.Ho) poy[i] -= p.Ho;
+            } else if (CONV) {
+                src = zsrc;
+                const int e = tid + 256 * i, row = e / B_TPR, col = (e - row * B_TPR) * 4;
+                const int m = m0 + row;
                 const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
                 if (m < m_end && k0 + col < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
                     src = reinterpret_cast<const char*>(p.x + (((int64_t)pimg[i] * p.H + iy) * p.W + ix) * p.C + c0 + col);
@@ -970,8 +1015,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
                 if (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
                 if (small_img)                                     // (images of fewer than 64 pixels: 32 rows can span several)
                     while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
-            } else if (m < m_end && k0 + col < p.K) {
-                src = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + k0 + col);
+            } else {
+                src = pb[i];
+                if (!full && !(m0 + rb[i] < m_end)) src = zsrc;
+                pb[i] += sb[i];
             }
             dst = lds0 + (unsigned)((2 * 32 * BM + buf * 32 * BN) * 4 + wave_u * 1024 + 4096 * i);
         }
@@ -1026,19 +1073,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     const int nst = (m_end - m_begin + 31) / 32;
     const int frow = lane & 31, fhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    float af[2][MT], bf[2][NT];                                  // MATH == 0: MFMA fragments of two k-steps
+    constexpr int FD = 4;                                        // MATH == 0: fragment ring, FD - 1 k-steps of LDS reads in flight
+    float af[FD][MT], bf[FD][NT];
+    // MATH == 0 tile -> column map: with two MFMA tiles per wave and operand, tile i takes the columns 2 c + i of the wave's
+    // 64 (not c + 32 i), so a lane's two A (two B) values of a k-step are NEIGHBOURS in the linear LDS row: one ds_read_b64
+    // at a compile-time offset instead of a ds_read2_b32 behind a v_add.  Only the labels of the accumulators change (the
+    // slab store below un-permutes): every output still sums its pixels in the same order -- bit-identical.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto rdf = [&](int set, int buf, int s) {
-        const float* Ab = As + buf * 32 * BM + wm * WTM;
-        const float* Bb = Bs + buf * 32 * BN + wn * WTN;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[set][i] = Ab[(2 * s + fhalf) * BM + i * 32 + frow];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[set][j] = Bb[(2 * s + fhalf) * BN + j * 32 + frow];
+        const float* Ab = As + buf * 32 * BM + wm * WTM + (2 * s + fhalf) * BM;
+        const float* Bb = Bs + buf * 32 * BN + wn * WTN + (2 * s + fhalf) * BN;
+        if constexpr (MT == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(Ab + 2 * frow);
+            af[set][0] = v[0];
+            af[set][1] = v[1];
+        } else {
+            af[set][0] = Ab[frow];
+        }
+        if constexpr (NT == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(Bb + 2 * frow);
+            bf[set][0] = v[0];
+            bf[set][1] = v[1];
+        } else {
+            bf[set][0] = Bb[frow];
+        }
     };
     if (nst > 0) {
         if constexpr (MATH == 0) {
 #pragma unroll
-            for (int it = 0; it < A_ITEMS + B_ITEMS; ++it) dma_item(0, m_begin, it);
+            for (int it = 0; it < A_ITEMS + B_ITEMS; ++it) dma_item(0, m_begin, it, m_begin + 32 <= m_end);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             load_stage(m_begin);
@@ -1047,7 +1110,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     }
     __syncthreads();
     if constexpr (MATH == 0)
-        if (nst > 0) rdf(0, 0, 0);
+        if (nst > 0) {
+#pragma unroll
+            for (int q = 0; q < FD - 1; ++q) rdf(q, 0, q);
+        }
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         if constexpr (MATH != 0)
@@ -1065,27 +1131,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
         constexpr int NI = A_ITEMS + B_ITEMS;
         const bool more = !(GRL_WGRAD_KO & 1) && st + 1 < nst;
         const bool more_rd = st + 1 < nst;
+        // fragment ring: the reads of k-step s + FD - 1 go out in front of the MFMAs of step s (a k-step is only 4 MFMAs =
+        // 256 cycles; one step of lookahead did not cover the LDS latency under load).  The last FD - 1 steps of a stage
+        // read the NEXT buffer, so the stage barrier sits in front of step 16 - (FD - 1): by then every read of this
+        // buffer has returned.
+        constexpr int SB = 16 - (FD - 1);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < 16) {
-                rdf(nxt, buf, s + 1);
-            } else {
+            if (s == SB) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (more_rd) rdf(0, buf ^ 1, 0);
             }
+            if (s + FD - 1 < 16) rdf((s + FD - 1) % FD, buf, s + FD - 1);
+            else if (more_rd) rdf((s + FD - 1) % FD, buf ^ 1, s + FD - 1 - 16);
             if (more && 2 * s < NI) {
-                const int mnext = (GRL_WGRAD_KO & 4) ? m_begin : m_begin + (st + 1) * 32;
-                dma_item(buf ^ 1, mnext, 2 * s);
-                dma_item(buf ^ 1, mnext, 2 * s + 1);
+                const int mnext = m_begin + (st + 1) * 32;
+                const bool full = mnext + 32 <= m_end;
+                dma_item(buf ^ 1, mnext, 2 * s, full);
+                dma_item(buf ^ 1, mnext, 2 * s + 1, full);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s % FD][i], bf[s % FD][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         } else {
@@ -1174,6 +1244,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     }
     float* out = p.slab + (int64_t)blockIdx.y * p.slab_stride;
     const int col_l = lane & 31;
+    if constexpr (MATH == 0) {
+        // (tile i / j of a two-tile wave holds the columns 2 c + i / 2 c + j: see rdf)
+        const bool pair_ok = NT == 2 && (p.K & 1) == 0 && (((uintptr_t)out & 7) == 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowt = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                const int n = n0 + wm * WTM + (MT == 2 ? 2 * rowt + i : rowt);
+                if (n >= p.N) continue;
+                const bool live = !(GRL_WGRAD_KO & 2) || acc[i][0][r] == 1.2345e-30f;
+                if constexpr (NT == 2) {
+                    const int k = k0 + wn * WTN + 2 * col_l;
+                    if (pair_ok && k + 1 < p.K) {
+                        if (live) *reinterpret_cast<f32x2*>(out + (int64_t)n * p.K + k) = f32x2{acc[i][0][r], acc[i][1][r]};
+                    } else {
+                        if (k < p.K && live) out[(int64_t)n * p.K + k] = acc[i][0][r];
+                        if (k + 1 < p.K && live) out[(int64_t)n * p.K + k + 1] = acc[i][1][r];
+                    }
+                } else {
+                    const int k = k0 + wn * WTN + col_l;
+                    if (k < p.K && live) out[(int64_t)n * p.K + k] = acc[i][0][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int k = k0 + wn * WTN + j * 32 + col_l;
@@ -1183,7 +1279,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (n < p.N && (!(GRL_WGRAD_KO & 2) || acc[i][j][r] == 1.2345e-30f)) out[(int64_t)n * p.K + k] = acc[i][j][r];
+                if (n < p.N) out[(int64_t)n * p.K + k] = acc[i][j][r];
             }
     }
 }

@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_cptr_t) reinterpret_cast<char*>(smem);
     const char* zsrc = reinterpret_cast<const char*>(&g_wgrad_zero_chunk);
-    asm volatile("" : "+s"(zsrc));      // keep the pointer in SGPRs: rematerialised, it is a GOT load (and an lgkmcnt(0) wait) per item
+    asm volatile("" : "+v"(zsrc));      // keep the pointer in registers: rematerialised, it is a GOT load (and an lgkmcnt(0) wait) per item
     // Dense operands: every item carries its source pointer and advances it by 32 rows per stage (a pointer that must read
     // zeros for its column stays on the zero chunk with stride 0), so a stage costs one 64-bit add per item -- plus, in
     // the one stage of a pixel range that is not full, a compare and a select.  Counters (tools/wgrad_vs_gemm_probe.py)
@@ -987,8 +987,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
         const char* src;
         unsigned dst;
         if (it < A_ITEMS) {
-            src = pa[it];
-            if (!full && !(m0 + ra[it] < m_end)) src = zsrc;
+            src = (full || m0 + ra[it] < m_end) ? pa[it] : zsrc;
             pa[it] += sa[it];
             dst = lds0 + (unsigned)((buf * 32 * BM) * 4 + wave_u * 1024 + 4096 * it);
         } else {
@@ -997,8 +996,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
                 // same-size stride-1 window: the tap's input pixel is the output pixel shifted by a constant, so the source
                 // is LINEAR in the pixel index (pointer + 32 rows per stage); the column test is fixed per item (Wo divides
                 // 32), only the row test follows the pixel's oy
-                src = pb[i];
-                if (!((unsigned)(poy[i] + ky - p.pad) < (unsigned)p.H) || (!full && !(m0 + rb[i] < m_end))) src = zsrc;
+                src = ((unsigned)(poy[i] + ky - p.pad) < (unsigned)p.H && (full || m0 + rb[i] < m_end)) ? pb[i] : zsrc;
                 pb[i] += sb[i];
                 poy[i] += adv_y;
                 if (poy[i] >= p.Ho) poy[i] -= p.Ho;
@@ -1016,8 +1014,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
                 if (small_img)                                     // (images of fewer than 64 pixels: 32 rows can span several)
                     while (poy[i] >= p.Ho) { poy[i] -= p.Ho; ++pimg[i]; }
             } else {
-                src = pb[i];
-                if (!full && !(m0 + rb[i] < m_end)) src = zsrc;
+                src = (full || m0 + rb[i] < m_end) ? pb[i] : zsrc;
                 pb[i] += sb[i];
             }
             dst = lds0 + (unsigned)((2 * 32 * BM + buf * 32 * BN) * 4 + wave_u * 1024 + 4096 * i);
@@ -1129,8 +1126,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
         // without any staging (GRL_WGRAD_KO=1) runs 15 % (dense) to 24 % (conv) faster than that.  Same MFMA order:
         // bit-identical.
         constexpr int NI = A_ITEMS + B_ITEMS;
-        const bool more = !(GRL_WGRAD_KO & 1) && st + 1 < nst;
-        const bool more_rd = st + 1 < nst;
         // fragment ring: the reads of k-step s + FD - 1 go out in front of the MFMAs of step s (a k-step is only 4 MFMAs =
         // 256 cycles; one step of lookahead did not cover the LDS latency under load).  The last FD - 1 steps of a stage
         // read the NEXT buffer, so the stage barrier sits in front of step 16 - (FD - 1): by then every read of this
@@ -1143,8 +1138,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
                 __syncthreads();
             }
             if (s + FD - 1 < 16) rdf((s + FD - 1) % FD, buf, s + FD - 1);
-            else if (more_rd) rdf((s + FD - 1) % FD, buf ^ 1, s + FD - 1 - 16);
-            if (more && 2 * s < NI) {
+            else rdf((s + FD - 1) % FD, buf ^ 1, s + FD - 1 - 16);       // (past the last stage: unused values, no branch)
+            // (no branch around the items: past the last stage every row is out of range, the items copy the zero chunk into the
+            // buffer nobody reads again -- a branch here makes hipcc drain lgkmcnt at its join, once per stage)
+            if (!(GRL_WGRAD_KO & 1) && 2 * s < NI) {
                 const int mnext = m_begin + (st + 1) * 32;
                 const bool full = mnext + 32 <= m_end;
                 dma_item(buf ^ 1, mnext, 2 * s, full);

@@ -140,6 +140,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     const char* dma_a[DMA ? BM / 32 : 1];
     const char* dma_b[DMA ? BN / 32 : 1];
     int dma_iy0[DMA && CONV ? BM / 32 : 1], dma_ix0[DMA && CONV ? BM / 32 : 1];      // conv: window origin of the row
+    // PIPE conv: per row, the address of its window origin (tap (0,0), channel 0; may lie outside the image -- only
+    // dereferenced where the mask allows) and a bit per tap that falls inside the image.  A stage then costs a row one
+    // AND, one compare, one 64-bit add of the wave-uniform tap offset and the select against the zero page, instead of two
+    // adds, two range tests and a 64-bit multiply-add chain (a plain VALU instruction takes ~4 cycles from the matrix pipe
+    // whatever the occupancy: tools/hw_probe/mfma_valu_overlap.hip)
+    const char* cbase[PIPE && CONV ? BM / 32 : 1];
+    uint32_t cmask[PIPE && CONV ? BM / 32 : 1];
     uint32_t pv_a[PIPE ? BM / 32 : 1], pv_b[PIPE ? BN / 32 : 1];                      // PIPE: per-lane byte offsets from the tile's row 0
     const char *pbase_a = nullptr, *pbase_b = nullptr;                                // PIPE: the tile's A / W row 0 (wave-uniform)
     int m0, n0, tile_m;
@@ -206,6 +213,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                     dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)img * p.H * p.W * p.C) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
                     dma_iy0[i] = oy * p.stride - p.pad;
                     dma_ix0[i] = ox * p.stride - p.pad;
+                    if constexpr (PIPE) {
+                        cbase[i] = dma_a[i] + ((int64_t)(dma_iy0[i] * p.W + dma_ix0[i]) * p.C) * ESZ;
+                        uint32_t mk = 0;
+                        for (int ky = 0, t = 0; ky < p.kh; ++ky)
+                            for (int kx = 0; kx < p.kw; ++kx, ++t)
+                                if ((unsigned)(dma_iy0[i] + ky) < (unsigned)p.H && (unsigned)(dma_ix0[i] + kx) < (unsigned)p.W) mk |= 1u << t;
+                        cmask[i] = mk;
+                    }
                 } else {
                     dma_a[i] = reinterpret_cast<const char*>(p.a) + ((int64_t)m * p.lda) * ESZ + ((d_chunk ^ ((r >> 1) & 7)) << 4);
                 }
@@ -231,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     // pieces (pn_src), so the address arithmetic interleaves with MFMAs instead of sitting in front of the DMA issue
     int pky = 0, pkx = 0, pc0 = 0;
     const char* pn_src[PIPE && CONV ? BM / 32 : 1];
+    const char* czero = reinterpret_cast<const char*>(g_zero_chunks) + (d_chunk << 4);
+    if constexpr (PIPE && CONV) asm volatile("" : "+v"(czero));       // (kept in registers: rematerialised it is a GOT load per use)
     auto conv_tap_reset = [&]() { pky = pkx = pc0 = 0; };
     auto conv_tap_advance = [&]() {
         pc0 += KST;
@@ -241,13 +258,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     };
     auto conv_addrs = [&]() {
         if constexpr (PIPE && CONV) {
+            const int64_t toff = ((int64_t)(pky * p.W + pkx) * p.C + pc0) * ESZ;       // wave-uniform
+            const uint32_t bit = 1u << (pky * p.kw + pkx);
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i) {
-                const int iy = dma_iy0[i] + pky, ix = dma_ix0[i] + pkx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                pn_src[i] = ok ? dma_a[i] + ((int64_t)(iy * p.W + ix) * p.C + pc0) * ESZ
-                               : reinterpret_cast<const char*>(g_zero_chunks) + (d_chunk << 4);
-            }
+            for (int i = 0; i < BM / 32; ++i)
+                pn_src[i] = (cmask[i] & bit) ? cbase[i] + toff : czero;
         }
     };
     auto dma_piece = [&](int buf, int ks, int i) {
@@ -1236,7 +1251,7 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
     static const bool dma_conv_on = [] { const char* e = getenv("GRL_GEMM_DMA_CONV"); return !e || atoi(e) != 0; }();
     if (d.conv) {
         constexpr bool CAN_DMA_CONV = (MATH == 0 || MATH == 2) && BM == 128;
-        if (CAN_DMA_CONV && dma_conv_on && d.ldw < (1 << 22)) {
+        if (CAN_DMA_CONV && dma_conv_on && d.ldw < (1 << 22) && d.kh * d.kw <= 32) {     // (one validity bit per tap)
             if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
             else launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, false, CAN_DMA_CONV>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, true, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);

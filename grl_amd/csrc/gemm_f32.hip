@@ -1261,7 +1261,8 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
         static const bool dma_on = [] { const char* e = getenv("GRL_GEMM_DMA"); return !e || atoi(e) != 0; }();
         constexpr bool CAN_DMA = (MATH == 0 || MATH == 2) && BM == 128;     // 128-byte operand rows (fp32 x 32 / bf16 x 64)
         // (the hand-scheduled loop addresses a tile's rows with 32-bit byte offsets from its first row: 127 rows x ld x 4 B)
-        if (CAN_DMA && dma_on && d.K >= 256 && d.lda < (1 << 22) && d.ldw < (1 << 22)) {
+        static const int dma_mink = [] { const char* e = getenv("GRL_GEMM_DMA_MINK"); return e ? atoi(e) : 256; }();
+        if (CAN_DMA && dma_on && d.K >= dma_mink && d.lda < (1 << 22) && d.ldw < (1 << 22)) {
             if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
             else launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, false, CAN_DMA>>(d, s, lds, tiles_n, num_tiles, vec_epi);
         } else if (seg) launch_kernel<gemm_f32_kernel<BM, BN, false, MATH, CAN_SEG>>(d, s, lds, tiles_n, num_tiles, vec_epi);

@@ -1121,6 +1121,7 @@ int64_t splitk_floats(const GrlGemm& d) {
 }
 
 struct TileChoice { int bm, bn, smode = 0; };
+int g_force_tile = 0;                 // grl_gemm_force_tile: (bm << 16) | bn, 0 = automatic
 
 TileChoice legacy_tile(const GrlGemm& d) {
     if (d.epilogue == GRL_EPI_SQDIFF) return {128, 128};          // pinned: fixed reduction order (see the epilogue)
@@ -1135,6 +1136,7 @@ TileChoice legacy_tile(const GrlGemm& d) {
         }
         return f;
     }();
+    if (g_force_tile) return {g_force_tile >> 16, g_force_tile & 0xffff};
     if (forced.bm) return forced;
     // Measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 128x128
     // tile wins when the K loop is long (>= 1024: 131-135 TFLOP/s); short-K layers are
@@ -1330,6 +1332,15 @@ int validate(const GrlGemm& d) {
 }
 
 }  // namespace
+
+extern "C" int grl_gemm_force_tile(int bm, int bn) {
+    const int prev = g_force_tile;
+    if (bm == 0 && bn == 0) { g_force_tile = 0; return prev; }
+    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 64 && bn == 128))
+        return grl_fail(GRL_EINVAL, "gemm_force_tile: tiles are 128x128, 128x64, 64x64");
+    g_force_tile = (bm << 16) | bn;
+    return prev;
+}
 
 extern "C" int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc) {
     if (!desc) return grl_fail(GRL_EINVAL, "null desc");

@@ -36,7 +36,7 @@ const char* grl_last_error(void);
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
  * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*;
  * round 4: 6 with grl_bottleneck_tail_bf16). */
-#define GRL_ABI_VERSION 6
+#define GRL_ABI_VERSION 7
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */
@@ -130,6 +130,11 @@ int64_t grl_conv_gemm_f32_workspace_floats(const GrlGemm* desc);
  * 0 = never, 1 = whenever the shape is legal.  Returns the previous mode; results do not depend
  * on it (same MFMA, same k order).  Not thread-safe. */
 int grl_gemm_bf16_tile_mode(int mode);
+/* Kernel-tuning / test hook of the fp32-storage datapaths: force the workgroup tile of the following grl_conv_gemm_f32
+ * calls to bm x bn (128x128, 128x64 or 64x64); (0, 0) returns to the per-shape rule.  Returns the previous setting as
+ * (bm << 16) | bn (0 = automatic), GRL_EINVAL for any other pair.  Results never depend on the tile (one k-ordered
+ * chain per output; the parity tests run every shape on every tile through this).  Not thread-safe. */
+int grl_gemm_force_tile(int bm, int bn);
 /* rows of the stats slab the call above writes (= number of M tiles it will use) */
 int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc);
 

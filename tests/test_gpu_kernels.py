@@ -559,9 +559,9 @@ def test_gemm_and_conv_fuzz_bit_exact(dev):
     float4 epilogues), every tile shape, more tiles than resident workgroups (a persistent
     workgroup then walks several tiles with the next tile's stage prefetched), rectangular and
     even-sized conv kernels, pad 0, stride 2, and the forced tile shapes."""
-    import os
-    from grl_amd import engine
+    from grl_amd import engine, _lib
     from oracle.ref_c import chain_gemm
+    lib = _lib.load()
     rng = np.random.default_rng(2024)
     dense = [(int(rng.integers(1, 700)), int(rng.integers(1, 300)), 32 * int(rng.integers(1, 9))) for _ in range(10)]
     dense += [(70000, 192, 64), (33000, 72, 96), (1100 * 128 // 8, 64, 32)]       # > 768 / 1024 tiles
@@ -569,16 +569,16 @@ def test_gemm_and_conv_fuzz_bit_exact(dev):
         a = rng.standard_normal((M, K)).astype(np.float32)
         w = rng.standard_normal((N, K)).astype(np.float32)
         ref = chain_gemm(a, w)
-        for tile in (None, '64x64', '128x64', '128x128'):
+        for tile in (None, (64, 64), (128, 64), (128, 128)):
             if tile and M * N > 4e6:
                 continue
-            os.environ.pop('GRL_GEMM_TILE', None)
-            if tile:
-                os.environ['GRL_GEMM_TILE'] = tile
-            y = torch.full((M, N), 7.0, device=dev)
-            engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K)
+            lib.grl_gemm_force_tile(*(tile or (0, 0)))         # (per call; GRL_GEMM_TILE is read once per process)
+            try:
+                y = torch.full((M, N), 7.0, device=dev)
+                engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K)
+            finally:
+                lib.grl_gemm_force_tile(0, 0)
             assert np.array_equal(y.cpu().numpy(), ref), (M, N, K, tile)
-    os.environ.pop('GRL_GEMM_TILE', None)
     convs = [(32, 40, 3, 3, 1, 1, 9, 7, 3), (64, 64, 1, 2, 1, 0, 8, 8, 2), (32, 96, 2, 2, 1, 0, 6, 10, 2),
              (64, 33, 3, 3, 2, 1, 12, 8, 5), (32, 64, 2, 1, 1, 0, 7, 5, 4), (96, 130, 1, 1, 2, 0, 10, 6, 3),
              (64, 64, 3, 3, 1, 1, 64, 32, 70)]                                     # 143360 rows: 2240 tiles
@@ -591,6 +591,47 @@ def test_gemm_and_conv_fuzz_bit_exact(dev):
         engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), y, n * Ho * Wo, cout, kh * kw * cin,
                     conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad))
         assert np.array_equal(y.cpu().numpy(), ref), (cin, cout, kh, kw, stride, pad, H, W, n)
+
+
+@pytest.mark.parametrize('tile', [(128, 128), (128, 64)])
+def test_hand_scheduled_stage_loop_ragged_edges_bit_exact(dev, tile):
+    """The LDS-DMA kernels' hand-scheduled stage loop (gemm_f32.hip PIPE: hidden DMA pieces, fragments carried across the
+    stage barrier, per-tile conv validity bits) on every edge it has: M and N that end inside a tile (clamped rows),
+    K = 256 .. 2304 (8 .. 72 stages, odd and even), more tiles than resident workgroups (next tile's first stage issued
+    behind the epilogue), strided A (lda > K), implicit-GEMM windows with stride 2 / no padding / images that end inside
+    a tile -- each on both 128-row tiles, bit for bit against the C oracle's fmaf chain."""
+    from grl_amd import engine, _lib
+    from oracle.ref_c import chain_gemm
+    lib = _lib.load()
+    rng = np.random.default_rng(7 + tile[1])
+    lib.grl_gemm_force_tile(*tile)
+    try:
+        for M, N, K in [(300, 200, 256), (129, 257, 512), (1000, 130, 288), (77, 64, 2304), (40000, 136, 320)]:
+            a = rng.standard_normal((M, K)).astype(np.float32)
+            w = rng.standard_normal((N, K)).astype(np.float32)
+            y = torch.full((M, N), 7.0, device=dev)
+            engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K)
+            assert np.array_equal(y.cpu().numpy(), chain_gemm(a, w)), (M, N, K)
+        # strided A: the GEMM reads K columns of a wider matrix
+        M, N, K, lda = 500, 96, 384, 640
+        a = rng.standard_normal((M, lda)).astype(np.float32)
+        w = rng.standard_normal((N, K)).astype(np.float32)
+        y = torch.empty(M, N, device=dev)
+        engine.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), y, M, N, K, lda=lda)
+        assert np.array_equal(y.cpu().numpy(), chain_gemm(np.ascontiguousarray(a[:, :K]), w))
+        for cin, cout, kh, kw, stride, pad, H, W, n in [(64, 72, 3, 3, 1, 1, 9, 7, 5), (96, 40, 3, 3, 2, 1, 11, 13, 3),
+                                                         (256, 130, 1, 1, 2, 0, 10, 6, 7), (32, 64, 3, 2, 1, 0, 12, 9, 4),
+                                                         (128, 64, 3, 3, 1, 1, 16, 8, 33)]:
+            x = rng.standard_normal((n, H, W, cin)).astype(np.float32)
+            w = (rng.standard_normal((cout, kh * kw * cin)) / np.sqrt(cin * kh * kw)).astype(np.float32)
+            cols, Ho, Wo = _im2col(x, kh, kw, stride, pad)
+            y = torch.empty(n * Ho * Wo, cout, device=dev)
+            engine.gemm(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), y, n * Ho * Wo, cout, kh * kw * cin,
+                        conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad))
+            assert np.array_equal(y.cpu().numpy(), chain_gemm(cols, w)), (cin, cout, kh, kw, stride, pad, H, W, n)
+    finally:
+        lib.grl_gemm_force_tile(0, 0)
+    assert lib.grl_gemm_force_tile(64, 128) < 0 and lib.grl_gemm_force_tile(0, 0) == 0      # illegal pair refused, state untouched
 
 
 def test_device_augmentation_matches_reference_transforms(dev, golden):

@@ -317,6 +317,53 @@ def test_oim_out_of_range_labels_do_not_touch_memory():
     assert changed == [False, False, True, False, False, True]
 
 
+@pytest.mark.parametrize('cin,cout,kh,kw,stride,pad,H,W,n', [
+    (64, 64, 3, 3, 1, 1, 16, 8, 5),       # same-size window, Wo divides 32: the linear-source fast path; 640 pixels
+    (128, 96, 3, 3, 1, 1, 32, 16, 3),     # ... Wo = 16, N ends inside a tile
+    (64, 40, 3, 3, 1, 1, 64, 32, 1),      # ... Wo = 32
+    (64, 64, 3, 3, 1, 1, 10, 6, 7),       # same size but Wo = 6: the generic pixel walk
+    (128, 72, 3, 3, 2, 1, 16, 16, 3),     # stride 2
+    (256, 64, 1, 1, 2, 0, 8, 8, 9),       # 1x1 / s2 downsample window
+    (64, 64, 3, 3, 1, 1, 4, 8, 9),        # 32-pixel images: a stage spans a whole image (C must be a multiple of 64)
+])
+def test_wgrad_conv_windows_fp32(cin, cout, kh, kw, stride, pad, H, W, n):
+    """fp32 weight gradient of an implicit-GEMM convolution, dW[o][c][tap] = sum_m dz[m][o] * x[window(m, tap)][c]: the
+    kernel's stage items come from per-item pointers (same-size stride-1 windows: a source that is linear in the pixel
+    index, with the column test fixed per item and the row test following the pixel) or from the generic pixel walk;
+    out-of-image taps, rows past the pixel range and columns past N / K read a zero chunk.  Operands sit inside
+    NaN-poisoned allocations: any read outside the window or past the range shows."""
+    from grl_amd import train_engine as TE
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(cin + 7 * H + W)
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    M, K = n * Ho * Wo, kh * kw * cin
+    x = rng.standard_normal((n, H, W, cin)).astype(np.float32)
+    dz = rng.standard_normal((M, cout)).astype(np.float32)
+    xp = np.zeros((n, H + 2 * pad, W + 2 * pad, cin), np.float64)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    cols = np.empty((n, Ho, Wo, kh * kw, cin), np.float64)
+    for ky in range(kh):
+        for kx in range(kw):
+            cols[:, :, :, ky * kw + kx] = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride]
+    ref = dz.astype(np.float64).T @ cols.reshape(M, K)                     # [cout][tap][c]
+    ref = ref.reshape(cout, kh * kw, cin).transpose(0, 2, 1).reshape(cout, K)       # dW leaves in torch layout [cout][c][kh][kw]
+    guard = 4096
+    bx = torch.full((n * H * W * cin + 2 * guard,), float('nan'), device=dev)
+    bz = torch.full((M * cout + 2 * guard,), float('nan'), device=dev)
+    bx[guard:guard + x.size] = torch.from_numpy(x.reshape(-1)).to(dev)
+    bz[guard:guard + dz.size] = torch.from_numpy(dz.reshape(-1)).to(dev)
+    xd = bx[guard:guard + x.size].view(n * H * W, cin)
+    dzd = bz[guard:guard + dz.size].view(M, cout)
+    dw = torch.zeros(cout, K, device=dev)
+    TE.wgrad(dzd, xd, dw, M, cout, K, conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad), accumulate=0)
+    got = dw.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) < 2e-6, _rel(got, ref)
+    dw2 = torch.zeros(cout, K, device=dev)
+    TE.wgrad(dzd, xd, dw2, M, cout, K, conv=(H, W, cin, Ho, Wo, kh, kw, stride, pad), accumulate=0)
+    assert torch.equal(dw, dw2)                           # private slabs, fixed reduction order: run-to-run identical
+
+
 @pytest.mark.parametrize('M,N,K', [(4, 2048, 128), (4, 128, 2048), (2, 32, 2048), (7, 64, 64), (33, 96, 160), (4, 1024, 512)])
 def test_wgrad_tiny_M_ignores_memory_past_the_operands(M, N, K):
     """dW = dz^T X with a handful of rows (TRL channel MLP: M = clips; verification head: M = pairs):

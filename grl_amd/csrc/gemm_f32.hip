@@ -1165,10 +1165,15 @@ TileChoice legacy_tile(const GrlGemm& d) {
     static const int bnz_narrow_k = [] { const char* e = getenv("GRL_GEMM_BNZ_NARROW"); return e ? atoi(e) : 512; }();
     const bool bnz_narrow = d.bn_z && d.math == GRL_MATH_F32 && d.K <= bnz_narrow_k;
     if (wide_on && !bnz_narrow && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
-        tiles(128, 128) >= 256 && !(d.res && d.K <= 128))
+        tiles(128, 128) >= 256 && !(d.res && d.K <= (d.stats ? 128 : 512)))
         return {128, 128};
     if (d.K <= 128) return {64, 64};
-    if (d.K <= 512) return tiles(128, 64) >= 448 ? TileChoice{128, 64} : TileChoice{64, 64};
+    // (round 4, re-measured per shape with grl_gemm_force_tile after the hand-scheduled loop: a residual-carrying K <= 512
+    // layer is better off on the 128 x 64 tile, which requests its residual rows before the LDS round trip -- 16384x2048x512
+    // 299 -> 284 us, 16384x1024x256 86 -> 83 --, and from one dense 128 x 64 tile per CU on that tile beats twice as many
+    // 64 x 64 ones -- 4096x512x512 25 -> 22 us.  The statistics GEMMs keep their thresholds: their tile is part of the
+    // partial sums' order)
+    if (d.K <= 512) return tiles(128, 64) >= ((d.stats || d.conv) ? 448 : 256) ? TileChoice{128, 64} : TileChoice{64, 64};
     if (tiles(128, 128) >= 448) return {128, 128};
     // (128-row tiles of a dense operand stage by LDS-DMA: from one tile per CU on they beat four times as many 64 x 64
     // tiles -- 4096 x 512 x 2048: 84.8 vs 95.7 us)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-shape timing of grl_conv_gemm_f32 on the shapes of one eval step (B x T = 32 x 4).
   python tools/gemm_bench.py [tile ...]     e.g.  128x128 128x64 64x64
-Each tile is forced through GRL_GEMM_TILE; 'auto' uses the library heuristic."""
+Each tile is forced through grl_gemm_force_tile; 'auto' uses the library heuristic.  The first rows of a cold
+process run on ramping clocks: warm the box with one throw-away run before comparing columns."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,10 +31,11 @@ def bench(tile, iters=20):
     elif tile in ('bf16x3', 'bf16', 'f32', 'bf16s'):
         math = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16s': 2}[tile]
         tile = 'auto'
+    from grl_amd import _lib
     if tile == 'auto':
-        os.environ.pop('GRL_GEMM_TILE', None)
+        _lib.load().grl_gemm_force_tile(0, 0)
     else:
-        os.environ['GRL_GEMM_TILE'] = tile
+        _lib.load().grl_gemm_force_tile(*(int(v) for v in tile.split('x')))      # (GRL_GEMM_TILE is read once per process)
     dev = torch.device('cuda:0')
     res = {}
     for (M, N, K, conv, calls, has_res) in SHAPES:

@@ -150,14 +150,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     uint32_t pv_a[PIPE ? BM / 32 : 1], pv_b[PIPE ? BN / 32 : 1];                      // PIPE: per-lane byte offsets from the tile's row 0
     const char *pbase_a = nullptr, *pbase_b = nullptr;                                // PIPE: the tile's A / W row 0 (wave-uniform)
     int m0, n0, tile_m;
+    const int tiles_m = num_tiles / tiles_n;
+    const int panel_w = (vec_epi & 8) && tiles_n > 8 && (tiles_n & 7) == 0 ? 8 : 0;         // (host: bit 3 of vec_epi)
     auto setup_tile = [&](int t) {
         int bid = t;
         {
             const int q = num_tiles >> 3, r = num_tiles & 7, xcd = bid & 7;
             bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         }
-        tile_m = bid / tiles_n;
-        const int tile_n = bid - tile_m * tiles_n;
+        // Column panels of 8 tiles (GRL_GEMM_PANEL): with more than 8 column tiles the plain row-major walk hands the 64
+        // tiles an XCD runs at a time as 4 rows x 16 columns (N = 2048) -- 20 operand panels per k-slice through its L2 --
+        // where 8 x 8 needs 16.  Each panel is walked over ALL row tiles before the next panel starts.
+        int tile_n;
+        if (panel_w > 0) {
+            const int per_panel = tiles_m * panel_w;
+            const int pn = bid / per_panel, rem = bid - pn * per_panel;
+            tile_m = rem / panel_w;
+            tile_n = pn * panel_w + (rem - tile_m * panel_w);
+        } else {
+            tile_m = bid / tiles_n;
+            tile_n = bid - tile_m * tiles_n;
+        }
         m0 = tile_m * BM;
         n0 = tile_n * BN;
         // ---- per-thread staging rows ----------------------------------------
@@ -637,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     // ---- epilogue --------------------------------------------------------------
     // acc[i][j][r] is Y[row][col] with row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31
     auto epilogue = [&](const int m0, const int n0, const int tile_m) {
-    if (vec_epi) {
+    if (vec_epi & 1) {
         // Wide path (N, ldy, ldres multiples of 4, 16-B aligned bases): each wave parks its
         // sub-tile in LDS (the A/B stages are dead: the K loop ended on a barrier) and
         // reads it back row-major, so every lane owns 4 consecutive channels of one
@@ -810,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
             // the 64 x 64 tile (smode 1: one slab row per 64 rows) or the 128 x 64 tile (smode 2) forms them: a row class
             // r mod 8 is added in row order within a 32-row (1) / 64-row (2) block, classes combine as the xor-shuffle
             // tree of an 8-lane column group, ((0+1)+(2+3)) + ((4+5)+(6+7)), then the blocks / wave rows.
-            const int smode = vec_epi >> 1;
+            const int smode = (vec_epi >> 1) & 3;
             if (smode != 0) {
                 auto run = [&](auto mode_a) {
                     constexpr bool A = decltype(mode_a)::value;
@@ -1250,8 +1263,9 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
                                                             : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
-    const int vec_epi = vec_epilogue_ok(d) ? 1 | (smode << 1) : 0;           // (bits 1..2: the statistics' order, choose_tile)
-    if (MATH == 2 && !vec_epi)
+    static const bool panel_on = [] { const char* e = getenv("GRL_GEMM_PANEL"); return !e || atoi(e) != 0; }();
+    const int vec_epi = (vec_epilogue_ok(d) ? 1 | (smode << 1) : 0) | (panel_on ? 8 : 0);     // (bits 1..2: the statistics' order, choose_tile; bit 3: column-panel tile walk)
+    if (MATH == 2 && !(vec_epi & 1))
         return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
     constexpr bool CAN_SEG = MATH == 0;
     const bool seg = CAN_SEG && d.kblock && d.K > SEG_STAGES * BK;

@@ -1178,7 +1178,7 @@ TileChoice legacy_tile(const GrlGemm& d) {
     static const int bnz_narrow_k = [] { const char* e = getenv("GRL_GEMM_BNZ_NARROW"); return e ? atoi(e) : 512; }();
     const bool bnz_narrow = d.bn_z && d.math == GRL_MATH_F32 && d.K <= bnz_narrow_k;
     if (wide_on && !bnz_narrow && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
-        tiles(128, 128) >= 256 && !(d.res && d.K <= (d.stats ? 128 : 512)))
+        tiles(128, 128) >= (d.conv ? 448 : 256) && !(d.res && d.K <= (d.stats ? 128 : 512)))     // (conv with 256..447 wide tiles: 512+ tiles of 128 x 64 -- 16384x256x2304: 159 -> 152 us)
         return {128, 128};
     if (d.K <= 128) return {64, 64};
     // (round 4, re-measured per shape with grl_gemm_force_tile after the hand-scheduled loop: a residual-carrying K <= 512

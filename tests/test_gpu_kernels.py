@@ -606,7 +606,9 @@ def test_hand_scheduled_stage_loop_ragged_edges_bit_exact(dev, tile):
     rng = np.random.default_rng(7 + tile[1])
     lib.grl_gemm_force_tile(*tile)
     try:
-        for M, N, K in [(300, 200, 256), (129, 257, 512), (1000, 130, 288), (77, 64, 2304), (40000, 136, 320)]:
+        # (N = 2048 / 3072: 16 / 24 column tiles on the 128-wide tile, 32 / 48 on the 64-wide one -- the column-panel tile walk)
+        for M, N, K in [(300, 200, 256), (129, 257, 512), (1000, 130, 288), (77, 64, 2304), (40000, 136, 320),
+                        (1200, 2048, 256), (700, 3072, 288)]:
             a = rng.standard_normal((M, K)).astype(np.float32)
             w = rng.standard_normal((N, K)).astype(np.float32)
             y = torch.full((M, N), 7.0, device=dev)

@@ -46,6 +46,9 @@ constexpr int BK = 32;
 #define GRL_GEMM_KO 0     // tools/gemm_ko.sh: timing-only knock-outs (1 no in-loop staging, 2 no stage barrier, 4 no epilogue, 8 all stages from k = 0); wrong results
 #endif
 constexpr int SEG_STAGES = 16;     // fp32 path: accumulator segment = 16 stages = 512 k
+#ifndef GRL_GEMM_RING3
+#define GRL_GEMM_RING3 1  // bf16-storage 128 x 64 LDS-DMA kernel: three stage buffers, DMA two stages ahead (0: compiler-scheduled two-stage loop)
+#endif
 #ifndef GRL_GEMM_PIPE
 #define GRL_GEMM_PIPE 1   // hand-scheduled stage loop of the dense fp32 LDS-DMA kernels (0: the compiler-scheduled loop)
 #endif
@@ -114,14 +117,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + elem_off * ESZ);
     };
     constexpr int A_ITEMS = BM / 32, B_ITEMS = BN / 32;   // 16-B items per thread per stage
+    // RING (bf16 storage, 128 x 64): a stage of that kernel is 8 MFMAs of 32 cycles per wave -- 0.1-0.2 us -- behind a DMA
+    // one stage deep: it waited for memory every stage (10-14 % MFMA busy; the hand-scheduled two-stage loop alone: +-0).
+    // Three 24 KB stage buffers (72 KB: still two workgroups per CU), pieces requested TWO stages ahead, counted
+    // `vmcnt(NP)` at the stage barrier (the newest stage's pieces may still be in flight).
+    constexpr bool RING = GRL_GEMM_PIPE && GRL_GEMM_RING3 && DMA && MATH == 2 && BM == 128 && BN == 64;
+    constexpr int NST = RING ? 3 : 2;
+    constexpr bool PIPE = (GRL_GEMM_PIPE && DMA && MATH == 0 && BM == 128) || RING;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [2][BM*32]           (MATH == 0)
-    float* Bs = smem + 2 * BM * BK;       // [2][BN*32]
+    float* Bs = smem + NST * BM * BK;     // [NST][BN*32]
     constexpr int PL = MATH == 3 ? 2 : 1; // bf16 planes per operand (hi, lo)
     char* const Ah = reinterpret_cast<char*>(smem);                // [2][PL][BM][64 B]
     char* const Bh = Ah + 2 * PL * BM * 64;                        // [2][PL][BN][64 B]
 
-    constexpr bool PIPE = GRL_GEMM_PIPE && DMA && MATH == 0 && BM == 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = PIPE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                 else dma16_hidden(pbase_a + kb, pv_a[i], dst);
             } else
                 dma16_hidden(pbase_b + kb, pv_b[i - BM / 32],
-                             lds_base + (uint32_t)((2 * BM * BK + buf * BN * BK) * 4 + (wave + 4 * (i - BM / 32)) * 1024));
+                             lds_base + (uint32_t)((NST * BM * BK + buf * BN * BK) * 4 + (wave + 4 * (i - BM / 32)) * 1024));
         }
     };
     auto dma_stage = [&](int buf, int ks) {
@@ -425,7 +434,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     }
 
     store_stage(0);
-    if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int NP_ALL = BM / 32 + BN / 32;              // DMA pieces of one stage per wave
+    if constexpr (RING) {
+        // the tile's SECOND stage follows its first at once (buffer 1 is free: the previous tile ended on a barrier)
+        if (nk > 1) {
+            if constexpr (CONV) { conv_tap_advance(); conv_addrs(); }
+#pragma unroll
+            for (int i = 0; i < NP_ALL; ++i) dma_piece(1, 1, i);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP_ALL) : "memory");      // stage 0 has landed, stage 1 may be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (PIPE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     // PIPE: fragments double-buffered in registers ACROSS the stage boundary.  Stage ks (buffer b): chunk q's 16 MFMAs run
@@ -453,11 +475,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
     };
     if constexpr (PIPE) prd(0, 0, 0);
 
+    int rbuf = 0;                                          // RING: the stage buffer of stage ks (ks % 3)
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+        const int buf = RING ? rbuf : (ks & 1);
         if constexpr (!PIPE)
             if (!(GRL_GEMM_KO & 1) && ks + 1 < nk) { load_stage(ks + 1); dma_stage(buf ^ 1, ks + 1); }
-        if constexpr (PIPE) {
+        if constexpr (RING) {
+            const int b1 = buf == 2 ? 0 : buf + 1;            // stage ks+1's buffer
+            const int b2 = b1 == 2 ? 0 : b1 + 1;              // stage ks+2's (= stage ks-1's: released by the previous barrier)
+            const bool more = ks + 1 < nk, more2 = ks + 2 < nk;
+            constexpr int NA = BM / 32, NB = BN / 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+                    prd((q + 1) & 1, buf, q + 1);
+                } else {
+                    if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");     // stage ks+1 landed; ks+2 in flight
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (more) prd(0, b1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // a chunk is ONE v_mfma_f32_32x32x16_bf16 per tile pair (the 16-byte fragment holds 8 k)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, paf[q & 1][i]),
+                                                                            __builtin_bit_cast(bf16x8, pbf[q & 1][j]), acc[i][j], 0, 0, 0);
+                // stage ks+2's pieces behind chunks 0 and 1 (dense: half and half; conv: the W pieces, then -- after the
+                // gather addresses -- the A pieces)
+                if (more2 && q < 2) {
+                    const int first = CONV ? (q == 0 ? NA : 0) : (q == 0 ? 0 : (NA + NB) / 2);
+                    const int cnt = CONV ? (q == 0 ? NB : NA) : (NA + NB) / 2;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < (CONV ? (NA > NB ? NA : NB) : (NA + NB) / 2); ++k)
+                        if (k < cnt) dma_piece(b2, ks + 2, first + k);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (CONV && q == 0) { conv_tap_advance(); conv_addrs(); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rbuf = b1;
+        } else if constexpr (PIPE) {
             const bool more = ks + 1 < nk;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1259,7 +1320,8 @@ template <int BM, int BN, int MATH>
 int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    constexpr size_t stage_bytes = (MATH == 0 || MATH == 2) ? (size_t)2 * (BM + BN) * BK * sizeof(float)
+    constexpr int NST = (GRL_GEMM_PIPE && GRL_GEMM_RING3 && MATH == 2 && BM == 128 && BN == 64) ? 3 : 2;      // (the kernel's RING)
+    constexpr size_t stage_bytes = (MATH == 0 || MATH == 2) ? (size_t)NST * (BM + BN) * BK * sizeof(float)
                                                             : (size_t)2 * (MATH == 3 ? 2 : 1) * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * BN * sizeof(float);       // epilogue staging
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;

@@ -395,6 +395,50 @@ def test_gemm_bf16_storage(dev, M, N, K, conv):
     assert torch.equal(y, y32.bfloat16())                               # one rounding on the store
 
 
+@pytest.mark.parametrize('M,N,K,conv', [
+    (512, 256, 2048, None), (300, 200, 256, None), (129, 72, 64, None), (5000, 136, 320, None), (8192, 512, 128, None),
+    (5 * 16 * 8, 128, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1)), (3 * 8 * 8, 96, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1)),
+    (7 * 5 * 3, 136, 256, (10, 6, 256, 5, 3, 1, 1, 2, 0))])
+def test_gemm_bf16_storage_ring_tile_equals_two_stage_tiles(dev, M, N, K, conv):
+    """The bf16-storage 128 x 64 LDS-DMA kernel runs a THREE-stage ring (pieces two stages ahead, counted waits, a tile's
+    second stage requested with its first, K of 1 / 2 / 3 / many stages, conv gather with the tap state advanced two stages
+    ahead); the 128 x 128 and 64 x 64 tiles run the two-stage loops.  Same MFMA, same k order: all three bit-identical,
+    with a residual / ReLU / per-channel affine epilogue, ragged M and N, more tiles than resident workgroups; and equal
+    to the exact fp32 path on the same values up to the summation order inside the bf16 MFMA."""
+    from grl_amd import engine, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5 + M + K)
+    cin = K if conv is None else conv[2]
+    rows_in = M if conv is None else (M // (conv[3] * conv[4])) * conv[0] * conv[1]
+    a = torch.from_numpy(rng.standard_normal((rows_in, cin)).astype(np.float32)).bfloat16().to(dev)
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).bfloat16().to(dev)
+    res = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).bfloat16().to(dev)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(dev)
+    sh = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    outs = {}
+    old = lib.grl_gemm_bf16_tile_mode(0)                       # keep the 256 x 256 kernel out of it
+    try:
+        for tile in ((128, 128), (128, 64), (64, 64)):
+            lib.grl_gemm_force_tile(*tile)
+            y = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev)
+            engine.gemm(a, w, y, M, N, K, scale=sc, shift=sh, res=res, relu=True, conv=conv, math=2)
+            outs[tile] = y
+    finally:
+        lib.grl_gemm_force_tile(0, 0)
+        lib.grl_gemm_bf16_tile_mode(old)
+    assert torch.equal(outs[(128, 64)], outs[(128, 128)]) and torch.equal(outs[(128, 64)], outs[(64, 64)])
+    # ... and right: the exact fp32 path on the same (bf16-representable) values, up to the products' summation order
+    ref, y32 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    engine.gemm(a.float(), w.float(), ref, M, N, K, scale=sc, shift=sh, res=res.float(), relu=True, conv=conv, math=0)
+    lib.grl_gemm_bf16_tile_mode(0); lib.grl_gemm_force_tile(128, 64)
+    try:
+        engine.gemm(a, w, y32, M, N, K, scale=sc, shift=sh, res=res, relu=True, conv=conv, math=2, out_f32=True)
+    finally:
+        lib.grl_gemm_force_tile(0, 0); lib.grl_gemm_bf16_tile_mode(old)
+    assert _rel(y32.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert torch.equal(outs[(128, 64)], y32.bfloat16())
+
+
 @pytest.mark.parametrize('M,N,K,conv', [(49152, 256, 512, None), (65536, 512, 128, None), (49152 + 136, 264, 192, None),
                                         (48 * 32 * 32, 256, 9 * 64, (32, 32, 64, 32, 32, 3, 3, 1, 1))])
 def test_gemm_bf16_256_kernel_selected_vs_torch_fp32(dev, M, N, K, conv):

@@ -60,7 +60,7 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 // `res` (row mapping res_rows / res_gstride), squared, summed per 32-row block in a fixed order (a lane over its 4 rows,
 // then the 8 lanes that own the same 8 channels by xor-shuffles) and written as fp32 partials y[M/32][N]: conv_f1's
 // output never reaches HBM (grl_model.py:146-149), as in the fp32 kernel.
-template <bool CONV, bool STATS = false, bool SQD = false>
+template <bool CONV, bool STATS = false, bool SQD = false, bool RES = false, bool GBIAS = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
                                                                const int num_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
 
         // the K loop ended on a barrier: both stage buffers are free.  Request the NEXT tile's first
         // stage now, so that it lands under this tile's epilogue.
-        const int cm0 = m0 + wr * 128, cn = n0 + wc * 64 + lcol;
+        const int cm0 = m0 + wr * 128, cn = n0 + wc * 64 + lcol, n0c = n0;
         const int stat_row = 2 * cur_tile_m + wr;
         const int next_t = t + (int)gridDim.x;
         if (next_t < num_tiles) {
@@ -250,116 +250,130 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
         }
 
         // ---- epilogue: acc[i][j][r] is Y[row][col], row = (r&3) + 8*(r>>2) + 4*fhalf, col = lane&31 ----
-        const bool n_ok = cn < p.N;
-        f32x4 sc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if (n_ok) {
+        // Two copies (round 5).  INTERIOR (the wave's 128 x 64 block lies inside the matrix) has no branch between its
+        // first residual request and its last store, so hipcc counts its loads and stores; with the per-row `m < M` and
+        // null-pointer tests in the way it emitted `s_waitcnt vmcnt(0)` in front of every load and store of the epilogue.
+        auto epilogue = [&](auto interior_) {
+            constexpr bool INT = decltype(interior_)::value;
+            const bool n_ok = INT || cn < p.N;
+            f32x4 sc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (n_ok) {
+                if (p.scale) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (p.scale) sc[u] = *reinterpret_cast<const f32x4*>(p.scale + cn + 4 * u);
-                if (p.shift) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
+                    for (int u = 0; u < 2; ++u) sc[u] = *reinterpret_cast<const f32x4*>(p.scale + cn + 4 * u);
+                }
+                if (p.shift) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
+                }
             }
-        }
-        f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // the four residual rows of this 32-row block are requested before the slab round trip
-            // (one dependent load per row would serialise the HBM-bound epilogue of a short-K layer)
-            bf16x8 res8[4];
-            if (r16) {
+            const bool relu = p.relu != 0;
+            f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            bf16x8 res8[2][4];
+            auto res_request = [&](int i) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = cm0 + i * 32 + it * 8 + lrow;
-                    if constexpr (SQD) {
-                        const int64_t rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
-                        if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
-                    } else {
-                        if (m < p.M && n_ok) res8[it] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + cn);
+                    int64_t rr = m;
+                    if constexpr (SQD) rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
+                    if (INT || (m < p.M && n_ok)) res8[i & 1][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                }
+            };
+            if constexpr (RES) res_request(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // two 32-row blocks of residual rows in flight (one dependent load per row would serialise the
+                // HBM-bound epilogue of a short-K layer)
+                if constexpr (RES) { if (i + 1 < 4) res_request(i + 1); }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                        Cs[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
                     }
-                }
-            }
+                // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
+                if constexpr (SQD) {
+                    f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 8 + lrow;
+                        if (n_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    Cs[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
-                }
-            // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
-            if constexpr (SQD) {
-                f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                            for (int u = 0; u < 2; ++u) {
+                                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
+                                v = v * sc[u] + sh[u];
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 8 + lrow;
-                    if (n_ok) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
-                            v = v * sc[u] + sh[u];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float f1v = (float)(__bf16)(v[e] > 0.f ? v[e] : 0.f);
-                                const float dd = f1v - (float)res8[it][4 * u + e];
-                                part[u][e] += dd * dd;
+                                for (int e = 0; e < 4; ++e) {
+                                    const float f1v = (float)(__bf16)(v[e] > 0.f ? v[e] : 0.f);
+                                    const float dd = f1v - (float)res8[i & 1][it][4 * u + e];
+                                    part[u][e] += dd * dd;
+                                }
                             }
                         }
                     }
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) part[u][e] += __shfl_xor(part[u][e], o);
+                    if (lrow == 0 && n_ok) {
+                        float* const yq = p.y + (int64_t)((cm0 + i * 32) >> 5) * p.ldy + cn;
+                        *reinterpret_cast<f32x4*>(yq) = part[0];
+                        *reinterpret_cast<f32x4*>(yq + 4) = part[1];
+                    }
+                    continue;
                 }
 #pragma unroll
-                for (int o = 8; o < 64; o <<= 1)
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + lrow;
+                    const int m = cm0 + i * 32 + row;
+                    if (INT || (m < p.M && n_ok)) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
+                            if constexpr (GBIAS)
+                                v += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
+                            if constexpr (STATS) { ssum[u] += v; ssq[u] += v * v; }
+                            v = v * sc[u] + sh[u];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float tt = v[e];
+                                if constexpr (RES) tt = tt + (float)res8[i & 1][it][4 * u + e];
+                                else tt = tt + 0.f;
+                                tt = relu ? (tt > 0.f ? tt : 0.f) : tt;
+                                o[4 * u + e] = (__bf16)tt;
+                            }
+                        }
+                        *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                    }
+                }
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) part[u][e] += __shfl_xor(part[u][e], o);
-                if (lrow == 0 && n_ok) {
-                    float* const yq = p.y + (int64_t)((cm0 + i * 32) >> 5) * p.ldy + cn;
-                    *reinterpret_cast<f32x4*>(yq) = part[0];
-                    *reinterpret_cast<f32x4*>(yq + 4) = part[1];
+                        for (int e = 0; e < 4; ++e) {
+                            ssum[u][e] += __shfl_xor(ssum[u][e], o);
+                            ssq[u][e] += __shfl_xor(ssq[u][e], o);
+                        }
                 }
-                continue;
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + lrow;
-                const int m = cm0 + i * 32 + row;
-                if (m < p.M && n_ok) {
-                    bf16x8 o;
+                if (lrow == 0 && n_ok) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
-                        if (p.gbias)
-                            v += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
-                        if constexpr (STATS) { ssum[u] += v; ssq[u] += v * v; }
-                        v = v * sc[u] + sh[u];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float tt = v[e] + (r16 ? (float)res8[it][4 * u + e] : 0.f);
-                            if (p.relu) tt = tt > 0.f ? tt : 0.f;
-                            o[4 * u + e] = (__bf16)tt;
-                        }
+                        *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 0) * p.N + cn + 4 * u) = ssum[u];
+                        *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 1) * p.N + cn + 4 * u) = ssq[u];
                     }
-                    *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
                 }
             }
-        }
-        if constexpr (STATS) {
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ssum[u][e] += __shfl_xor(ssum[u][e], o);
-                        ssq[u][e] += __shfl_xor(ssq[u][e], o);
-                    }
-            }
-            if (lrow == 0 && n_ok) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 0) * p.N + cn + 4 * u) = ssum[u];
-                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 1) * p.N + cn + 4 * u) = ssq[u];
-                }
-            }
-        }
+        };
+        const bool interior = cm0 + 128 <= p.M && n0c + wc * 64 + 64 <= p.N;       // (wave-uniform)
+        if (interior) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         if (next_t >= num_tiles) break;
         t = next_t;
     }
@@ -411,22 +425,46 @@ bool grl_gemm_bf16_256_takes(const GrlGemm& d) {
 
 int grl_gemm_bf16_256_stat_rows(const GrlGemm& d) { return 2 * ((d.M + TB - 1) / TB); }
 
-int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
-    const int mode = g_mode;
-    if (sqdiff_ok(d)) {
-        static const bool attr_sq = [] {
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-            return true;
-        }();
-        (void)attr_sq;
-        int dev = 0, cus = 256;
+namespace {
+template <bool CONV, bool STATS, bool SQD, bool RES, bool GBIAS>
+void launch_256(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int num_tiles) {
+    auto kern = gemm_bf16_256_kernel<CONV, STATS, SQD, RES, GBIAS>;
+    static const bool attr = [&] {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, num_tiles);
+}
+template <bool CONV, bool STATS>
+void launch_256_epi(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int num_tiles) {
+    if (d.res) {
+        if (d.gbias) launch_256<CONV, STATS, false, true, true>(d, s, grid, tiles_n, num_tiles);
+        else launch_256<CONV, STATS, false, true, false>(d, s, grid, tiles_n, num_tiles);
+    } else {
+        if (d.gbias) launch_256<CONV, STATS, false, false, true>(d, s, grid, tiles_n, num_tiles);
+        else launch_256<CONV, STATS, false, false, false>(d, s, grid, tiles_n, num_tiles);
+    }
+}
+int cus_of_device() {                  // persistent grid: one 8-wave workgroup per CU, a multiple of 8
+    static const int cus = [] {
+        int dev = 0, n = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount / 8 * 8 > 0 ? prop.multiProcessorCount / 8 * 8 : 8;
+            n = prop.multiProcessorCount;
+        return n / 8 * 8 > 0 ? n / 8 * 8 : 8;
+    }();
+    return cus;
+}
+}  // namespace
+
+int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
+    const int mode = g_mode;
+    const int cus = cus_of_device();
+    if (sqdiff_ok(d)) {
         const int tiles_n = d.N / TB;
         const int64_t num_tiles = (int64_t)(d.M / TB) * tiles_n;
-        hipLaunchKernelGGL((gemm_bf16_256_kernel<false, false, true>), dim3((unsigned)(num_tiles < cus ? num_tiles : cus)), dim3(512),
-                           2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        launch_256<false, false, true, true, false>(d, s, (unsigned)(num_tiles < cus ? num_tiles : cus), tiles_n, (int)num_tiles);
         const int e = grl_check_launch("grl_conv_gemm_f32 (bf16 256x256, SQDIFF)");
         return e ? e : 1;
     }
@@ -444,32 +482,15 @@ int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     // one workgroup per CU: fewer than ~3/4 of a wave of tiles leaves the chip idle and the
     // 128 x 128 family (two workgroups per CU, 4x the tiles) does better
     if (mode < 0 && (num_tiles < 192 || d.N < 256)) return 0;      // (K = 64 included: full 512-byte output rows, 319 -> 283 us on 1048576 x 256 x 64)
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        return true;
-    }();
-    (void)attr;
-    static const int cus = [] {                  // persistent grid: one 8-wave workgroup per CU, a multiple of 8
-        int dev = 0, n = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n = prop.multiProcessorCount;
-        return n / 8 * 8 > 0 ? n / 8 * 8 : 8;
-    }();
     const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
     if (d.stats) {
         if (!al16(d.stats)) return 0;
-        if (d.conv)
-            hipLaunchKernelGGL((gemm_bf16_256_kernel<true, true>), dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
-        else
-            hipLaunchKernelGGL((gemm_bf16_256_kernel<false, true>), dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        if (d.conv) launch_256_epi<true, true>(d, s, grid, tiles_n, (int)num_tiles);
+        else launch_256_epi<false, true>(d, s, grid, tiles_n, (int)num_tiles);
     } else if (d.conv)
-        hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        launch_256_epi<true, false>(d, s, grid, tiles_n, (int)num_tiles);
     else
-        hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, (int)num_tiles);
+        launch_256_epi<false, false>(d, s, grid, tiles_n, (int)num_tiles);
     const int e = grl_check_launch("grl_conv_gemm_f32 (bf16 256x256)");
     return e ? e : 1;
 }

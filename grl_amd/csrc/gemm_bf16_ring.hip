@@ -45,6 +45,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef GRL_RING_SCHED
 #define GRL_RING_SCHED 2
 #endif
+#ifndef GRL_RING_M16
+#define GRL_RING_M16 0     // timing-only probe: v_mfma_f32_16x16x32_bf16 on the same fragment traffic (wrong results)
+#endif
 #ifndef GRL_RING_KO
 #define GRL_RING_KO 0      // timing-only knock-outs (wrong results): 1 no DMA in the loop, 2 no epilogue, 4 no MFMA, 8 every half-stage re-reads k block 0, 16 no fragment reads
 #endif
@@ -88,21 +91,24 @@ struct Group {
 // TM x TN tile, 8 waves; wave tile WM x 64.  NS ring slots.  CONV: implicit-GEMM gather of A.  STATS / SQD: see
 // gemm_bf16.hip (same epilogues, same summation orders).  DEEPRES: residual rows of the whole wave tile requested up
 // front (else per 32-row block).
-template <int TM, int TN, int NS, bool CONV, bool STATS, bool SQD, bool GROUPED>
+template <int TM, int TN, int NS, bool CONV, bool STATS, bool SQD, bool GROUPED, bool RES, bool GBIAS>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p, const Group grp, const int tiles_n,
-                                                                const int tiles_per_problem, const int num_tiles) {
+                                                                const int tiles_per_problem, const int num_tiles,
+                                                                const int phase_cycles) {
     constexpr int WGN = TN / 64, WGM = 8 / WGN;           // waves along N / M
     constexpr int WM = TM / WGM, MI = WM / 32;            // wave tile rows, MFMA row blocks
     constexpr int SLOT = (TM + TN) * 64;                  // bytes of one ring slot (A rows then W rows, 64 B each)
     constexpr int PA = TM / 128, PB = TN / 128;           // 1 KiB DMA pieces per wave per half-stage
     constexpr int NP = PA + PB;
-    // DMA issue schedule.  A stage is 2 * NP wave-instructions: the odd half-stage that opens it issues instructions
-    // 0 .. NP-1 (pieces 0 .. NP/2-1, both k-halves), the even one behind it NP .. 2*NP-1.  Issue points of a half-stage:
-    // P0 behind the k-step-1 fragment reads, P1 inside the first eight MFMAs, P2 behind them, P3 inside the last eight
-    // (behind the barrier).  SCHED 1: half at P0, half at P2; SCHED 2: one instruction per point.
-    constexpr int SCHED = GRL_RING_SCHED;
-    auto pos_of = [](int k) constexpr { return SCHED == 2 ? (k & 3) : (k < (NP + 1) / 2 ? 0 : 2); };
-    constexpr int QPRE = [&]() constexpr { int n = 0; for (int k = 0; k < NP; ++k) n += pos_of(k) < 3; return n; }();
+    // DMA issue schedule.  A vector-memory instruction blocks its wave until the texture-address unit takes it (about
+    // 18 cycles per 1 KiB instruction at the 110 GB/s a CU gets out of L2): eight waves that reach their DMA
+    // instructions together (they leave every barrier together) all sit in that queue, the two waves of a SIMD
+    // included, and nobody issues MFMAs -- the DMA's transfer time ADDS to the matrix time (knock-outs: MFMA only
+    // 0.53 us per half-stage, MFMA + DMA 0.80, everything 1.08).  So every wave gets its own window: wave w issues its
+    // NP instructions of the half-stage in one burst in front of MFMA pair w of the half-stage's eight (waves 0-3 in
+    // front of the barrier, their SIMD partners 4-7 behind it).  A stage is 2 * NP instructions per wave: chunk A
+    // (pieces 0 .. NP/2-1, both k-halves) in the half-stage that opens it, chunk B one half-stage later.  Waves 0-3 open
+    // stage (2s, 2s+1) in half-stage 2s-3, waves 4-7 behind the barrier of half-stage 2s-4 (both slots are free there).
     constexpr bool SLAB_ALIAS = (NS * SLOT + 8 * 4096) > 160 * 1024;
     static_assert(!SLAB_ALIAS || (PA == 2 && PB == 2), "slab aliasing: the wave's DMA footprint must be 2 + 2 KiB");
     static_assert(MI == 2 || MI == 4, "wave tile");
@@ -110,6 +116,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WGN, wc = wave % WGN;
+    const bool late = wave >= 4;                             // DMA schedule: waves 4-7 issue behind the barrier
+    const int win = MI == 4 ? wave : wave >> 1;              // ... in window `win` of the half-stage's 2 * MI
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
 
     // ------------------------------------------------------------------ loader (runs D half-stages ahead)
@@ -242,7 +250,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
     if (issued > 2) wait_vm<2 * NP>(); else wait_vm<0>();    // stage 0 has landed (stage 1 may be in flight)
     __builtin_amdgcn_s_barrier();
 
-    bool l_open = false;                                     // a stage is open (its second half is issued by the next even half-stage)
+    // Phase offset between workgroups.  Every workgroup starts at the same time with the same amount of work per tile, so
+    // all 256 CUs run their main loops together (HBM idle) and their epilogues together (HBM saturated: 256 KiB of residual
+    // reads and output stores per tile and CU).  Workgroups sleep p/8 of `phase_cycles` (the host's estimate of one
+    // tile's main loop) before their first tile, p = their index within the XCD mod 8: afterwards some CUs are always in
+    // their epilogue while the others compute.
+    if (phase_cycles > 0) {
+        const int ph = ((int)blockIdx.x >> 3) & 7;
+        for (int c = ph * (phase_cycles >> 3); c > 0; c -= 64 * 100) __builtin_amdgcn_s_sleep(100);
+    }
+    bool l_open = false;                                     // the stage opened last exists (its chunk B follows one half-stage later)
     int c_slot = 0;
     for (int t = blockIdx.x; t < num_tiles; t += (int)gridDim.x) {
         f32x16 acc[MI][2];
@@ -275,12 +292,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
             asm volatile("ds_read_b128 %0, %1" : "=v"(bf[set][0]) : "v"(bb_));                          \
             asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(bf[set][1]) : "v"(bb_));              \
         } while (0)
+#if GRL_RING_M16
+#define RING_MFMA(set, i_, j_)                                                                              \
+        do {                                                                                            \
+            f32x4 q0_ = __builtin_shufflevector(acc[i_][j_], acc[i_][j_], 8 * (set) + 0, 8 * (set) + 1, 8 * (set) + 2, 8 * (set) + 3); \
+            f32x4 q1_ = __builtin_shufflevector(acc[i_][j_], acc[i_][j_], 8 * (set) + 4, 8 * (set) + 5, 8 * (set) + 6, 8 * (set) + 7); \
+            q0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][i_], bf[set][j_], q0_, 0, 0, 0);     \
+            q1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][i_], bf[set][j_], q1_, 0, 0, 0);     \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { acc[i_][j_][8 * (set) + e_] = q0_[e_]; acc[i_][j_][8 * (set) + 4 + e_] = q1_[e_]; } \
+        } while (0)
+#else
+#define RING_MFMA(set, i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i_], bf[set][j_], acc[i_][j_], 0, 0, 0)
+#endif
 #define RING_MM(set, i0, i1)                                                                                \
         do {                                                                                            \
             if (!(GRL_RING_KO & 4)) {                                                                   \
-                _Pragma("unroll") for (int i = i0; i < i1; ++i)                                         \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bf[set][j], acc[i][j], 0, 0, 0); \
+                _Pragma("unroll") for (int i_ = (i0); i_ < (i1); ++i_)                                  \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                    \
+                        RING_MFMA(set, i_, j_);                                                     \
             }                                                                                           \
         } while (0)
 #define RING_LGKM(n)                                                                                        \
@@ -296,29 +325,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
         // One half-stage.  PAR: parity of g (odd half-stages open a stage); OPEN: a stage is being issued during this
         // pair of half-stages.  What may stay in flight at the barrier (the NEXT half-stage's stage must have landed) is a
         // compile-time count: this half-stage's instructions so far, plus the odd half-stage's NP when this one is even.
-        auto half_stage = [&](auto par_, const bool open, const bool last_of_tile) {
+        auto half_stage = [&](auto par_, const bool last_of_tile) {
             constexpr bool PAR = decltype(par_)::value;
             const unsigned sb = lds0 + (unsigned)c_slot * SLOT;
             const unsigned aa1 = (sb + a_lane) ^ 32u, bb1 = (sb + b_lane) ^ 32u;
-            auto issue_at = [&](int P) {                     // (one wave-uniform branch around the point's instructions)
-                if (open) {
+            // This wave's DMA window of the half-stage (see SCHED): chunk A = the stage's first NP instructions (and the
+            // decision whether there is a stage to open), chunk B = the rest, one half-stage later.
+            const bool phase_a = (PAR != late);
+            auto window = [&](int idx) {
+                if (idx == win) {
+                    if (phase_a) {
+                        l_open = !(GRL_RING_KO & 1) && issued < total;
+                        if (l_open) {
+                            issued += 2;
 #pragma unroll
-                    for (int k = 0; k < NP; ++k)
-                        if (pos_of(k) == P) loader_instr(PAR ? k : NP + k);
+                            for (int n = 0; n < NP; ++n) loader_instr(n);
+                        }
+                    } else if (l_open) {
+#pragma unroll
+                        for (int n = NP; n < 2 * NP; ++n) loader_instr(n);
+                        loader_advance();
+                    }
                 }
             };
             RING_RD(1, aa1, bb1);
-            issue_at(0);
+            window(0);
             if constexpr (NRD == 6) { RING_LGKM(6); } else { RING_LGKM(4); }
-            RING_MM(0, 0, MI / 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (SCHED == 2) issue_at(1);
-            RING_MM(0, MI / 2, MI);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_at(2);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (i) window(i);
+                RING_MM(0, i, i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             RING_LGKM(0);                                    // every read of this slot has returned
             c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
-            if (open) wait_vm<(PAR ? QPRE : NP + QPRE)>(); else wait_vm<0>();
+            if (l_open) wait_vm<(PAR ? NP : 2 * NP)>(); else wait_vm<0>();
             __builtin_amdgcn_s_barrier();                    // slot g+1 landed for everyone; slot g is free
             __builtin_amdgcn_sched_barrier(0);
             if (!last_of_tile) {
@@ -327,24 +368,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                 RING_RD(0, aa, bb);
             }
             __builtin_amdgcn_sched_barrier(0);
-            RING_MM(1, 0, MI / 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (SCHED == 2) issue_at(3);
-            RING_MM(1, MI / 2, MI);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!PAR) { if (open) loader_advance(); }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                window(MI + i);
+                RING_MM(1, i, i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
 #pragma unroll 1
         for (int hk = 0; hk < nkh; hk += 2) {
-            // even half-stage: finishes the stage the previous odd one opened (possibly in the previous tile)
-            half_stage(std::false_type{}, l_open, false);
-            // odd half-stage: opens the stage 3-4 half-stages ahead (both of its slots are free since the last barrier)
-            l_open = !(GRL_RING_KO & 1) && issued < total;
-            if (l_open) issued += 2;
-            half_stage(std::true_type{}, l_open, hk + 2 >= nkh);
+            half_stage(std::false_type{}, false);
+            half_stage(std::true_type{}, hk + 2 >= nkh);
         }
 #undef RING_RD
 #undef RING_MM
+#undef RING_MFMA
 #undef RING_LGKM
         if (GRL_RING_KO & 2) {
             float z = 0.f;                                   // (every accumulator stays live: no MFMA may be dropped)
@@ -389,135 +427,149 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
             shift = pick4(grp.shift, gi);
         }
         float* const y32 = reinterpret_cast<float*>(y16);
-        const bool n_ok = cn < p.N;
-        f32x4 sc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if (n_ok) {
+        // Two copies of the epilogue.  INTERIOR (the wave's 128 x 64 block lies inside the matrix: every tile but the
+        // edge ones) has no branch at all between the first residual request and the last store: hipcc can then count
+        // its loads and stores.  With the per-row `m < M` / null-pointer tests in the way it emitted `s_waitcnt vmcnt(0)`
+        // in front of EVERY load and store (each store waited for the previous one's acknowledge: ~15 us per tile, 40 %
+        // of the short-K layers' time, in this kernel and in gemm_bf16_256_kernel alike).
+        auto epilogue = [&](auto interior_) {
+            constexpr bool INT = decltype(interior_)::value;
+            const bool n_ok = INT || cn < p.N;
+            f32x4 sc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (n_ok) {
+                if (scale) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (scale) sc[u] = *reinterpret_cast<const f32x4*>(scale + cn + 4 * u);
-                if (shift) sh[u] = *reinterpret_cast<const f32x4*>(shift + cn + 4 * u);
+                    for (int u = 0; u < 2; ++u) sc[u] = *reinterpret_cast<const f32x4*>(scale + cn + 4 * u);
+                }
+                if (shift) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(shift + cn + 4 * u);
+                }
             }
-        }
-        // residual rows: two 32-row blocks (8 x 1 KiB per wave) in flight -- block i+1 is requested before block i goes
-        // through the slab
-        bf16x8 res8[2][4];
-        auto res_request = [&](int i) {
+            const bool relu = p.relu != 0;
+            // residual rows: two 32-row blocks (8 x 1 KiB per wave) in flight -- block i+1 is requested before block i
+            // goes through the slab
+            bf16x8 res8[2][4];
+            auto res_request = [&](int i) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int m = cm0 + i * 32 + it * 8 + lrow;
+                for (int it = 0; it < 4; ++it) {
+                    const int m = cm0 + i * 32 + it * 8 + lrow;
+                    int64_t rr = m;
+                    if constexpr (SQD) rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
+                    if (INT || (m < p.M && n_ok)) res8[i & 1][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                }
+            };
+            if constexpr (RES) res_request(0);
+            f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (RES) { if (i + 1 < MI) res_request(i + 1); }
+                f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};        // SQD: per 32-row block
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                        // 16-row half of the 32-row block
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = q * 8 + r8;
+                            const int row = (r & 3) + 4 * fhalf;              // row inside the 8-row half-slab
+                            float* const half = ((r >> 2) & 1) ? slab_hi : slab_lo;
+                            half[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
+                        }
+                    // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int it = q * 2 + ps;
+                        const float* const half = ps ? slab_hi : slab_lo;
+                        const int m = cm0 + i * 32 + it * 8 + lrow;
+                        f32x4 v[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            v[u] = *reinterpret_cast<const f32x4*>(half + lrow * 64 + ((lcol + 4 * u) ^ (((lrow >> 1) & 1) << 2)));
+                        if constexpr (SQD) {
+                            if (n_ok) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    f32x4 w_ = v[u] * sc[u] + sh[u];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float f1v = (float)(__bf16)(w_[e] > 0.f ? w_[e] : 0.f);
+                                        const float dd = f1v - (float)res8[i & 1][it][4 * u + e];
+                                        part[u][e] += dd * dd;
+                                    }
+                                }
+                            }
+                        } else {
+                            if (INT || (m < p.M && n_ok)) {
+                                bf16x8 o;
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    f32x4 w_ = v[u];
+                                    if constexpr (GBIAS)
+                                        w_ += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
+                                    if constexpr (STATS) { ssum[u] += w_; ssq[u] += w_ * w_; }
+                                    w_ = w_ * sc[u] + sh[u];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float tt = w_[e];
+                                        if constexpr (RES) tt = tt + (float)res8[i & 1][it][4 * u + e];
+                                        else tt = tt + 0.f;
+                                        tt = relu ? (tt > 0.f ? tt : 0.f) : tt;
+                                        o[4 * u + e] = (__bf16)tt;
+                                    }
+                                }
+                                *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                            }
+                        }
+                    }
+                }
                 if constexpr (SQD) {
-                    const int64_t rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
-                    if (m < p.M && n_ok) res8[i & 1][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
-                } else {
-                    if (m < p.M && n_ok) res8[i & 1][it] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + cn);
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) part[u][e] += __shfl_xor(part[u][e], o);
+                    if (lrow == 0 && n_ok) {
+                        float* const yq = y32 + (int64_t)((cm0 + i * 32) >> 5) * p.ldy + cn;
+                        *reinterpret_cast<f32x4*>(yq) = part[0];
+                        *reinterpret_cast<f32x4*>(yq + 4) = part[1];
+                    }
+                }
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ssum[u][e] += __shfl_xor(ssum[u][e], o);
+                            ssq[u][e] += __shfl_xor(ssq[u][e], o);
+                        }
+                }
+                if (lrow == 0 && n_ok) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 0) * p.N + cn + 4 * u) = ssum[u];
+                        *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 1) * p.N + cn + 4 * u) = ssq[u];
+                    }
                 }
             }
         };
-        if (r16) res_request(0);
-        f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if (r16 && i + 1 < MI) res_request(i + 1);
-            f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};        // SQD: per 32-row block
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {                        // 16-row half of the 32-row block
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = q * 8 + r8;
-                        const int row = (r & 3) + 4 * fhalf;              // row inside the 8-row half-slab
-                        float* const half = ((r >> 2) & 1) ? slab_hi : slab_lo;
-                        half[row * 64 + ((j * 32 + frow) ^ (((row >> 1) & 1) << 2))] = acc[i][j][r];
-                    }
-                // (the same wave wrote and reads the slab: a wave's LDS operations complete in order)
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int it = q * 2 + ps;
-                    const float* const half = ps ? slab_hi : slab_lo;
-                    const int m = cm0 + i * 32 + it * 8 + lrow;
-                    f32x4 v[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        v[u] = *reinterpret_cast<const f32x4*>(half + lrow * 64 + ((lcol + 4 * u) ^ (((lrow >> 1) & 1) << 2)));
-                    if constexpr (SQD) {
-                        if (n_ok) {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                f32x4 w_ = v[u] * sc[u] + sh[u];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float f1v = (float)(__bf16)(w_[e] > 0.f ? w_[e] : 0.f);
-                                    const float dd = f1v - (float)res8[i & 1][it][4 * u + e];
-                                    part[u][e] += dd * dd;
-                                }
-                            }
-                        }
-                    } else {
-                        if (m < p.M && n_ok) {
-                            bf16x8 o;
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                f32x4 w_ = v[u];
-                                if (p.gbias)
-                                    w_ += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
-                                if constexpr (STATS) { ssum[u] += w_; ssq[u] += w_ * w_; }
-                                w_ = w_ * sc[u] + sh[u];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float tt = w_[e] + (r16 ? (float)res8[i & 1][it][4 * u + e] : 0.f);
-                                    if (p.relu) tt = tt > 0.f ? tt : 0.f;
-                                    o[4 * u + e] = (__bf16)tt;
-                                }
-                            }
-                            *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
-                        }
-                    }
-                }
-            }
-            if constexpr (SQD) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) part[u][e] += __shfl_xor(part[u][e], o);
-                if (lrow == 0 && n_ok) {
-                    float* const yq = y32 + (int64_t)((cm0 + i * 32) >> 5) * p.ldy + cn;
-                    *reinterpret_cast<f32x4*>(yq) = part[0];
-                    *reinterpret_cast<f32x4*>(yq + 4) = part[1];
-                }
-            }
-        }
-        if constexpr (STATS) {
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ssum[u][e] += __shfl_xor(ssum[u][e], o);
-                        ssq[u][e] += __shfl_xor(ssq[u][e], o);
-                    }
-            }
-            if (lrow == 0 && n_ok) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 0) * p.N + cn + 4 * u) = ssum[u];
-                    *reinterpret_cast<f32x4*>(p.stats + ((int64_t)stat_row * 2 + 1) * p.N + cn + 4 * u) = ssq[u];
-                }
-            }
-        }
+        const bool interior = cm0 + WM <= p.M && n0 + wc * 64 + 64 <= p.N;       // (wave-uniform)
+        if (interior) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     wait_vm<0>();                                            // nothing of the ring may land in LDS after the wave has left
 }
 
-template <int TM, int TN, int NS, bool CONV, bool STATS, bool SQD, bool GROUPED>
+template <int TM, int TN, int NS, bool CONV, bool STATS, bool SQD, bool GROUPED, bool RES = false, bool GBIAS = false>
 int launch_one(const GrlGemm& d, const Group& grp, hipStream_t s) {
     constexpr int SLOT = (TM + TN) * 64;
     constexpr bool alias = (NS * SLOT + 8 * 4096) > 160 * 1024;
     constexpr int lds = NS * SLOT + (alias ? 0 : 8 * 4096);
-    auto kern = gemm_bf16_ring_kernel<TM, TN, NS, CONV, STATS, SQD, GROUPED>;
+    auto kern = gemm_bf16_ring_kernel<TM, TN, NS, CONV, STATS, SQD, GROUPED, RES, GBIAS>;
     static const bool attr = [&] {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         return true;
@@ -534,7 +586,11 @@ int launch_one(const GrlGemm& d, const Group& grp, hipStream_t s) {
     const int per = tiles_m * tiles_n;
     const int num_tiles = per * (GROUPED ? grp.n : 1);
     const unsigned grid = (unsigned)(num_tiles < cus ? num_tiles : cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, d, grp, tiles_n, per, num_tiles);
+    // phase offset (see the kernel): only when a workgroup walks several tiles whose epilogue moves a tile of HBM traffic
+    static const int phase_env = [] { const char* e = getenv("GRL_RING_PHASE"); return e ? atoi(e) : -1; }();
+    int phase = 0;
+    if (num_tiles >= 2 * cus) phase = phase_env >= 0 ? phase_env * (d.K / 32) : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, d, grp, tiles_n, per, num_tiles, phase);
     return grl_check_launch("grl_conv_gemm_f32 (bf16 ring)");
 }
 
@@ -556,22 +612,33 @@ inline bool shape_ok(const GrlGemm& d) {
 template <int TM, int TN, int NS>
 int launch_tile(const GrlGemm& d, const Group& grp, hipStream_t s) {
     const bool grouped = grp.n > 1;
+    const bool res = grouped ? grp.res[0] != nullptr : d.res != nullptr;
     if (d.epilogue == GRL_EPI_SQDIFF) {
         if (d.M % TM || d.N % TN) return 1;
-        return grouped ? launch_one<TM, TN, NS, false, false, true, true>(d, grp, s) : launch_one<TM, TN, NS, false, false, true, false>(d, grp, s);
+        return grouped ? launch_one<TM, TN, NS, false, false, true, true, true>(d, grp, s) : launch_one<TM, TN, NS, false, false, true, false, true>(d, grp, s);
     }
-    if (d.stats) {
+    if (d.stats) {                                           // train forward: BatchNorm statistics (no residual there)
         if constexpr (TM == 256 && TN == 256) {
-            if (grouped) return 1;
-            return d.conv ? launch_one<TM, TN, NS, true, true, false, false>(d, grp, s) : launch_one<TM, TN, NS, false, true, false, false>(d, grp, s);
+            if (grouped || res) return 1;
+            if (d.conv) return d.gbias ? 1 : launch_one<TM, TN, NS, true, true, false, false>(d, grp, s);
+            return d.gbias ? launch_one<TM, TN, NS, false, true, false, false, false, true>(d, grp, s)
+                           : launch_one<TM, TN, NS, false, true, false, false>(d, grp, s);
         }
         return 1;
     }
-    if (d.conv) return grouped ? 1 : launch_one<TM, TN, NS, true, false, false, false>(d, grp, s);
-    return grouped ? launch_one<TM, TN, NS, false, false, false, true>(d, grp, s) : launch_one<TM, TN, NS, false, false, false, false>(d, grp, s);
+    if (d.conv) {
+        if (grouped || d.gbias) return 1;
+        return res ? launch_one<TM, TN, NS, true, false, false, false, true>(d, grp, s) : launch_one<TM, TN, NS, true, false, false, false>(d, grp, s);
+    }
+    if (grouped) {
+        if (d.gbias) return 1;
+        return res ? launch_one<TM, TN, NS, false, false, false, true, true>(d, grp, s) : launch_one<TM, TN, NS, false, false, false, true>(d, grp, s);
+    }
+    if (d.gbias) return res ? 1 : launch_one<TM, TN, NS, false, false, false, false, false, true>(d, grp, s);
+    return res ? launch_one<TM, TN, NS, false, false, false, false, true>(d, grp, s) : launch_one<TM, TN, NS, false, false, false, false>(d, grp, s);
 }
 
-// variant: 0 = 256 x 256 / 4 slots, 1 = 256 x 256 / 5 slots, 2 = 256 x 128 / 5 slots, 3 = 128 x 256 / 5 slots.
+// variant: 1 = 256 x 256, 2 = 256 x 128 (five ring slots each).
 // 0 = launched, 1 = not covered, < 0 = error
 int launch_variant(const GrlGemm& d, const Group& grp, hipStream_t s, int variant) {
     if (!shape_ok(d)) return 1;
@@ -579,7 +646,6 @@ int launch_variant(const GrlGemm& d, const Group& grp, hipStream_t s, int varian
         case 0: return 1;
         case 1: return launch_tile<256, 256, 5>(d, grp, s);
         case 2: return launch_tile<256, 128, 5>(d, grp, s);
-        case 3: return launch_tile<128, 256, 5>(d, grp, s);
     }
     return 1;
 }

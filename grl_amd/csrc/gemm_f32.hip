@@ -718,6 +718,114 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         // row: float4 scale/shift/residual loads and 256-B contiguous row segments per
         // 16 lanes on the store, instead of 64 dword-wide store instructions.
         float* Cs = smem;                                   // [BM][BN]
+        // ---- fast path (round 5): interior tile, plain affine epilogue (+ residual, ReLU) ----------------------------
+        // The general code below tests `m < M`, p.rowscale, p.gbias, p.res, p.stats, p.bn_z ... inside its row loop:
+        // dozens of basic blocks, and hipcc -- which tracks vmcnt per block -- put `s_waitcnt vmcnt(0)` in front of nearly
+        // every residual load and output store (458 of the 463 vmcnt waits of the 128 x 128 kernel were (0)): a store
+        // waited for the previous store's acknowledge.  Here the tile lies inside the matrix and nothing optional is set,
+        // so the row loop is ONE basic block: residual rows are requested a chunk ahead, stores never wait for stores.
+        // Same operations in the same order as below: bit-identical.  (Not in the K-blocked SEG instantiations: the
+        // train-mode forward they serve always carries statistics, and their second accumulator set leaves no registers.)
+        if constexpr (!SEG) {
+            const bool fast = p.epilogue == GRL_EPI_AFFINE && !p.rowscale && !p.gbias && !p.stats && !p.bn_z &&
+                              m0 + BM <= p.M && n0 + BN <= p.N && (MATH != 2 || (!p.out_f32 && p.N % 8 == 0));
+            if (fast) {
+                auto park = [&]() {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + wn * WTN + j * 32 + col_l] = acc[i][j][r];
+                };
+                const bool relu = p.relu != 0;
+                auto run = [&](auto has_res_) {
+                    constexpr bool HAS_RES = decltype(has_res_)::value;
+                    if constexpr (MATH == 2) {
+                        constexpr int LPR8 = WTN / 8, RPI8 = 64 / LPR8, NIT = WTM / RPI8, CH = (BM == 128 && BN == 128) ? 2 : (NIT < 4 ? NIT : 4);
+                        const int lrow = lane / LPR8, lcol = (lane % LPR8) * 8;
+                        const int n = n0 + wn * WTN + lcol;
+                        f32x4 sc[2], sh[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            sc[u] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + 4 * u) : f32x4{1.f, 1.f, 1.f, 1.f};
+                            sh[u] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        const __bf16* const r16 = reinterpret_cast<const __bf16*>(p.res);
+                        __bf16* const y16 = reinterpret_cast<__bf16*>(p.y);
+                        bf16x8 r8[2][CH];
+                        auto request = [&](int c) {
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) {
+                                const int m = m0 + wm * WTM + (c * CH + k) * RPI8 + lrow;
+                                r8[c & 1][k] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + n);
+                            }
+                        };
+                        if constexpr (HAS_RES) request(0);
+                        park();
+#pragma unroll
+                        for (int c = 0; c < NIT / CH; ++c) {
+                            if constexpr (HAS_RES) { if (c + 1 < NIT / CH) request(c + 1); }
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) {
+                                const int row = wm * WTM + (c * CH + k) * RPI8 + lrow;
+                                const int m = m0 + row;
+                                bf16x8 o;
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol + 4 * u);
+                                    v = v * sc[u] + sh[u];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = v[e];
+                                        if constexpr (HAS_RES) t = t + (float)r8[c & 1][k][4 * u + e];
+                                        else t = t + 0.f;
+                                        t = relu ? (t > 0.f ? t : 0.f) : t;
+                                        o[4 * u + e] = (__bf16)t;
+                                    }
+                                }
+                                *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + n) = o;
+                            }
+                        }
+                    } else {
+                        constexpr int LPR = WTN / 4, RPI = 64 / LPR, NIT = WTM / RPI, CH = (BM == 128 && BN == 128) ? 2 : (NIT < 4 ? NIT : 4);
+                        const int lrow = lane / LPR, lcol = (lane % LPR) * 4;
+                        const int n = n0 + wn * WTN + lcol;
+                        const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 rr[2][CH];
+                        auto request = [&](int c) {
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) {
+                                const int m = m0 + wm * WTM + (c * CH + k) * RPI + lrow;
+                                rr[c & 1][k] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                            }
+                        };
+                        if constexpr (HAS_RES) request(0);
+                        park();
+#pragma unroll
+                        for (int c = 0; c < NIT / CH; ++c) {
+                            if constexpr (HAS_RES) { if (c + 1 < NIT / CH) request(c + 1); }
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) {
+                                const int row = wm * WTM + (c * CH + k) * RPI + lrow;
+                                const int m = m0 + row;
+                                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol);
+                                v = v * sc + sh;
+                                if constexpr (HAS_RES) v += rr[c & 1][k];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = relu ? (v[e] > 0.f ? v[e] : 0.f) : v[e];
+                                *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                            }
+                        }
+                    }
+                };
+                if (p.res) run(std::true_type{});
+                else run(std::false_type{});
+                return;
+            }
+        }
         // fp32 residual rows of this lane, requested BEFORE the accumulators take their round trip through LDS:
         // the epilogue of a short-K layer is a read-modify-write of the output at HBM speed, and a residual load
         // issued per row inside the store loop serialises its latency with the stores

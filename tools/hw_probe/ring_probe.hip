@@ -1,5 +1,8 @@
 // Standalone A/B of the bf16-storage GEMM kernels (no torch): gemm_bf16_256_kernel (rounds 2-4) against the round-5
 // ring kernel on the shapes of BASELINE configs[2], bit-for-bit comparison of the outputs + timing with HIP events.
+// Operand data matters: the chip lowers its clock under the bf16 MFMA + DMA load, by an amount that depends on the data
+// (f2: 593 us on dense random operands, 453 us on zeros) -- the default A operand is post-ReLU (half zeros) like the real
+// activations; DENSE=1: dense random, ZERO=1: zeros.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off tools/hw_probe/ring_probe.hip -o tools/hw_probe/ring_probe
 //   ./tools/hw_probe/ring_probe [reps]
 #include <hip/hip_runtime.h>
@@ -32,6 +35,13 @@ __global__ void fill_bf16(__bf16* p, size_t n, unsigned seed, float scale, float
         unsigned h = (unsigned)i * 2654435761u ^ seed;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
         p[i] = (__bf16)(((h & 0xffff) / 32768.f - 1.f) * scale + offset);
+    }
+}
+// post-ReLU activations: max(0, x) of a centred value -- half of the elements are exact zeros, as on the real path
+__global__ void relu_bf16(__bf16* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = (float)p[i];
+        p[i] = (__bf16)(v > 0.f ? v : 0.f);
     }
 }
 __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale, float offset) {
@@ -70,6 +80,7 @@ float time_ms(F&& f, int reps) {
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
+    const float dscale = getenv("ZERO") ? 0.f : 1.f;      // ZERO=1: all-zero operands (what the clock does without the data-dependent power)
     const char* only = argc > 2 ? argv[2] : nullptr;
     std::vector<Shape> shapes = {
         {"f2 65536x2048x2048", 65536, 2048, 2048, false, false, false, 0, 1},
@@ -107,8 +118,9 @@ int main(int argc, char** argv) {
             CK(hipMalloc(&res[g], M * N * 2));
             CK(hipMalloc(&y_old[g], y_elems * 2));
             CK(hipMalloc(&y_new[g], y_elems * 2));
-            fill_bf16<<<1024, 256>>>(a[g], a_elems, 11u + g, 1.f, 0.3f);
-            fill_bf16<<<1024, 256>>>(w[g], N * K, 23u + g, 1.5f / sqrtf((float)K), 0.f);
+            fill_bf16<<<1024, 256>>>(a[g], a_elems, 11u + g, dscale, getenv("DENSE") ? 0.3f * dscale : 0.f);
+            if (!getenv("DENSE")) relu_bf16<<<1024, 256>>>(a[g], a_elems);
+            fill_bf16<<<1024, 256>>>(w[g], N * K, 23u + g, dscale * 1.5f / sqrtf((float)K), 0.f);
             fill_bf16<<<1024, 256>>>(res[g], M * N, 37u + g, 1.f, 0.f);
         }
         CK(hipMalloc(&scale, N * 4));

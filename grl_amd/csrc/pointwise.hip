@@ -4,6 +4,7 @@
 // 16 bytes per lane per access (float4) with consecutive lanes on consecutive
 // addresses.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/grl_hip.h"
@@ -135,18 +136,26 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     constexpr int P_N = 3 * SM_PH * SM_PW, P_IT = (P_N + 255) / 256, W_N = 64 * SM_WLD / 4, W_IT = (W_N + 255) / 256;
     float pv[P_IT];
     f32x4 wv[W_IT];
+    // (round 5: the u8 / fp32 choice is made OUTSIDE the loop -- with `norm ? xu[o] : xi[o]` inside it every iteration
+    //  was a branch again and hipcc, which counts vmcnt per basic block, waited vmcnt(0) after each load)
+    auto load_patch = [&](auto u8_) {
+        constexpr bool U8 = decltype(u8_)::value;
 #pragma unroll
-    for (int it = 0; it < P_IT; ++it) {
-        const int i = tid + it * 256;
-        const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
-        const int iy = iy0 + r, ix = ix0 + q;
-        const bool ok = i < P_N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const int cc = c < 3 ? c : 0;
-        const int64_t o = ok ? ((int64_t)cc * H + iy) * W + ix : 0;
-        pv[it] = norm ? (float)xu[o] : xi[o];
-        if (norm) pv[it] = (pv[it] / 255.f - norm[cc]) / norm[3 + cc];
-        if (!ok) pv[it] = 0.f;
-    }
+        for (int it = 0; it < P_IT; ++it) {
+            const int i = tid + it * 256;
+            const int c = i / (SM_PH * SM_PW), r = (i / SM_PW) % SM_PH, q = i % SM_PW;
+            const int iy = iy0 + r, ix = ix0 + q;
+            const bool ok = i < P_N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int cc = c < 3 ? c : 0;
+            const int64_t o = ok ? ((int64_t)cc * H + iy) * W + ix : 0;
+            float v;
+            if constexpr (U8) v = ((float)xu[o] / 255.f - norm[cc]) / norm[3 + cc];
+            else v = xi[o];
+            pv[it] = ok ? v : 0.f;
+        }
+    };
+    if (norm) load_patch(std::true_type{});
+    else load_patch(std::false_type{});
     if (wp) {                                          // LDS image made once by grl_stem_pack_weight
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {

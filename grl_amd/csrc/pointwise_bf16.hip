@@ -3,6 +3,7 @@
 // (8 channels), arithmetic and all reductions are fp32, per-channel / per-clip vectors
 // stay fp32.  Same semantics and reference call sites as their fp32 twins in pointwise.hip.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "../../include/grl_hip.h"
 #include "common.h"
@@ -213,19 +214,28 @@ __global__ __launch_bounds__(256) void stem_b16_kernel(
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
     constexpr int P_IT = (SB_PATCH + 255) / 256, W_IT = (64 * SB_ROWB / 16 + 255) / 256;
     float pv[P_IT];
+    // (the u8 / fp32 choice is made OUTSIDE the loop: with `norm ? xu[o] : xi[o]` inside it every iteration was a
+    //  branch, and hipcc -- which counts vmcnt per basic block -- waited vmcnt(0) after each load: P_IT exposed
+    //  latencies per tile instead of one.  Round 5.)
     auto load_patch = [&](const int oy0) {
         const int iy0 = oy0 * 2 - 3;
+        auto body = [&](auto u8_) {
+            constexpr bool U8 = decltype(u8_)::value;
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it) {
-            const int i = tid + it * 256;
-            const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
-            const int iy = iy0 + r, ix = ix0 + q;
-            const bool ok = i < SB_PATCH && q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
-            pv[it] = norm ? (float)xu[o] : xi[o];
-            if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
-            if (!ok) pv[it] = 0.f;
-        }
+            for (int it = 0; it < P_IT; ++it) {
+                const int i = tid + it * 256;
+                const int cr = i / SB_PWP, q = i - cr * SB_PWP, c = cr / SB_PH, r = cr - c * SB_PH;
+                const int iy = iy0 + r, ix = ix0 + q;
+                const bool ok = i < SB_PATCH && q < SB_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
+                float v;
+                if constexpr (U8) v = ((float)xu[o] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
+                else v = xi[o];
+                pv[it] = ok ? v : 0.f;
+            }
+        };
+        if (norm) body(std::true_type{});
+        else body(std::false_type{});
     };
     int oy0 = blockIdx.y * (SB_TPW * SB_TH);
     load_patch(oy0);
@@ -408,19 +418,28 @@ __global__ __launch_bounds__(256) void stem_pool_b16_kernel(
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
     constexpr int P_IT = (SP_PATCH + 255) / 256, W_IT = (64 * SB_ROWB / 16 + 255) / 256;
     float pv[P_IT];
+    // (the u8 / fp32 choice is made OUTSIDE the loop: with `norm ? xu[o] : xi[o]` inside it every iteration was a
+    //  branch, and hipcc -- which counts vmcnt per basic block -- waited vmcnt(0) after each load: P_IT exposed
+    //  latencies per tile instead of one.  Round 5.)
     auto load_patch = [&](const int oy0) {
         const int iy0 = oy0 * 2 - 3;
+        auto body = [&](auto u8_) {
+            constexpr bool U8 = decltype(u8_)::value;
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it) {
-            const int i = tid + it * 256;
-            const int cr = i / SP_PWP, q = i - cr * SP_PWP, c = cr / SP_PH, r = cr - c * SP_PH;
-            const int iy = iy0 + r, ix = q - 3;
-            const bool ok = i < SP_PATCH && q < SP_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
-            pv[it] = norm ? (float)xu[o] : xi[o];
-            if (norm) pv[it] = (pv[it] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
-            if (!ok) pv[it] = 0.f;
-        }
+            for (int it = 0; it < P_IT; ++it) {
+                const int i = tid + it * 256;
+                const int cr = i / SP_PWP, q = i - cr * SP_PWP, c = cr / SP_PH, r = cr - c * SP_PH;
+                const int iy = iy0 + r, ix = q - 3;
+                const bool ok = i < SP_PATCH && q < SP_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int64_t o = ok ? ((int64_t)c * H + iy) * W + ix : 0;
+                float v;
+                if constexpr (U8) v = ((float)xu[o] / 255.f - norm[c < 3 ? c : 0]) / norm[3 + (c < 3 ? c : 0)];
+                else v = xi[o];
+                pv[it] = ok ? v : 0.f;
+            }
+        };
+        if (norm) body(std::true_type{});
+        else body(std::false_type{});
     };
     const int strip0 = blockIdx.x * (SP_TPW * SP_TH);           // first stem row whose pooled row this workgroup emits
     int oy0 = strip0 > 0 ? strip0 - SP_TH : 0;                  // (warm-up tile above the strip)

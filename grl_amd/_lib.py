@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GRL_HIP_LIB') or os.path.join(_HERE, 'libgrl_hip.so')     # (override: A/B builds, tools/gemm_ko.sh)
 
-ABI_VERSION = 7       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+ABI_VERSION = 8       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
@@ -61,6 +61,7 @@ _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
+    'grl_conv_gemm_f32_group': ([C.POINTER(GrlGemm), C.c_int, _fp], C.c_int),
     'grl_gemm_force_tile': ([C.c_int, C.c_int], C.c_int),
     'grl_conv_gemm_f32_workspace_floats': ([C.POINTER(GrlGemm)], _i64),
     'grl_gemm_bf16_tile_mode': ([C.c_int], C.c_int),

@@ -651,3 +651,45 @@ int launch_variant(const GrlGemm& d, const Group& grp, hipStream_t s, int varian
 }
 
 }  // namespace ring
+
+#ifndef GRL_RING_NO_CABI
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI: several GEMMs of ONE shape in one launch (include/grl_hip.h).  The two directions of a TRL step run the same
+// 8192-row GEMMs on different operands (grl_model.py:131-167): M = 8192 gives 64-128 tiles of the large bf16 tiles --
+// half a chip -- and two launches on two streams cannot share a CU (one workgroup owns its LDS).  Grouped, they are one
+// launch of 256 x 128 tiles that fills the chip: 8192 x 512 x 2048 x 2: 2 x 35 us -> 44 us.
+extern "C" int grl_conv_gemm_f32_group(const GrlGemm* descs, int n, void* stream) {
+    if (!descs || n < 1 || n > 4) return grl_fail(GRL_EINVAL, "gemm_group: 1..4 descriptors");
+    const GrlGemm& d0 = descs[0];
+    bool same = true;
+    for (int g = 1; g < n; ++g) {
+        const GrlGemm& d = descs[g];
+        same = same && d.M == d0.M && d.N == d0.N && d.K == d0.K && d.lda == d0.lda && d.ldw == d0.ldw && d.ldy == d0.ldy &&
+               d.ldres == d0.ldres && d.relu == d0.relu && d.epilogue == d0.epilogue && d.math == d0.math && d.conv == d0.conv &&
+               d.out_f32 == d0.out_f32 && (d.res != nullptr) == (d0.res != nullptr) && (d.scale != nullptr) == (d0.scale != nullptr) &&
+               (d.shift != nullptr) == (d0.shift != nullptr);
+    }
+    bool plain = true;                      // what the grouped kernel covers: dense, affine, no optional operand but res
+    for (int g = 0; g < n; ++g) {
+        const GrlGemm& d = descs[g];
+        plain = plain && ring::shape_ok(d) && !d.conv && d.epilogue == GRL_EPI_AFFINE && !d.stats && !d.gbias && !d.bn_z && !d.kblock;
+    }
+    static const bool group_on = [] { const char* e = getenv("GRL_GEMM_GROUP"); return !e || atoi(e) != 0; }();
+    if (n >= 2 && same && plain && group_on && d0.scale && d0.shift) {
+        ring::Group grp;
+        grp.n = n;
+        for (int g = 0; g < 4; ++g) {
+            const GrlGemm& d = descs[g < n ? g : 0];
+            grp.a[g] = d.a; grp.w[g] = d.w; grp.y[g] = d.y; grp.scale[g] = d.scale; grp.shift[g] = d.shift; grp.res[g] = d.res;
+        }
+        // tiles: 256 x 128 while 256 x 256 tiles would leave CUs without one
+        const int64_t t256 = (int64_t)((d0.M + 255) / 256) * ((d0.N + 255) / 256) * n;
+        const int rc = t256 < 256 ? ring::launch_tile<256, 128, 5>(d0, grp, (hipStream_t)stream)
+                                  : ring::launch_tile<256, 256, 5>(d0, grp, (hipStream_t)stream);
+        if (rc <= 0) return rc;                              // launched (0) or failed (< 0); 1 = not covered
+    }
+    for (int g = 0; g < n; ++g)
+        if (const int rc = grl_conv_gemm_f32(&descs[g], stream)) return rc;
+    return GRL_OK;
+}
+#endif  // GRL_RING_NO_CABI

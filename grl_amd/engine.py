@@ -201,6 +201,30 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     return y
 
 
+def gemm_group(calls):
+    """Several dense GEMMs of ONE shape in one launch where the library can group them (grl_conv_gemm_f32_group;
+    bit-identical to ``gemm(**c)`` for every c in order, which is also what it falls back to).  ``calls``: list of
+    dicts with the plain-affine keyword subset of :func:`gemm` (a, w, y, M, N, K, scale, shift, res, relu, math, ld*)."""
+    n = len(calls)
+    arr = (GrlGemm * n)()
+    for d, c in zip(arr, calls):
+        d.a, d.w, d.y = ptr(c['a']), ptr(c['w']), ptr(c['y'])
+        d.scale, d.shift, d.res = ptr(c.get('scale')), ptr(c.get('shift')), ptr(c.get('res'))
+        d.M, d.N, d.K = c['M'], c['N'], c['K']
+        d.lda = c.get('lda') or d.K
+        d.ldw = c.get('ldw') or d.K
+        d.ldy = c.get('ldy') or d.N
+        d.ldres = c.get('ldres') or d.N
+        d.relu = 1 if c.get('relu') else 0
+        d.epilogue = EPI_AFFINE
+        m = c.get('math')
+        d.math = (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if m is None else m
+    check(_lib.load().grl_conv_gemm_f32_group(arr, n, _lib.stream()), 'grl_conv_gemm_f32_group')
+    if _DEBUG_SYNC:
+        _debug_sync('gemm_group x%d %s' % (n, (calls[0]['M'], calls[0]['N'], calls[0]['K'])))
+    return [c['y'] for c in calls]
+
+
 _DEBUG_SYNC = bool(os.environ.get('GRL_DEBUG_SYNC'))      # debugging only: name every launch on stderr and wait for it
 
 
@@ -501,6 +525,7 @@ def gce_eval(plan, x4, b, t, taps=None):
 # same per-direction order, per-direction scratch: bit-identical to the single-stream order
 # (GRL_TRL_STREAMS=0, or taps requested).
 TRL_STREAMS = os.environ.get('GRL_TRL_STREAMS', '1') != '0'
+TRL_GROUP = os.environ.get('GRL_TRL_GROUP', '0') != '0'       # bf16 storage: conv1 / conv2 of both directions as grouped launches (measured slower: see below)
 _side_streams = {}
 
 
@@ -526,6 +551,20 @@ class _TrlFork(object):
 
     def on(self, di):
         return torch.cuda.stream(self.side if di == 1 else self.main)
+
+    def side_to_main(self):
+        """main waits for everything issued on the side stream so far"""
+        if self.two:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+
+    def main_to_side(self):
+        """the side stream waits for everything issued on the main stream so far"""
+        if self.two:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
 
     def join(self, *side_tensors):
         if self.two:
@@ -794,7 +833,21 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     _call('grl_temporal_mean_bf16', ptr(xu), ptr(memo0), b, t, frame)
     gapc = _new((b * t, Cc), x)
     _call('grl_group_mean_bf16', ptr(xc), ptr(gapc), b * t, PIX, Cc, Cc, C.c_float(1.0), 0)
+    # bf16 storage: the large bf16 tiles own a CU's LDS, so the two directions' M = b * 128 GEMMs cannot share a CU and
+    # each leaves half the chip idle.  Round 5: the two directions' conv1 / conv2 of a step (same shape, different
+    # operands) go out as ONE grouped launch (grl_conv_gemm_f32_group: 256 x 128 tiles over both problems, bit-identical
+    # to the separate launches) on the main stream, between two event hand-offs; everything else of a direction stays on
+    # its own stream.  Every buffer that crosses streams is allocated on the main stream before the fork and lives until
+    # the join.  MEASURED SLOWER in the pipeline (configs[2] same box 10.48 -> 10.68 ms; on ONE stream 10.78): alone the
+    # grouped launch beats two launches (44 vs 2 x 35 us), but the 128 x 64 ring kernel the separate launches run on keeps
+    # two workgroups per CU, so the two streams' launches already share every CU -- and the hand-offs cost their bubbles.
+    # Off by default (GRL_TRL_GROUP=1 switches it on; kept tested: test_trl_grouped_launches_equal_two_stream_form).
+    grouped = TRL_GROUP and len(plan.dirs) == 2
     fk = _TrlFork(x.device, taps is None and len(plan.dirs) == 2)
+    bufs = None
+    if grouped:
+        bufs = [dict(s=_newb((Mb, Cc), x), o=_newb((Mb, 512), x), o2=_newb((Mb, 512), x),
+                     m=(_newb((Mb, Cc), x), _newb((Mb, Cc), x))) for _ in plan.dirs]
     fk.fork()
     f2, fc, scr = [], [], []
     for di, d in enumerate(plan.dirs):
@@ -805,24 +858,49 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device) if (fk.two or di == 0) else fc[0])
             scr.append((_new((b, Cc), x), _new((b, 128), x)))
     memo = [memo0, memo0]
+
+    def f1_branch(di, d, ti):
+        dvec, hid = scr[di]
+        if FUSE_TRL_SQDIFF and Mb % 256 == 0:
+            # the squared difference reduced in the f1 GEMM's epilogue (32-row partial sums): conv_f1's output
+            # never reaches HBM -- round 3: the bf16 256 x 256 kernel has the epilogue too
+            dpart = _new((Mb // 32, Cc), x)
+            gemm(memo[di], d['f1'].wb(), dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
+                 res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX, math=MATH_BF16S)
+            _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
+        else:
+            f1 = _newb((Mb, Cc), x)
+            gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
+            _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
+        _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
+              None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+
     for i in range(t):
+        tis = [i, t - 1 - i]
+        if grouped:
+            for di, d in enumerate(plan.dirs):
+                with fk.on(di):
+                    f1_branch(di, d, tis[di])
+                    _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[tis[di] * frame:]), ptr(bufs[di]['s']),
+                          b, frame, t * frame)
+            fk.side_to_main()
+            gemm_group([dict(a=bufs[di]['s'], w=d['c1'].wb(), y=bufs[di]['o'], M=Mb, N=512, K=Cc, scale=d['c1'].scale,
+                             shift=d['c1'].shift, relu=True, math=MATH_BF16S) for di, d in enumerate(plan.dirs)])
+            gemm_group([dict(a=bufs[di]['o'], w=d['c2'].wb(), y=bufs[di]['o2'], M=Mb, N=512, K=512, scale=d['c2'].scale,
+                             shift=d['c2'].shift, relu=True, math=MATH_BF16S) for di, d in enumerate(plan.dirs)])
+            fk.main_to_side()
+            for di, d in enumerate(plan.dirs):
+                with fk.on(di):
+                    c3 = d['c3']
+                    nm = bufs[di]['m'][i & 1]
+                    gemm(bufs[di]['o2'], c3.wb(), nm, Mb, Cc, 512, scale=c3.scale, shift=c3.shift, res=bufs[di]['s'], relu=True,
+                         math=MATH_BF16S)
+                    memo[di] = nm
+            continue
         for di, d in enumerate(plan.dirs):
             with fk.on(di):
-                ti = i if di == 0 else t - 1 - i
-                dvec, hid = scr[di]
-                if FUSE_TRL_SQDIFF and Mb % 256 == 0:
-                    # the squared difference reduced in the f1 GEMM's epilogue (32-row partial sums): conv_f1's output
-                    # never reaches HBM -- round 3: the bf16 256 x 256 kernel has the epilogue too
-                    dpart = _new((Mb // 32, Cc), x)
-                    gemm(memo[di], d['f1'].wb(), dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
-                         res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX, math=MATH_BF16S)
-                    _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
-                else:
-                    f1 = _newb((Mb, Cc), x)
-                    gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
-                    _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
-                _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                      None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+                ti = tis[di]
+                f1_branch(di, d, ti)
                 s_ = _newb((Mb, Cc), x)
                 _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
                 c1, c2_, c3 = d['c1'], d['c2'], d['c3']

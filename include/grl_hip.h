@@ -35,8 +35,8 @@ const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
  * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*;
- * round 4: 6 with grl_bottleneck_tail_bf16). */
-#define GRL_ABI_VERSION 7
+ * round 4: 6 with grl_bottleneck_tail_bf16, 7 grl_gemm_force_tile; round 5: 8 with grl_conv_gemm_f32_group). */
+#define GRL_ABI_VERSION 8
 int grl_abi_version(void);
 
 /* epilogue selector of grl_conv_gemm_f32 */
@@ -137,6 +137,14 @@ int grl_gemm_bf16_tile_mode(int mode);
 int grl_gemm_force_tile(int bm, int bn);
 /* rows of the stats slab the call above writes (= number of M tiles it will use) */
 int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc);
+/* n (1..4) GEMMs in ONE launch where the kernels allow it (round 5): the same result, bit for bit, as n calls of
+ * grl_conv_gemm_f32 in order -- which is also what runs when they do not (different shapes or flags, fp32 storage,
+ * conv geometry, statistics ...).  Grouped today: GRL_MATH_BF16S dense GEMMs of one shape with the plain affine
+ * epilogue (scale, shift, optional res, relu) that differ only in a, w, y, scale, shift, res.
+ * Replaces: the conv1 / conv2 1x1 convolutions of the forward AND the backward memo block of one TRL step
+ * (reid/models/grl_model.py:56-64 called at :155 and :167) -- two independent 8192-row GEMMs of the same shape that
+ * each fill half a chip.  GRL_GEMM_GROUP=0: always n separate launches. */
+int grl_conv_gemm_f32_group(const GrlGemm* descs, int n, void* stream);
 
 /* [N][C][kh][kw] (torch layout) -> [N][kh*kw][C]; replaces nothing in the
  * reference (layout packing for the implicit GEMM). */

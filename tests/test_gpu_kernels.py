@@ -519,6 +519,55 @@ def test_gemm_bf16_256_tile_equals_128_family(dev, M, N, K, conv, gb):
     assert torch.equal(ys[1][:M], ref.bfloat16()) or _rel(ys[1][:M].float().cpu().numpy(), ref.cpu().numpy()) < 8e-3
 
 
+@pytest.mark.parametrize('M,N,K,n,res', [
+    (8192, 512, 2048, 2, False),        # the TRL memo block's conv1 of both directions (256 x 128 ring tiles, 256 of them)
+    (8192, 512, 512, 2, False),         # ... conv2
+    (2048, 2048, 512, 2, True),         # residual, 256 x 256 ring tiles
+    (700, 520, 192, 3, True),           # ragged M and N, three problems, edge-tile epilogue
+    (256, 64, 64, 4, False),            # one tile per problem, K = one stage
+    (300, 200, 128, 2, True)])          # N % 8 == 0 only
+def test_gemm_group_equals_separate_launches(dev, M, N, K, n, res):
+    """grl_conv_gemm_f32_group (round 5: the bf16 ring kernel over several problems of one shape) against one
+    grl_conv_gemm_f32 call per problem: bit-identical outputs, nothing written past a problem's M rows."""
+    from grl_amd import engine
+    rng = np.random.default_rng(M + N + K + n)
+    calls, refs = [], []
+    for g in range(n):
+        a = torch.from_numpy(np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)).bfloat16().to(dev)
+        w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).bfloat16().to(dev)
+        r = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).bfloat16().to(dev) if res else None
+        sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(dev)
+        sh = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+        y = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ref = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev)
+        engine.gemm(a, w, ref, M, N, K, scale=sc, shift=sh, res=r, relu=True, math=2)
+        calls.append(dict(a=a, w=w, y=y, M=M, N=N, K=K, scale=sc, shift=sh, res=r, relu=True, math=2))
+        refs.append(ref)
+    engine.gemm_group(calls)
+    for c, ref in zip(calls, refs):
+        assert torch.equal(c['y'], ref)
+        assert bool((c['y'][M] == 7.0).all())
+
+
+def test_gemm_group_falls_back_for_ungroupable_calls(dev):
+    """Different shapes, or the exact-fp32 datapath: the group call runs the problems one by one (same results)."""
+    from grl_amd import engine
+    rng = np.random.default_rng(5)
+    calls, refs = [], []
+    for (M, N, K) in ((128, 64, 64), (256, 128, 32)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev)
+        w = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).to(dev)
+        sc = torch.ones(N, device=dev)
+        sh = torch.zeros(N, device=dev)
+        y, ref = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+        engine.gemm(a, w, ref, M, N, K, scale=sc, shift=sh, math=0)
+        calls.append(dict(a=a, w=w, y=y, M=M, N=N, K=K, scale=sc, shift=sh, math=0))
+        refs.append(ref)
+    engine.gemm_group(calls)
+    for c, ref in zip(calls, refs):
+        assert torch.equal(c['y'], ref)
+
+
 def test_bf16_storage_pointwise_twins(dev):
     """bf16-storage twins of the bandwidth-bound kernels against their fp32 twins on
     bf16-representable data: identical fp32 results for the reductions, one rounding on bf16

@@ -460,6 +460,24 @@ def test_baseline_config2_bf16_T8_B64(gpu_models):
     assert err < 3e-2
 
 
+def test_trl_grouped_launches_equal_two_stream_form(gpu_models):
+    """bf16 storage: the TRL step's conv1 / conv2 of both directions as grouped launches on one stream (round 5)
+    against the two-stream form of rounds 2-4: the same kernels' arithmetic per output, bit-identical features."""
+    from grl_amd import engine
+    cnn, siam, _ = gpu_models
+    clips = synth_clips(6, 8, seed=11).cuda()
+    old = engine.TRL_GROUP
+    try:
+        with engine.math_mode('bf16s'):
+            engine.TRL_GROUP = True
+            a = engine.extract_features(cnn, siam, clips)
+            engine.TRL_GROUP = False
+            b = engine.extract_features(cnn, siam, clips)
+    finally:
+        engine.TRL_GROUP = old
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 def test_baseline_config4_full_mars_rank1_map():
     """BASELINE configs[4]: the full MARS-size query x gallery matrix on the GPU, then the
     reference's host ranking: Rank-1 / mAP / CMC equal to those of the CPU (BLAS) distance

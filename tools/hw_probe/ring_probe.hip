@@ -11,6 +11,7 @@
 #include <string.h>
 #include <vector>
 #include <string>
+#define GRL_RING_NO_CABI 1
 #include "../../grl_amd/csrc/gemm_bf16.hip"
 #include "../../grl_amd/csrc/gemm_bf16_ring.hip"
 

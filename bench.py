@@ -241,7 +241,7 @@ def cpu_baseline(sd, ssd):
                       "step, T=%d, %d timed passes (%.1f s)" % (cores, os.cpu_count() or 0, nb, T, passes, dt)}
 
 
-def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=None, profile='default', graph=False,
+def train_series(dev, math, steps=20, warmup=5, b=32, t=4, rank=0, world=1, dist=None, profile='default', graph=False,
                  roofline=False):
     """One SEQTrainer step (forward + 5-term loss + HIP backward + bucketed gradient all-reduce when a process
     group is up + SGD) on b x t synthetic pair-interleaved clips per rank.  Timed with a barrier + device sync on
@@ -306,17 +306,28 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
             loss = step()
         barrier()
         del waits[:]
+        # a HIP event on the launch stream after every step (read after the timed region: nothing blocks the host):
+        # the spread of the step times says whether a series is stable (round 4: 6 steps after 3 warm-ups could not
+        # tell a regression from allocator / clock-ramp jitter -- driver 58.8 ms against 53.5 here)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for k in range(steps):
             loss = step()
+            marks[k + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
         assert bool(torch.isfinite(loss).all())
     finally:
         train_engine.set_math(old)
     dt = max_over_ranks(dist, dev, dt)
     ms = dt / steps * 1e3
-    out = {"ms_per_step": round(ms, 2), "clips_per_sec": round(max(world, 1) * b / ms * 1e3, 1)}
+    out = {"ms_per_step": round(ms, 2), "clips_per_sec": round(max(world, 1) * b / ms * 1e3, 1),
+           "steps": steps, "warmup": warmup,
+           "step_ms_on_stream": {"median": round(per_step[len(per_step) // 2], 2), "min": round(per_step[0], 2),
+                                 "max": round(per_step[-1], 2)},
+           "side_streams": side_streams_state()}
     if roofline:
         # per GPU: algorithmic FLOPs of this rank's step / the step time; the dominant kernels timed live (N = 1 only:
         # the timing pass runs extra steps, which at N > 1 would have to stay in lockstep over the collectives)
@@ -337,13 +348,21 @@ def train_series(dev, math, steps=6, warmup=3, b=32, t=4, rank=0, world=1, dist=
     return out
 
 
-def train_step_ms(dev, math, steps=6, warmup=3, b=32, t=4, graph=False):
+def side_streams_state():
+    """which of the train step's side streams are switched on (environment: GRL_TRL_STREAMS / GRL_WGRAD_STREAM /
+    GRL_HEAD_STREAMS): a series measured without them is a different regime (EXPERIMENTS.md, round 4: 7-9 %)"""
+    from grl_amd import engine, train_engine
+    from grl_amd.reid.train import trainer
+    return {"trl": bool(engine.TRL_STREAMS), "wgrad": bool(train_engine.WGRAD_STREAM), "heads": bool(trainer.HEAD_STREAMS)}
+
+
+def train_step_ms(dev, math, steps=20, warmup=5, b=32, t=4, graph=False):
     return train_series(dev, math, steps, warmup, b, t, graph=graph)["ms_per_step"]
 
 
-def train_step_record(dev, math, steps=6, warmup=3, b=32, t=4):
+def train_step_record(dev, math, steps=20, warmup=5, b=32, t=4):
     r = train_series(dev, math, steps, warmup, b, t, roofline=True)
-    return {"ms_per_step": r["ms_per_step"], "clips_per_sec": r["clips_per_sec"], "roofline": r["roofline"]}
+    return {k: r[k] for k in ("ms_per_step", "clips_per_sec", "steps", "warmup", "step_ms_on_stream", "side_streams", "roofline")}
 
 
 def train_block(dev, rank, world, dist, backend):
@@ -357,7 +376,7 @@ def train_block(dev, rank, world, dist, backend):
            "rccl_version": rccl_version()}
     for m in ('f32', 'mixed'):
         release_cached_blocks()
-        out[m] = train_series(dev, m, steps=5, warmup=2, b=64, t=4, rank=rank, world=world, dist=dist, roofline=True)
+        out[m] = train_series(dev, m, steps=12, warmup=4, b=64, t=4, rank=rank, world=world, dist=dist, roofline=True)
     return out
 
 
@@ -410,7 +429,7 @@ def secondary_block(dev, cnn, siam, steps):
     out["train step, B x T = 32 x 4 (fwd + loss + bwd + SGD)"] = {m: fresh(m) for m in ('f32', 'mixed', 'bf16x3', 'bf16s')}
     # (`--mode train --graph` replays the same step from a HIP graph -- grl_amd.train_graph, bit-identical; measured
     # slower than the eager step on this stack, EXPERIMENTS.md, so it is not part of the default line)
-    v = fresh('bf16s', b=64, t=8)
+    v = fresh('bf16s', b=64, t=8, steps=12, warmup=4)
     release_cached_blocks()
     v["frames_per_sec"] = round(512 / v["ms_per_step"] * 1e3)
     out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = v

@@ -573,7 +573,10 @@ class TrainBlockGuard(object):
     def __init__(self, rank, world, limit, emit_error_line):
         import tempfile
         self.rank, self.world, self.limit, self.emit_error_line = rank, world, limit, emit_error_line
-        key = 'grl_bench_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'))
+        # (GRL_BENCH_NONCE: set per launch by launch_ranks -- with a reused port / run id a rank could otherwise read the
+        #  .err file of an EARLIER failed run; bare torchrun launches fall back to the launcher's pid, shared by its ranks)
+        key = 'grl_bench_%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'),
+                                      os.environ.get('GRL_BENCH_NONCE') or os.getppid())
         self.err = os.path.join(tempfile.gettempdir(), key + '.err')
         self.out = os.path.join(tempfile.gettempdir(), key + '.out')
         self.done = threading.Event()
@@ -656,6 +659,7 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '8')
+    env['GRL_BENCH_NONCE'] = '%d_%d' % (os.getpid(), int(time.time() * 1e3))      # (TrainBlockGuard's file key)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)

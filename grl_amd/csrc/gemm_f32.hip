@@ -727,7 +727,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         // Same operations in the same order as below: bit-identical.  (Not in the K-blocked SEG instantiations: the
         // train-mode forward they serve always carries statistics, and their second accumulator set leaves no registers.)
         if constexpr (!SEG) {
-            const bool fast = p.epilogue == GRL_EPI_AFFINE && !p.rowscale && !p.gbias && !p.stats && !p.bn_z &&
+            // (... or carrying a BatchNorm-backward reduce, GrlGemm.bn_z: the data-gradient GEMMs of a training step --
+            //  a row of z and a mask word per output row on top of the residual, the launches the general loop hurt most)
+            const bool bnz = MATH != 2 && p.bn_z != nullptr && p.stats != nullptr;
+            const bool fast = p.epilogue == GRL_EPI_AFFINE && !p.rowscale && !p.gbias && (bnz || (!p.stats && !p.bn_z)) &&
                               m0 + BM <= p.M && n0 + BN <= p.N && (MATH != 2 || (!p.out_f32 && p.N % 8 == 0));
             if (fast) {
                 auto park = [&]() {
@@ -740,8 +743,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                                 Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + wn * WTN + j * 32 + col_l] = acc[i][j][r];
                 };
                 const bool relu = p.relu != 0;
-                auto run = [&](auto has_res_) {
+                auto run = [&](auto has_res_, auto bnz_) {
                     constexpr bool HAS_RES = decltype(has_res_)::value;
+                    constexpr bool BNZ = decltype(bnz_)::value && MATH != 2;
                     if constexpr (MATH == 2) {
                         constexpr int LPR8 = WTN / 8, RPI8 = 64 / LPR8, NIT = WTM / RPI8, CH = (BM == 128 && BN == 128) ? 2 : (NIT < 4 ? NIT : 4);
                         const int lrow = lane / LPR8, lcol = (lane % LPR8) * 8;
@@ -794,19 +798,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                         const int n = n0 + wn * WTN + lcol;
                         const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
                         const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        f32x4 rr[2][CH];
+                        // BatchNorm-backward reduce: the three mask forms of the general loop without a branch -- recorded
+                        // bits (a mask byte is loaded either way; all ones where there are none), and / or the forward's
+                        // (z - mean) * mscale + mbeta > 0 (`+ 0` where mbeta is absent leaves the comparison as it is)
+                        f32x4 bmu = sh, bis = sh, bms = f32x4{0.f, 0.f, 0.f, 0.f}, bmb = bms;
+                        const bool use_bits = BNZ && p.bn_bits != nullptr;
+                        if constexpr (BNZ) {
+                            bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + n);
+                            bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + n);
+                            if (!use_bits && p.bn_mscale) {
+                                bms = *reinterpret_cast<const f32x4*>(p.bn_mscale + n);
+                                bmb = p.bn_mbeta ? *reinterpret_cast<const f32x4*>(p.bn_mbeta + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
+                        // (a valid word to load where there are no recorded bits: the z row itself)
+                        const uint8_t* const bbyte = use_bits ? p.bn_bits : reinterpret_cast<const uint8_t*>(p.bn_z);
+                        const bool use_ms = BNZ && !use_bits && p.bn_mscale != nullptr;
+                        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 rr[2][CH], zz[2][BNZ ? CH : 1];
+                        uint32_t bb[2][BNZ ? CH : 1];
                         auto request = [&](int c) {
 #pragma unroll
                             for (int k = 0; k < CH; ++k) {
                                 const int m = m0 + wm * WTM + (c * CH + k) * RPI + lrow;
-                                rr[c & 1][k] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                                if constexpr (HAS_RES) rr[c & 1][k] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
+                                if constexpr (BNZ) {
+                                    zz[c & 1][k] = *reinterpret_cast<const f32x4*>(p.bn_z + (int64_t)m * p.N + n);
+                                    bb[c & 1][k] = bbyte[((int64_t)m * p.N + n) >> 2];
+                                }
                             }
                         };
-                        if constexpr (HAS_RES) request(0);
+                        if constexpr (HAS_RES || BNZ) request(0);
                         park();
 #pragma unroll
                         for (int c = 0; c < NIT / CH; ++c) {
-                            if constexpr (HAS_RES) { if (c + 1 < NIT / CH) request(c + 1); }
+                            if constexpr (HAS_RES || BNZ) { if (c + 1 < NIT / CH) request(c + 1); }
 #pragma unroll
                             for (int k = 0; k < CH; ++k) {
                                 const int row = wm * WTM + (c * CH + k) * RPI + lrow;
@@ -816,13 +842,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                                 if constexpr (HAS_RES) v += rr[c & 1][k];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = relu ? (v[e] > 0.f ? v[e] : 0.f) : v[e];
+                                if constexpr (BNZ) {
+                                    const f32x4 zc = zz[c & 1][k] - bmu;
+                                    const uint32_t mk = use_bits ? bb[c & 1][k] : 0xfu;
+                                    const f32x4 t = zc * bms + bmb;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = ((((mk >> e) & 1u) != 0) & (!use_ms | (t[e] > 0.f))) ? v[e] : 0.f;
+                                    ssum += v; ssq += v * (zc * bis);
+                                }
                                 *reinterpret_cast<f32x4*>(p.y + (int64_t)m * p.ldy + n) = v;
+                            }
+                        }
+                        if constexpr (BNZ) {
+                            // the general path's reduction, step for step (a lane's rows above; then the lanes of a column
+                            // group, the two wave rows through LDS): stats[tile_m][0|1][n]
+#pragma unroll
+                            for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+                            }
+                            __syncthreads();                               // every wave has read its C slab: LDS is free
+                            float* red = smem;                             // [2 wm][2][BN]
+                            if (lrow == 0) {
+                                *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + wn * WTN + lcol) = ssum;
+                                *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + wn * WTN + lcol) = ssq;
+                            }
+                            __syncthreads();
+                            for (int c = tid; c < BN; c += 256) {
+                                const int nn = n0 + c;
+                                p.stats[((int64_t)tile_m * 2 + 0) * p.N + nn] = red[0 * BN + c] + red[2 * BN + c];
+                                p.stats[((int64_t)tile_m * 2 + 1) * p.N + nn] = red[1 * BN + c] + red[3 * BN + c];
                             }
                         }
                     }
                 };
-                if (p.res) run(std::true_type{});
-                else run(std::false_type{});
+                if (bnz) {
+                    if (p.res) run(std::true_type{}, std::true_type{});
+                    else run(std::false_type{}, std::true_type{});
+                } else if (p.res) run(std::true_type{}, std::false_type{});
+                else run(std::false_type{}, std::false_type{});
                 return;
             }
         }
@@ -1378,7 +1436,8 @@ TileChoice choose_tile(const GrlGemm& d) {
     TileChoice t = legacy_tile(d);
     const char* const ws_env = getenv("GRL_GEMM_WIDE_STATS");             // (read per call: the parity test toggles it)
     const bool wide_stats = !ws_env || atoi(ws_env) != 0;
-    static const bool forced = getenv("GRL_GEMM_TILE") != nullptr;
+    static const bool forced_env = getenv("GRL_GEMM_TILE") != nullptr;
+    const bool forced = forced_env || g_force_tile != 0;       // (a forced tile -- environment or grl_gemm_force_tile -- is final)
     if (!wide_stats || forced || !d.stats || d.bn_z || d.math == GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.N < 128 ||
         !vec_epilogue_ok(d) || ((uintptr_t)d.stats & 15) != 0)
         return t;

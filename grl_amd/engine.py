@@ -476,7 +476,7 @@ def trunk_eval(plan, x, taps=None):
                 res = cur
             nxt = plan.blocks[bi]['c1'] if bi < len(plan.blocks) else None
             o1 = None
-            if FUSE_BNECK and nxt is not None and _bneck_tail_f32_ok(e['c3'], nxt):
+            if FUSE_BNECK and nxt is not None and _bneck_tail_f32_ok(e['c3'], nxt, n * Ho * Wo):
                 # layers 1-2: conv3 + residual + ReLU AND the next block's conv1 in one launch, bit-identical to the two
                 # GEMM launches (fuse_f32.hip) -- the 4P-wide output is written once and never re-read
                 cur, o1 = bneck_tail_f32(o2, e['c3'], res, nxt, n * Ho * Wo)
@@ -683,7 +683,7 @@ def conv3x3_c64_bf16(x, c, n_img, H, W, relu=True):
 
 def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     if (FUSE_C64 and c.k == 3 and stride == 1 and c.cin == 64 and c.N == 64 and W == 32 and H % 8 == 0 and res is None
-            and not kw):
+            and not kw and n_img * H * W * 128 < (1 << 32)):          # (32-bit byte offsets inside that kernel)
         return conv3x3_c64_bf16(x, c, n_img, H, W, relu), H, W
     if c.k == 1 and stride == 1:
         M = n_img * H * W
@@ -700,8 +700,10 @@ def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     return y, Ho, Wo
 
 
-def _bneck_tail_ok(c3, c1n):
-    return (c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and
+def _bneck_tail_ok(c3, c1n, M):
+    # (the fused kernels address with 32-bit byte offsets: M * C4 * 2 bytes must stay below 4 GiB, else the per-conv
+    #  launches -- 64-bit row addressing -- take the block)
+    return (c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and M * c3.N * 2 < (1 << 32) and
             bool(_lib.load().grl_bottleneck_tail_bf16_supported(c3.K, c3.N, c1n.N)))
 
 
@@ -732,8 +734,9 @@ def bneck_tail_bf16(t2, c3, res, c1n, M, down=None, x0=None):
     return y, u
 
 
-def _bneck_tail_f32_ok(c3, c1n):
-    return (_math[0] == MATH_F32 and c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and
+def _bneck_tail_f32_ok(c3, c1n, M):
+    # (32-bit byte offsets inside the fused kernel: M * C4 * 4 bytes below 4 GiB, else one launch per convolution)
+    return (_math[0] == MATH_F32 and c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and M * c3.N * 4 < (1 << 32) and
             bool(_lib.load().grl_bottleneck_tail_f32_supported(c3.K, c3.N, c1n.N)))
 
 
@@ -789,7 +792,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
         o2, Ho, Wo = _conv_b16(o1, e['c2'], n, H, W, stride=s)
         nxt = plan.blocks[bi + 1]['c1'] if bi + 1 < len(plan.blocks) else None
-        fuse = FUSE_BNECK and nxt is not None and _bneck_tail_ok(e['c3'], nxt)
+        fuse = FUSE_BNECK and nxt is not None and _bneck_tail_ok(e['c3'], nxt, n * Ho * Wo)
         o1 = None
         if fuse and FUSE_DOWN and _bneck_down_ok(e['c3'], nxt, e['down'], s):
             # layer 1's first block: the downsample branch too -- its 4P-wide output is neither written nor re-read

@@ -233,7 +233,7 @@ class Tape(object):
         self.bnrec = {}         # id(activation of a conv_bn) -> _BNRec: what its BatchNorm backward needs (fused reduce)
         self.fuse_ok = set()    # ids of activations whose ONLY consumers are conv_bn ops (as input or residual)
         self.prep_event = None  # WeightPrep launched on the side stream: the launch stream joins it before layer 1
-        self.foreign = {}       # data_ptr -> tensor: gradient buffers the tape does NOT own exclusively (handed in by
+        self.foreign = {}       # storage data_ptr -> tensor: gradient buffers the tape does NOT own exclusively (handed in by
                                 # autograd, or registered for more than one forward tensor): never masked / overwritten
                                 # in place.  The tensors are held so that the address cannot be recycled within the step.
 
@@ -268,7 +268,8 @@ class Tape(object):
     def owns(self, g):
         """True if ``g`` is a gradient buffer a tape op allocated for exactly one forward tensor (so the op that
         popped it may overwrite it in place)."""
-        return g.data_ptr() not in self.foreign
+        # (storage identity, not data_ptr: a view of a foreign buffer at a non-zero offset is foreign too)
+        return g.untyped_storage().data_ptr() not in self.foreign
 
     # gradients of parameters --------------------------------------------------
     def reserve_param_grads(self, params, cuts=None):
@@ -1115,7 +1116,7 @@ def trl_train(tp, model, xu, xc, b, t):
         dfc = tp.g.get(id(fcorr))
         if dfc is not None:         # f_corr = fc[0] + fc[1]: both directions read the same upstream gradient
             tp.g[id(fc[0])] = tp.g[id(fc[1])] = dfc
-            tp.foreign[dfc.data_ptr()] = dfc
+            tp.foreign[dfc.untyped_storage().data_ptr()] = dfc
         if d is not None:
             tp.held.append(d)
             for di, m in enumerate((mf, mb_)):
@@ -1181,10 +1182,10 @@ class _GrlTrainFn(torch.autograd.Function):
         xu_out, xc_out = ctx.outs
         if d_uncorr is not None:
             tp.g[id(xu_out)] = d_uncorr.contiguous()
-            tp.foreign[tp.g[id(xu_out)].data_ptr()] = tp.g[id(xu_out)]
+            tp.foreign[tp.g[id(xu_out)].untyped_storage().data_ptr()] = tp.g[id(xu_out)]
         if d_corr is not None:
             tp.g[id(xc_out)] = d_corr.contiguous().view(xc_out.shape)
-            tp.foreign[tp.g[id(xc_out)].data_ptr()] = tp.g[id(xc_out)]
+            tp.foreign[tp.g[id(xc_out)].untyped_storage().data_ptr()] = tp.g[id(xc_out)]
         tp.backward()
         tp.flush()                                   # (whatever no section mark has sent)
         if tp.prep is not None and not tp.prep.ready:

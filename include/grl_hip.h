@@ -133,7 +133,9 @@ int grl_gemm_bf16_tile_mode(int mode);
 /* Kernel-tuning / test hook of the fp32-storage datapaths: force the workgroup tile of the following grl_conv_gemm_f32
  * calls to bm x bn (128x128, 128x64 or 64x64); (0, 0) returns to the per-shape rule.  Returns the previous setting as
  * (bm << 16) | bn (0 = automatic), GRL_EINVAL for any other pair.  Results never depend on the tile (one k-ordered
- * chain per output; the parity tests run every shape on every tile through this).  Not thread-safe. */
+ * chain per output; the parity tests run every shape on every tile through this).  TEST HOOK: process-wide state,
+ * not synchronised -- single-threaded callers only.  A forced tile is final: the statistics GEMMs' promotion to the
+ * 128 x 128 tile (choose_tile) does not apply while one is set. */
 int grl_gemm_force_tile(int bm, int bn);
 /* rows of the stats slab the call above writes (= number of M tiles it will use) */
 int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc);

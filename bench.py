@@ -570,13 +570,13 @@ class TrainBlockGuard(object):
     A watchdog thread per rank polls them, so a healthy rank that sits in a collective whose peer has failed leaves
     within a second instead of waiting for the time limit -- but only after rank 0 has printed."""
 
-    def __init__(self, rank, world, limit, emit_error_line):
+    def __init__(self, rank, world, limit, emit_error_line, tag='train'):
         import tempfile
         self.rank, self.world, self.limit, self.emit_error_line = rank, world, limit, emit_error_line
         # (GRL_BENCH_NONCE: set per launch by launch_ranks -- with a reused port / run id a rank could otherwise read the
         #  .err file of an EARLIER failed run; bare torchrun launches fall back to the launcher's pid, shared by its ranks)
-        key = 'grl_bench_%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'),
-                                      os.environ.get('GRL_BENCH_NONCE') or os.getppid())
+        key = 'grl_bench_%s_%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'),
+                                         os.environ.get('GRL_BENCH_NONCE') or os.getppid(), tag)
         self.err = os.path.join(tempfile.gettempdir(), key + '.err')
         self.out = os.path.join(tempfile.gettempdir(), key + '.out')
         self.done = threading.Event()
@@ -646,6 +646,39 @@ def run_guarded(guard, world, fn):
     return r
 
 
+def preflight(dist, rank, world, dev, backend):
+    """First contact of the process group (N > 1), BEFORE anything is measured: a 1 MB all-reduce whose result is
+    checked, timed twice (the first includes the communicator set-up), and what every rank sits on -- so that a hang or
+    a wrong topology at the first real multi-GPU run is attributable from the one JSON line.  Replaces nothing in the
+    reference (nn.DataParallel, mars_train.py:80-82, has no such step); `dev` None = CPU tensors (gloo dry run)."""
+    x = torch.ones(1 << 18, dtype=torch.float32, device=dev if dev is not None else 'cpu')
+    times = []
+    for _ in range(2):
+        if dev is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = x.clone()
+        dist.all_reduce(y)
+        if dev is not None:
+            torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        if not bool((y == float(world)).all()):
+            raise RuntimeError('preflight all-reduce returned %r, expected %d on every element' % (float(y[0]), world))
+    me = {"rank": rank, "pid": os.getpid(), "device": None}
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        me.update({"device": dev.index, "name": pr.name, "cus": pr.multi_processor_count,
+                   "pci_bus_id": getattr(pr, 'pci_bus_id', None), "hbm_gib": round(pr.total_memory / 2 ** 30, 1)})
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    return {"backend": backend, "ranks": world, "rccl_version": rccl_version() if backend == 'nccl' else None,
+            "allreduce_1MB_ms": {"first (with communicator set-up)": round(times[0], 3), "second": round(times[1], 3)},
+            "ipc": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                    "NCCL_env": {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))}},
+            "distinct_devices": len({(r["device"], r.get("pci_bus_id")) for r in ranks}) if dev is not None else None,
+            "per_rank": ranks}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process group
     (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and return its exit code.  This
@@ -702,6 +735,9 @@ def main():
                     help="eval (default): the headline clip-features/sec; train: secondary series, one "
                          "SEQTrainer step (forward + 5-term loss + HIP backward + grad all-reduce + SGD)")
     ap.add_argument('--no-train-block', action='store_true', help='skip the configs[3] `train` block of the eval line')
+    ap.add_argument('--no-preflight', action='store_true',
+                    help='N > 1: skip the first-contact step (a checked 1 MB all-reduce + every rank\'s device) that '
+                         'otherwise runs before anything is measured and is reported as `preflight` in the line')
     ap.add_argument('--graph', action='store_true', help='--mode train: replay the step from a HIP graph (single GPU)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher check (CPU tests): every rank joins a gloo group, the ranks are counted with an '
@@ -723,6 +759,8 @@ def main():
             dist.init_process_group('gloo')
             dist.all_reduce(n)
         line = {"dry_run": True, "world_size": int(n.item()), "n_gpus": args.gpus}
+        if world > 1 and not args.no_preflight:
+            line["preflight"] = preflight(dist, rank, world, None, 'gloo')
         fault = os.environ.get('GRL_BENCH_DRY_TRAIN')        # tests: 'ok' | 'hang' | 'raise' (on rank 1)
         if fault and world > 1:
             def fake_train_block():
@@ -759,6 +797,13 @@ def main():
         local = 0
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local)
+    pre = None
+    if dist is not None and world > 1 and not args.no_preflight:
+        # under the same guard as the train block: a hang in RCCL's first collective leaves ONE line and a red exit code
+        def pre_error(reason):
+            emit({"metric": "clip-features/sec", "value": None, "n_gpus": world, "preflight": {"error": reason}})
+        pguard = TrainBlockGuard(rank, world, float(os.environ.get('GRL_BENCH_PREFLIGHT_TIMEOUT', '120')), pre_error, tag='pre')
+        pre = run_guarded(pguard, world, lambda: preflight(dist, rank, world, dev, backend))
 
     from grl_amd import engine, _lib
     from grl_amd.synthetic import synth_clips
@@ -837,6 +882,8 @@ def main():
             out["dist_backend"] = dist.get_backend()
             out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == 'nccl' else None
             out["world_size"] = dist.get_world_size()
+            if pre is not None:
+                out["preflight"] = pre
     if want_train:
         # Every rank: the training step has collectives (RCCL gradient all-reduce at N > 1).  The headline line must
         # not depend on them: at N > 1 a guard prints it with `train: {"error"}` if the block hangs or raises on any

@@ -217,7 +217,9 @@ def test_bench_launcher_starts_n_fresh_ranks():
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
-    assert json.loads(lines[0]) == {"dry_run": True, "world_size": 2, "n_gpus": 2}
+    line = json.loads(lines[0])
+    line.pop('preflight')                                   # (round 5: the first-contact report, tested below)
+    assert line == {"dry_run": True, "world_size": 2, "n_gpus": 2}
     # the command the launcher builds
     import importlib.util
     spec = importlib.util.spec_from_file_location('grl_bench', os.path.join(ROOT, 'bench.py'))
@@ -286,3 +288,24 @@ def test_trainer_helpers_on_cpu_tensors():
         z = logits + 1
     fk.join()
     assert torch.equal(z, logits + 1)
+
+
+def test_bench_preflight_reports_every_rank():
+    """N > 1: the first-contact step (a checked 1 MB all-reduce + what every rank sits on) is part of the line --
+    here on two gloo ranks through the launcher's dry run (no GPU); `--no-preflight` leaves it out."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    pre = line['preflight']
+    assert pre['ranks'] == 2 and pre['backend'] == 'gloo'
+    assert sorted(r['rank'] for r in pre['per_rank']) == [0, 1]
+    assert len({r['pid'] for r in pre['per_rank']}) == 2
+    assert pre['allreduce_1MB_ms']['second'] > 0
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--no-preflight'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0
+    assert 'preflight' not in json.loads(res.stdout.decode().strip().splitlines()[-1])

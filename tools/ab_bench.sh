@@ -5,7 +5,7 @@
 A=$1; B=$2; shift 2
 for rep in 1 2 3; do
   for L in "$A" "$B"; do
-    ms=$(GRL_HIP_LIB=$L python bench.py --no-cpu-baseline --no-alt --no-train-block "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('roofline',{}).get('kernel','')[-60:])")
+    ms=$(GRL_HIP_LIB=$L python bench.py --no-cpu-baseline --no-alt --no-train-block "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])")
     echo "$(basename $L) $* : $ms"
   done
 done

@@ -91,6 +91,7 @@ _SIGNATURES = {
     'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),
     'grl_bn_bwd_finish': ([_fp] * 9 + [C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
+    'grl_bn_bwd_finish_bf16': ([_fp] * 9 + [C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_relu_bwd': ([_fp, _fp, _fp, _i64, C.c_int, _fp], C.c_int),
     'grl_axpby': ([_fp, _fp, _fp, C.c_float, C.c_float, _i64, _fp], C.c_int),
     'grl_axpy_strided': ([_fp, _i64, _fp, _i64, C.c_int, _i64, C.c_float, C.c_int, _fp], C.c_int),

@@ -60,7 +60,10 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 // `res` (row mapping res_rows / res_gstride), squared, summed per 32-row block in a fixed order (a lane over its 4 rows,
 // then the 8 lanes that own the same 8 channels by xor-shuffles) and written as fp32 partials y[M/32][N]: conv_f1's
 // output never reaches HBM (grl_model.py:146-149), as in the fp32 kernel.
-template <bool CONV, bool STATS = false, bool SQD = false, bool RES = false, bool GBIAS = false>
+// BNZ (round 5; with STATS): the BatchNorm-backward reduce of GrlGemm.bn_z in the interior epilogue -- 1: mask from the
+// recorded ReLU bits (one byte per eight outputs), 2: from z itself ((z - mean) * mscale + mbeta > 0), 3: no mask.  The two
+// statistics rows of a tile then hold sum g and sum g * (z - mean) * invstd of the masked gradient g the kernel stores.
+template <bool CONV, bool STATS = false, bool SQD = false, bool RES = false, bool GBIAS = false, int BNZ = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
                                                                const int num_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -269,22 +272,45 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
             }
             const bool relu = p.relu != 0;
             f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            bf16x8 res8[2][4];
+            // (BNZ: one block of rows in flight instead of two -- the z rows and the per-channel vectors need the registers)
+            constexpr int NB = BNZ ? 1 : 2;
+            bf16x8 res8[NB][4], z8[BNZ ? 1 : 1][BNZ ? 4 : 1];
+            uint32_t bb[BNZ == 1 ? 4 : 1];
+            const __bf16* const z16 = reinterpret_cast<const __bf16*>(p.bn_z);
+            f32x4 bmu[2], bis[2], bms[2], bmb[2];
+            if constexpr (BNZ != 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bmu[u] = *reinterpret_cast<const f32x4*>(p.bn_mean + cn + 4 * u);
+                    bis[u] = *reinterpret_cast<const f32x4*>(p.bn_invstd + cn + 4 * u);
+                    if constexpr (BNZ == 2) {
+                        bms[u] = *reinterpret_cast<const f32x4*>(p.bn_mscale + cn + 4 * u);
+                        bmb[u] = p.bn_mbeta ? *reinterpret_cast<const f32x4*>(p.bn_mbeta + cn + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
             auto res_request = [&](int i) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = cm0 + i * 32 + it * 8 + lrow;
                     int64_t rr = m;
                     if constexpr (SQD) rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
-                    if (INT || (m < p.M && n_ok)) res8[i & 1][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                    if constexpr (RES) {
+                        if (INT || (m < p.M && n_ok)) res8[i % NB][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                    }
+                    if constexpr (BNZ != 0) {
+                        z8[0][it] = *reinterpret_cast<const bf16x8*>(z16 + (int64_t)m * p.N + cn);
+                        if constexpr (BNZ == 1) bb[it] = p.bn_bits[((int64_t)m * p.N + cn) >> 3];
+                    }
                 }
             };
-            if constexpr (RES) res_request(0);
+            if constexpr (RES && NB == 2) res_request(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // two 32-row blocks of residual rows in flight (one dependent load per row would serialise the
                 // HBM-bound epilogue of a short-K layer)
-                if constexpr (RES) { if (i + 1 < 4) res_request(i + 1); }
+                if constexpr (NB == 2) { if constexpr (RES) { if (i + 1 < 4) res_request(i + 1); } }
+                else if constexpr (RES || BNZ != 0) res_request(i);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const float f1v = (float)(__bf16)(v[e] > 0.f ? v[e] : 0.f);
-                                    const float dd = f1v - (float)res8[i & 1][it][4 * u + e];
+                                    const float dd = f1v - (float)res8[i % NB][it][4 * u + e];
                                     part[u][e] += dd * dd;
                                 }
                             }
@@ -336,16 +362,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
                             if constexpr (GBIAS)
                                 v += *reinterpret_cast<const f32x4*>(p.gbias + (int64_t)(m / p.rows_per_group) * p.N + cn + 4 * u);
-                            if constexpr (STATS) { ssum[u] += v; ssq[u] += v * v; }
+                            if constexpr (STATS && BNZ == 0) { ssum[u] += v; ssq[u] += v * v; }
                             v = v * sc[u] + sh[u];
+                            f32x4 tv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float tt = v[e];
-                                if constexpr (RES) tt = tt + (float)res8[i & 1][it][4 * u + e];
+                                if constexpr (RES) tt = tt + (float)res8[i % NB][it][4 * u + e];
                                 else tt = tt + 0.f;
                                 tt = relu ? (tt > 0.f ? tt : 0.f) : tt;
-                                o[4 * u + e] = (__bf16)tt;
+                                tv[e] = tt;
                             }
+                            if constexpr (BNZ != 0) {
+                                f32x4 zc;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) zc[e] = (float)z8[0][it][4 * u + e] - bmu[u][e];
+                                if constexpr (BNZ == 1) {
+                                    const uint32_t mk = bb[it] >> (4 * u);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) tv[e] = ((mk >> e) & 1u) ? tv[e] : 0.f;
+                                } else if constexpr (BNZ == 2) {
+                                    const f32x4 tm = zc * bms[u] + bmb[u];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) tv[e] = tm[e] > 0.f ? tv[e] : 0.f;
+                                }
+                                ssum[u] += tv; ssq[u] += tv * (zc * bis[u]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[4 * u + e] = (__bf16)tv[e];
                         }
                         *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
                     }
@@ -409,6 +453,8 @@ static bool sqdiff_ok(const GrlGemm& d) {
 
 bool grl_gemm_bf16_256_takes(const GrlGemm& d) {
     const int mode = g_mode;
+    // (the BatchNorm-backward reduce lives in the INTERIOR epilogue: every tile must be one)
+    if (d.bn_z && (!d.stats || d.gbias || d.M % TB || d.N % TB || !d.bn_mean || !d.bn_invstd)) return false;
     if (sqdiff_ok(d)) return true;
     if (mode == 0) return false;
     if (d.math != GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.rowscale || d.out_f32) return false;
@@ -426,9 +472,9 @@ bool grl_gemm_bf16_256_takes(const GrlGemm& d) {
 int grl_gemm_bf16_256_stat_rows(const GrlGemm& d) { return 2 * ((d.M + TB - 1) / TB); }
 
 namespace {
-template <bool CONV, bool STATS, bool SQD, bool RES, bool GBIAS>
+template <bool CONV, bool STATS, bool SQD, bool RES, bool GBIAS, int BNZ = 0>
 void launch_256(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int num_tiles) {
-    auto kern = gemm_bf16_256_kernel<CONV, STATS, SQD, RES, GBIAS>;
+    auto kern = gemm_bf16_256_kernel<CONV, STATS, SQD, RES, GBIAS, BNZ>;
     static const bool attr = [&] {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         return true;
@@ -436,8 +482,21 @@ void launch_256(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int
     (void)attr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * STAGE, s, d, tiles_n, num_tiles);
 }
+template <bool CONV, int BNZ>
+void launch_256_bnz(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int num_tiles) {
+    if (d.res) launch_256<CONV, true, false, true, false, BNZ>(d, s, grid, tiles_n, num_tiles);
+    else launch_256<CONV, true, false, false, false, BNZ>(d, s, grid, tiles_n, num_tiles);
+}
 template <bool CONV, bool STATS>
 void launch_256_epi(const GrlGemm& d, hipStream_t s, unsigned grid, int tiles_n, int num_tiles) {
+    if constexpr (STATS) {
+        if (d.bn_z) {                       // (takes() has checked: every tile interior, no per-clip bias)
+            if (d.bn_bits) launch_256_bnz<CONV, 1>(d, s, grid, tiles_n, num_tiles);
+            else if (d.bn_mscale) launch_256_bnz<CONV, 2>(d, s, grid, tiles_n, num_tiles);
+            else launch_256_bnz<CONV, 3>(d, s, grid, tiles_n, num_tiles);
+            return;
+        }
+    }
     if (d.res) {
         if (d.gbias) launch_256<CONV, STATS, false, true, true>(d, s, grid, tiles_n, num_tiles);
         else launch_256<CONV, STATS, false, true, false>(d, s, grid, tiles_n, num_tiles);
@@ -461,6 +520,7 @@ int cus_of_device() {                  // persistent grid: one 8-wave workgroup 
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s) {
     const int mode = g_mode;
     const int cus = cus_of_device();
+    if (d.bn_z && (!d.stats || d.gbias || d.M % TB || d.N % TB || !d.bn_mean || !d.bn_invstd)) return 0;
     if (sqdiff_ok(d)) {
         const int tiles_n = d.N / TB;
         const int64_t num_tiles = (int64_t)(d.M / TB) * tiles_n;

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
         if constexpr (!SEG) {
             // (... or carrying a BatchNorm-backward reduce, GrlGemm.bn_z: the data-gradient GEMMs of a training step --
             //  a row of z and a mask word per output row on top of the residual, the launches the general loop hurt most)
-            const bool bnz = MATH != 2 && p.bn_z != nullptr && p.stats != nullptr;
+            const bool bnz = p.bn_z != nullptr && p.stats != nullptr;
             const bool fast = p.epilogue == GRL_EPI_AFFINE && !p.rowscale && !p.gbias && (bnz || (!p.stats && !p.bn_z)) &&
                               m0 + BM <= p.M && n0 + BN <= p.N && (MATH != 2 || (!p.out_f32 && p.N % 8 == 0));
             if (fast) {
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                 const bool relu = p.relu != 0;
                 auto run = [&](auto has_res_, auto bnz_) {
                     constexpr bool HAS_RES = decltype(has_res_)::value;
-                    constexpr bool BNZ = decltype(bnz_)::value && MATH != 2;
+                    constexpr bool BNZ = decltype(bnz_)::value;
                     if constexpr (MATH == 2) {
                         constexpr int LPR8 = WTN / 8, RPI8 = 64 / LPR8, NIT = WTM / RPI8, CH = (BM == 128 && BN == 128) ? 2 : (NIT < 4 ? NIT : 4);
                         const int lrow = lane / LPR8, lcol = (lane % LPR8) * 8;
@@ -758,19 +758,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                         }
                         const __bf16* const r16 = reinterpret_cast<const __bf16*>(p.res);
                         __bf16* const y16 = reinterpret_cast<__bf16*>(p.y);
-                        bf16x8 r8[2][CH];
+                        // BatchNorm-backward reduce on bf16 storage (round 5): z is a bf16 [M][N] tensor, the recorded
+                        // ReLU bits one byte per eight outputs; the sums are taken from the fp32 value before it is
+                        // rounded to bf16
+                        const __bf16* const z16 = reinterpret_cast<const __bf16*>(p.bn_z);
+                        const bool use_bits = BNZ && p.bn_bits != nullptr;
+                        const bool use_ms = BNZ && !use_bits && p.bn_mscale != nullptr;
+                        const uint8_t* const bbyte = use_bits ? p.bn_bits : reinterpret_cast<const uint8_t*>(p.bn_z);
+                        f32x4 bmu[2], bis[2], bms[2], bmb[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            bmu[u] = bis[u] = bms[u] = bmb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if constexpr (BNZ) {
+                                bmu[u] = *reinterpret_cast<const f32x4*>(p.bn_mean + n + 4 * u);
+                                bis[u] = *reinterpret_cast<const f32x4*>(p.bn_invstd + n + 4 * u);
+                                if (use_ms) {
+                                    bms[u] = *reinterpret_cast<const f32x4*>(p.bn_mscale + n + 4 * u);
+                                    if (p.bn_mbeta) bmb[u] = *reinterpret_cast<const f32x4*>(p.bn_mbeta + n + 4 * u);
+                                }
+                            }
+                        }
+                        f32x4 ssum8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                        bf16x8 r8[2][CH], z8[2][BNZ ? CH : 1];
+                        uint32_t bb[2][BNZ ? CH : 1];
                         auto request = [&](int c) {
 #pragma unroll
                             for (int k = 0; k < CH; ++k) {
                                 const int m = m0 + wm * WTM + (c * CH + k) * RPI8 + lrow;
-                                r8[c & 1][k] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + n);
+                                if constexpr (HAS_RES) r8[c & 1][k] = *reinterpret_cast<const bf16x8*>(r16 + (int64_t)m * p.ldres + n);
+                                if constexpr (BNZ) {
+                                    z8[c & 1][k] = *reinterpret_cast<const bf16x8*>(z16 + (int64_t)m * p.N + n);
+                                    bb[c & 1][k] = bbyte[((int64_t)m * p.N + n) >> 3];
+                                }
                             }
                         };
-                        if constexpr (HAS_RES) request(0);
+                        if constexpr (HAS_RES || BNZ) request(0);
                         park();
 #pragma unroll
                         for (int c = 0; c < NIT / CH; ++c) {
-                            if constexpr (HAS_RES) { if (c + 1 < NIT / CH) request(c + 1); }
+                            if constexpr (HAS_RES || BNZ) { if (c + 1 < NIT / CH) request(c + 1); }
 #pragma unroll
                             for (int k = 0; k < CH; ++k) {
                                 const int row = wm * WTM + (c * CH + k) * RPI8 + lrow;
@@ -780,16 +806,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                                 for (int u = 0; u < 2; ++u) {
                                     f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + wn * WTN + lcol + 4 * u);
                                     v = v * sc[u] + sh[u];
+                                    f32x4 tv;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
                                         float t = v[e];
                                         if constexpr (HAS_RES) t = t + (float)r8[c & 1][k][4 * u + e];
                                         else t = t + 0.f;
                                         t = relu ? (t > 0.f ? t : 0.f) : t;
-                                        o[4 * u + e] = (__bf16)t;
+                                        tv[e] = t;
                                     }
+                                    if constexpr (BNZ) {
+                                        f32x4 zc;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) zc[e] = (float)z8[c & 1][k][4 * u + e] - bmu[u][e];
+                                        const uint32_t mk = use_bits ? (bb[c & 1][k] >> (4 * u)) : 0xfu;
+                                        const f32x4 tm = zc * bms[u] + bmb[u];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) tv[e] = ((((mk >> e) & 1u) != 0) & (!use_ms | (tm[e] > 0.f))) ? tv[e] : 0.f;
+                                        ssum8[u] += tv; ssq8[u] += tv * (zc * bis[u]);
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[4 * u + e] = (__bf16)tv[e];
                                 }
                                 *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + n) = o;
+                            }
+                        }
+                        if constexpr (BNZ) {
+                            // (the statistics epilogue's reduction: the lanes of a column group, the two wave rows through LDS)
+#pragma unroll
+                            for (int o2 = LPR8; o2 < 64; o2 <<= 1) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        ssum8[u][e] += __shfl_xor(ssum8[u][e], o2);
+                                        ssq8[u][e] += __shfl_xor(ssq8[u][e], o2);
+                                    }
+                            }
+                            __syncthreads();                               // every wave has read its C slab: LDS is free
+                            float* red = smem;                             // [2 wm][2][BN]
+                            if (lrow == 0) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + wn * WTN + lcol + 4 * u) = ssum8[u];
+                                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + wn * WTN + lcol + 4 * u) = ssq8[u];
+                                }
+                            }
+                            __syncthreads();
+                            for (int c = tid; c < BN; c += 256) {
+                                const int nn = n0 + c;
+                                p.stats[((int64_t)tile_m * 2 + 0) * p.N + nn] = red[0 * BN + c] + red[2 * BN + c];
+                                p.stats[((int64_t)tile_m * 2 + 1) * p.N + nn] = red[1 * BN + c] + red[3 * BN + c];
                             }
                         }
                     } else {
@@ -1496,6 +1563,8 @@ int launch_math(const GrlGemm& d, hipStream_t s, int smode) {
     const int vec_epi = (vec_epilogue_ok(d) ? 1 | (smode << 1) : 0) | (panel_on ? 8 : 0);     // (bits 1..2: the statistics' order, choose_tile; bit 3: column-panel tile walk)
     if (MATH == 2 && !(vec_epi & 1))
         return grl_fail(GRL_EINVAL, "gemm bf16s: y/res/scale/shift/gbias must be 16-byte aligned");
+    if (MATH == 2 && d.bn_z && (d.M % BM || d.N % BN))
+        return grl_fail(GRL_EINVAL, "gemm bf16s: bn_z on a %d x %d tile needs M, N multiples of the tile", BM, BN);
     constexpr bool CAN_SEG = MATH == 0;
     const bool seg = CAN_SEG && d.kblock && d.K > SEG_STAGES * BK;
     static const bool dma_conv_on = [] { const char* e = getenv("GRL_GEMM_DMA_CONV"); return !e || atoi(e) != 0; }();
@@ -1568,8 +1637,11 @@ int validate(const GrlGemm& d) {
     }
     if (d.kblock && d.math != GRL_MATH_F32) return grl_fail(GRL_EINVAL, "gemm: kblock needs GRL_MATH_F32");
     if (d.bn_z) {
-        if (d.math == GRL_MATH_BF16S || d.epilogue != GRL_EPI_AFFINE || d.kblock || !d.stats || !d.bn_mean || !d.bn_invstd)
-            return grl_fail(GRL_EINVAL, "gemm: bn_z needs fp32 storage, the AFFINE epilogue, no kblock, stats, bn_mean, bn_invstd");
+        if (d.epilogue != GRL_EPI_AFFINE || d.kblock || !d.stats || !d.bn_mean || !d.bn_invstd)
+            return grl_fail(GRL_EINVAL, "gemm: bn_z needs the AFFINE epilogue, no kblock, stats, bn_mean, bn_invstd");
+        // bf16 storage (round 5): only the branch-free interior epilogue carries the reduce -- every tile must be one
+        if (d.math == GRL_MATH_BF16S && (d.M % 128 || (d.N % 128 && d.N != 64) || d.out_f32 || d.ldy % 8 || (d.res && d.ldres % 8)))
+            return grl_fail(GRL_EINVAL, "gemm bf16s: bn_z needs M %% 128 == 0, N %% 128 == 0 (or N == 64), bf16 output");
         if (d.N % 4 || d.ldy % 4 || (d.res && d.ldres % 4) || ((uintptr_t)d.y & 15) || ((uintptr_t)d.res & 15) ||
             ((uintptr_t)d.bn_z & 15) || ((uintptr_t)d.bn_mean & 15) || ((uintptr_t)d.bn_invstd & 15) ||
             ((uintptr_t)d.bn_mscale & 15) || ((uintptr_t)d.bn_mbeta & 15) || ((uintptr_t)d.bn_bits & 3) ||

@@ -629,6 +629,24 @@ extern "C" int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, c
     return grl_check_launch("grl_bn_bwd_bf16");
 }
 
+// The tail of grl_bn_bwd_bf16 when the data-gradient GEMM that completed the gradient already masked it and left the two
+// column sums in `slab` (GrlGemm.bn_z on bf16 storage, round 5): finalize + apply only.
+extern "C" int grl_bn_bwd_finish_bf16(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                      void* dz, float* dgamma, float* dbeta, const float* slab, int rows, float* coef_ws, int M,
+                                      int C, void* gres, int gres_accumulate, void* stream) {
+    GRL_REQUIRE(g && z && mean && invstd && dz && slab && coef_ws && rows > 0 && M > 0 && C % 8 == 0, "bn_bwd_finish_bf16: bad args");
+    GRL_REQUIRE(al16(g) && al16(z) && al16(dz) && al16(gres), "bn_bwd_finish_bf16: 16-byte aligned tensors");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
+    const int64_t total8 = (int64_t)M * C / 8;
+    // g is masked already: no activation, no mask recomputation; gres == g (the residual adopts the buffer) needs nothing
+    __bf16* const gres2 = gres == g ? nullptr : B16(gres);
+    hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(g), CB16(z), (const __bf16*)nullptr,
+                       mean, invstd, gamma, coef_ws, B16(dz), C, total8, gres2, gres2 ? gres_accumulate : 0, (const float*)nullptr,
+                       (const float*)nullptr, (const uint8_t*)nullptr);
+    return grl_check_launch("grl_bn_bwd_finish_bf16");
+}
+
 extern "C" int grl_relu_bwd_bf16(const void* dy, const void* act, void* out, int64_t n, int accumulate, void* stream) {
     GRL_REQUIRE(dy && out && n > 0 && n % 8 == 0 && al16(dy) && al16(act) && al16(out), "relu_bwd_bf16: bad args");
     hipLaunchKernelGGL(relu_bwd_b16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, CB16(dy), CB16(act),

@@ -189,7 +189,8 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
         rows = lib.grl_conv_gemm_f32_stat_rows(C.byref(d))
         # (bf16 storage: zero-filled -- the 256 x 256 kernel writes two rows per tile, the 128 x 128 family one per
         # 128 rows; whichever takes the launch, rows it does not write must read as zero)
-        slab = (torch.zeros if d.math == MATH_BF16S else torch.empty)((rows, 2, N), dtype=torch.float32, device=y.device)
+        # (... except under a fused BatchNorm-backward reduce: every tile is interior there and writes all of its rows)
+        slab = (torch.zeros if (d.math == MATH_BF16S and bn is None) else torch.empty)((rows, 2, N), dtype=torch.float32, device=y.device)
         d.stats = ptr(slab)
         check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
         if _DEBUG_SYNC:

@@ -439,6 +439,7 @@ class Tape(object):
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
 BN_REDUCE_FUSED = os.environ.get('GRL_BN_REDUCE_FUSED', '1') != '0'     # A/B and tests only
+BN_REDUCE_FUSED_BF16 = os.environ.get('GRL_BN_REDUCE_FUSED_BF16', '1') != '0'   # ... on bf16 storage (round 5)
 PREP_ASYNC = os.environ.get('GRL_PREP_ASYNC', '1') != '0'               # A/B and tests only
 RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B and tests only
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
@@ -602,7 +603,10 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
     _bn_use(tp, x)
     _bn_use(tp, res)
     rec = None
-    if relu and (res is None or bits is not None) and a.dtype != BF16:
+    # (bf16 storage, round 5: the 128-row tile family carries the reduce in its interior epilogue -- every tile of the
+    #  data-gradient GEMM that completes grad(a) must be one: M % 128 == 0, N % 128 == 0 or N == 64)
+    bn16_ok = BN_REDUCE_FUSED_BF16 and M % 128 == 0 and (N % 128 == 0 or N == 64)
+    if relu and (res is None or bits is not None) and (a.dtype != BF16 or bn16_ok):
         rec = _BNRec()
         rec.z, rec.st, rec.bits, rec.from_z, rec.uses, rec.slab = z, st, bits, res is None, 0, None
         tp.bnrec[id(a)] = rec
@@ -625,7 +629,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             # the GEMM that completed grad(a) masked it and left the two column sums (rec.slab): finalize + apply only
             dz = _newl((M, N), da)
             coef = _new((2, N), da)
-            _call('grl_bn_bwd_finish', ptr(da), ptr(z), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(dz),
+            _call(_k('grl_bn_bwd_finish', da), ptr(da), ptr(z), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(dz),
                   ptr(tp.pgrad(bn.weight)), ptr(tp.pgrad(bn.bias)), ptr(rec.slab), rec.slab.shape[0], ptr(coef), M, N,
                   ptr(gres), gacc)
             rec.slab = None
@@ -662,7 +666,7 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     # this data gradient completes grad(x) and x = relu(bn(z') (+res')) of a conv_bn whose consumers are all known: run
     # that BatchNorm's backward reduce in the GEMM epilogue (GrlGemm.bn_z) instead of re-reading the gradient
     rec = tp.bnrec.get(id(x)) if (BN_REDUCE_FUSED and id(x) in tp.fuse_ok) else None
-    fuse = (rec is not None and rec.uses == 1 and stride == 1 and kcols is None and dz.dtype == torch.float32)
+    fuse = (rec is not None and rec.uses == 1 and stride == 1 and kcols is None)
     if rec is not None:
         rec.uses -= 1
     if k == 1:

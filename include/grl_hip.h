@@ -113,13 +113,16 @@ typedef struct GrlGemm {
      * stats[tile][0][n] = sum_rows g, stats[tile][1][n] = sum_rows g * (z - mean) * invstd -- what
      * grl_bn_bwd's reduce pass computes, without re-reading the gradient (grl_bn_bwd_finish does the rest).
      * mask: bn_bits (the forward's recorded (y > 0) bytes, grl_bn_apply_centered) if given, else
-     * ((z - mean) * bn_mscale + bn_mbeta > 0) if bn_mscale is given, else none.  bn_z NULL = off. */
+     * ((z - mean) * bn_mscale + bn_mbeta > 0) if bn_mscale is given, else none.  bn_z NULL = off.
+     * Round 5: GRL_MATH_BF16S too -- bn_z is then a bf16 [M][N] tensor, bn_bits one byte per EIGHT outputs, the sums are
+     * taken from the fp32 value before it is rounded to bf16; needs M % 128 == 0 and N % 128 == 0 (or N == 64): the
+     * reduce lives in the branch-free interior epilogue of the 128-row tile family (grl_bn_bwd_finish_bf16 does the rest). */
     const float*   bn_z;       /* [M][N] (row stride N) */
     const float*   bn_mean;    /* [N] */
     const float*   bn_invstd;  /* [N] */
     const float*   bn_mscale;  /* [N] or NULL */
     const float*   bn_mbeta;   /* [N] or NULL */
-    const uint8_t* bn_bits;    /* [M * N / 4] or NULL */
+    const uint8_t* bn_bits;    /* [M * N / 4] (bf16 storage: [M * N / 8]) or NULL */
 } GrlGemm;
 
 int grl_conv_gemm_f32(const GrlGemm* desc, void* stream);
@@ -341,6 +344,10 @@ int grl_bn_bwd(const float* dy, const float* z, const float* act, const float* m
 int grl_bn_bwd_finish(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma,
                       float* dz, float* dgamma, float* dbeta, const float* slab, int rows, float* coef_ws, int M, int C,
                       float* gres, int gres_accumulate, void* stream);
+/* the bf16-storage twin (g, z, dz, gres bf16; round 5): the tail of grl_bn_bwd_bf16 behind a GrlGemm.bn_z GEMM */
+int grl_bn_bwd_finish_bf16(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                           void* dz, float* dgamma, float* dbeta, const float* slab, int rows, float* coef_ws, int M, int C,
+                           void* gres, int gres_accumulate, void* stream);
 
 /* out (+)= dy * (act > 0)   (ReLU backward; act NULL = plain copy/accumulate) */
 int grl_relu_bwd(const float* dy, const float* act, float* out, int64_t n, int accumulate, void* stream);

@@ -143,6 +143,7 @@ def augment_normalize_u8(clips, params):
 FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
 FUSE_STEM_POOL = os.environ.get('GRL_FUSE_STEM_POOL', '1') != '0'   # A/B and tests: 0 = stem and max-pool as two launches (bf16 storage)
 FUSE_DOWN = os.environ.get('GRL_FUSE_DOWN', '1') != '0'         # A/B and tests: 0 = the downsample conv as its own launch
+SLAB_CHECK = False  # tests only: poison every statistics slab and verify that the GEMM wrote all of it
 SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
 
 
@@ -187,12 +188,18 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
             d.splitk_ws, d.splitk_ws_floats = ptr(ws), need
     if want_stats:
         rows = lib.grl_conv_gemm_f32_stat_rows(C.byref(d))
-        # (bf16 storage: zero-filled -- the 256 x 256 kernel writes two rows per tile, the 128 x 128 family one per
-        # 128 rows; whichever takes the launch, rows it does not write must read as zero)
-        # (... except under a fused BatchNorm-backward reduce: every tile is interior there and writes all of its rows)
-        slab = (torch.zeros if (d.math == MATH_BF16S and bn is None) else torch.empty)((rows, 2, N), dtype=torch.float32, device=y.device)
+        # (`rows` is the row count of the kernel that takes THIS launch -- two per 256-row tile of the bf16 256 x 256 kernel,
+        #  one per tile row of the 128-row family -- and every one of them is written, ragged last tiles included: no fill.
+        #  Rounds 2-4 zero-filled the bf16-storage slabs defensively: 79 fill launches per training step.  SLAB_CHECK
+        #  (tests): poison the slab and verify after the launch that nothing of the poison is left.)
+        slab = torch.empty((rows, 2, N), dtype=torch.float32, device=y.device)
+        if SLAB_CHECK:
+            slab.fill_(float('nan'))
         d.stats = ptr(slab)
         check(lib.grl_conv_gemm_f32(C.byref(d), _lib.stream()), 'grl_conv_gemm_f32')
+        if SLAB_CHECK and bool(torch.isnan(slab).any()):
+            raise AssertionError('statistics slab of gemm %s math %d conv %s: %d of %d rows not written' % (
+                (M, N, K), d.math, conv, int(torch.isnan(slab).any(dim=2).any(dim=1).sum()), rows))
         if _DEBUG_SYNC:
             _debug_sync('gemm+stats %s math %d conv %s' % ((M, N, K), d.math, conv))
         return y, slab

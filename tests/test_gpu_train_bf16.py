@@ -605,3 +605,84 @@ def test_bn_backward_reduce_in_the_gemm_epilogue(golden, math):
         worst = max(worst, e)
         assert e < (1e-3 if math == 'mixed' else 2e-4), (k, e)
     print('fused BN reduce: %d BatchNorms, worst gradient deviation %.1e' % (fused_calls[0], worst))
+
+
+@pytest.mark.gpu
+def test_bn_backward_reduce_in_the_gemm_epilogue_bf16_storage():
+    """Round 5: the fused BatchNorm-backward reduce on bf16 storage (GrlGemm.bn_z with GRL_MATH_BF16S -- the interior
+    epilogue of the 128-row tiles and of gemm_bf16_256_kernel, grl_bn_bwd_finish_bf16) against the separate
+    bn_bwd_reduce pass.  The forward is bit-identical.  The two backward passes are NOT each other's reference: the
+    separate pass sums the gradient after it was rounded to bf16, the epilogue sums the fp32 value before the rounding
+    -- on near-cancelling sums (the bn3 biases: 262144 signed terms, |sum| ~ 2e-3) the rounded terms' noise is the
+    size of the sum itself.  Both are therefore held against the exact-fp32 step of the same inputs: the fused path
+    must be at least as close to it as the separate pass (median and 90th percentile over all parameter tensors), and
+    it must actually be taken."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clip = synth_clips_structured(B, T, seed=97).cuda()
+    g = torch.Generator().manual_seed(8)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs, fused_calls = {}, {}
+    orig = TE._call
+    try:
+        for name, math, fused in (('f32', 'f32', True), ('fused', 'bf16s', True), ('separate', 'bf16s', False)):
+            old = TE.set_math(math)
+            TE.BN_REDUCE_FUSED_BF16 = fused
+            n = [0]
+
+            def spy(fn, *a, _n=n):
+                if fn == 'grl_bn_bwd_finish_bf16':
+                    _n[0] += 1
+                return orig(fn, *a)
+            TE._call = spy
+            try:
+                cnn = _fresh()
+                xu, xc = cnn(clip)
+                ((xu * r1).sum() + (xc * r2).sum()).backward()
+            finally:
+                TE.set_math(old)
+            fused_calls[name] = n[0]
+            outs[name] = ([xu.detach().clone(), xc.detach().clone()],
+                          {k: p.grad.double() for k, p in cnn.named_parameters() if p.grad is not None})
+    finally:
+        TE._call = orig
+        TE.BN_REDUCE_FUSED_BF16 = True
+    torch.cuda.synchronize()
+    assert fused_calls['fused'] >= 30 and fused_calls['separate'] == 0, fused_calls
+    assert all(torch.equal(a, b) for a, b in zip(outs['fused'][0], outs['separate'][0]))
+    ef, es = [], []
+    for k, gt in outs['f32'][1].items():
+        if float(gt.norm()) < 1e-12:
+            continue
+        ef.append(float((outs['fused'][1][k] - gt).norm() / gt.norm()))
+        es.append(float((outs['separate'][1][k] - gt).norm() / gt.norm()))
+    ef.sort(); es.sort()
+    med = lambda v: v[len(v) // 2]
+    p90 = lambda v: v[len(v) * 9 // 10]
+    print('bf16s BN reduce vs the fp32 step: fused median %.2e p90 %.2e max %.2e | separate median %.2e p90 %.2e max %.2e (%d BatchNorms fused)' % (
+        med(ef), p90(ef), ef[-1], med(es), p90(es), es[-1], fused_calls['fused']))
+    assert med(ef) <= 1.05 * med(es) and p90(ef) <= 1.05 * p90(es)
+
+
+@pytest.mark.gpu
+def test_statistics_slabs_are_written_completely():
+    """engine.gemm(stats=True) no longer zero-fills its slab (79 fill launches per bf16-storage training step): with
+    every slab poisoned (engine.SLAB_CHECK) a training forward + backward in both storages must leave no poison --
+    i.e. the row count grl_conv_gemm_f32_stat_rows reports is the row count the kernel that takes the launch writes."""
+    from grl_amd import engine, train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    clip = synth_clips_structured(4, 4, seed=5).cuda()
+    engine.SLAB_CHECK = True
+    try:
+        for math in ('bf16s', 'f32'):
+            old = TE.set_math(math)
+            try:
+                cnn = _fresh()
+                xu, xc = cnn(clip)
+                (xu.sum() + xc.sum()).backward()
+                assert bool(torch.isfinite(xu).all()) and bool(torch.isfinite(xc).all())
+            finally:
+                TE.set_math(old)
+    finally:
+        engine.SLAB_CHECK = False

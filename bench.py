@@ -844,7 +844,7 @@ def main():
         # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
         peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
         traffic, pmc_name = None, None
-        for pmc_name in ('r04_gemm_pmc.json', 'r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
+        for pmc_name in ('r05_gemm_pmc.json', 'r04_gemm_pmc.json', 'r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
             pmc = os.path.join(ROOT, 'profiles', pmc_name)
             if os.path.isfile(pmc):
                 traffic = json.load(open(pmc)).get('hbm_bytes_per_step')

@@ -848,6 +848,7 @@ struct WgradArgs {
     int64_t slab_stride;         // N*K
     int chunk;                   // pixels per split (multiple of 32)
     int conv, H, W, C, Ho, Wo, kh, kw, stride, pad;
+    int tiles_n, tile_mode;      // XCD-aware tile map (wgrad_tile_of)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -869,6 +870,34 @@ __device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) 
 #ifndef GRL_WGRAD_KO
 #define GRL_WGRAD_KO 0      // timing-only knock-outs (1: no in-loop staging, 2: no slab store); wrong results
 #endif
+// XCD-aware tile map of the weight-gradient kernels (round 5).  Workgroups are dealt round-robin over the 8 XCDs by their
+// linear id (b and b + 8 share one L2); with tile_k fastest the 32 tiles an XCD holds of one 16 x 16 pixel-range row were
+// 16 tile_n x 2 tile_k = 18 operand panels through its L2 -- every XCD read ALL of dz.  Here XCD j gets a rectangle of
+// the tile grid, (tiles_n / 2) x (tiles_k / 4) (or / 4 x / 2): 8 x 4 tiles = 12 panels.  Which tile a workgroup computes
+// does not enter any sum: bit-identical.  `mode` 0: the plain map (gridDim.x not a multiple of 8, odd tile counts, or
+// GRL_WGRAD_XCD=0).
+__device__ __forceinline__ void wgrad_tile_of(int bid, int tiles_n, int tiles_k, int mode, int& tile_n, int& tile_k) {
+    if (mode == 0) {
+        tile_n = bid / tiles_k;
+        tile_k = bid - tile_n * tiles_k;
+        return;
+    }
+    const int gn = mode == 1 ? 2 : 4, gk = 8 / gn;             // XCD regions along n and k
+    const int rn = tiles_n / gn, rk = tiles_k / gk;            // tiles per region
+    const int xcd = bid & 7, slot = bid >> 3;                  // slot: 0 .. rn * rk - 1
+    const int xn = xcd / gk, xk = xcd - xn * gk;
+    const int sn = slot / rk, sk = slot - sn * rk;
+    tile_n = xn * rn + sn;
+    tile_k = xk * rk + sk;
+}
+static int wgrad_tile_mode(int tiles_n, int tiles_k) {
+    static const bool on = [] { const char* e = getenv("GRL_WGRAD_XCD"); return !e || atoi(e) != 0; }();
+    if (!on || tiles_n * tiles_k < 64) return 0;
+    // the squarer rectangle first: regions of (tiles_n / gn) x (tiles_k / gk) tiles
+    const bool m1 = tiles_n % 2 == 0 && tiles_k % 4 == 0, m2 = tiles_n % 4 == 0 && tiles_k % 2 == 0;
+    if (m1 && m2) return (tiles_n / 2 + tiles_k / 4) <= (tiles_n / 4 + tiles_k / 2) ? 1 : 2;
+    return m1 ? 1 : m2 ? 2 : 0;
+}
 template <int BM, int BN, bool CONV, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const int tiles_k) {
     static_assert(MATH == 0 || (BM == 128 && BN == 128), "the bf16 datapaths are written for 128 x 128 tiles");
@@ -878,7 +907,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p, const 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][32][BM]
     float* Bs = smem + 2 * 32 * BM;        // [2][32][BN]
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    int tile_n, tile_k;
+    wgrad_tile_of((int)blockIdx.x, p.tiles_n, tiles_k, p.tile_mode, tile_n, tile_k);
     const int n0 = tile_n * BM, k0 = tile_k * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -1296,7 +1326,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16in_kernel(const WgradArgs p, 
     char* const sm8 = reinterpret_cast<char*>(smem);      // [2 buf][A plane, B plane]
     const __bf16* const dzp = reinterpret_cast<const __bf16*>(p.dz);
     const __bf16* const xp = reinterpret_cast<const __bf16*>(p.x);
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    int tile_n, tile_k;
+    wgrad_tile_of((int)blockIdx.x, p.tiles_n, tiles_k, p.tile_mode, tile_n, tile_k);
     const int n0 = tile_n * BM, k0 = tile_k * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -1457,7 +1488,8 @@ __global__ __launch_bounds__(512) void wgrad_b16in_256_kernel(const WgradArgs p,
     char* const sm8 = reinterpret_cast<char*>(smem);
     const char* const dz8 = reinterpret_cast<const char*>(p.dz);
     const char* const x8 = reinterpret_cast<const char*>(p.x);
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    int tile_n, tile_k;
+    wgrad_tile_of((int)blockIdx.x, p.tiles_n, tiles_k, p.tile_mode, tile_n, tile_k);
     const int n0 = tile_n * TBW, k0 = tile_k * TBW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1950,6 +1982,8 @@ extern "C" int grl_conv_wgrad_f32(const GrlWgrad* desc, void* stream) {
     a.kh = d.kh; a.kw = d.kw; a.stride = d.stride; a.pad = d.pad;
     const int real_splits = (d.M + a.chunk - 1) / a.chunk;
     const int tiles_n = (d.N + bm - 1) / bm, tiles_k = (d.K + bn - 1) / bn;
+    a.tiles_n = tiles_n;
+    a.tile_mode = wgrad_tile_mode(tiles_n, tiles_k);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)2 * 32 * (bm + bn) * sizeof(float);
     dim3 grid(tiles_n * tiles_k, real_splits);

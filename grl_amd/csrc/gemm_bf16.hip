@@ -33,6 +33,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -270,7 +271,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                     for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
                 }
             }
-            const bool relu = p.relu != 0;
+            const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+            __bf16* yrow = SQD ? nullptr : y16 + (int64_t)(cm0 + lrow) * p.ldy + cn;
+            const int64_t ystep = (int64_t)8 * p.ldy;
             f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             // (BNZ: one block of rows in flight instead of two -- the z rows and the per-channel vectors need the registers)
             constexpr int NB = BNZ ? 1 : 2;
@@ -289,14 +292,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                     }
                 }
             }
+            // (row pointers are CARRIED -- + 8 rows per step -- instead of recomputed: a 64-bit multiply-add and two shift-adds
+            //  per load and store were a tenth of the epilogue's instructions)
+            const __bf16* rrow = RES && !SQD ? r16 + (int64_t)(cm0 + lrow) * p.ldres + cn : nullptr;
+            const int64_t rstep = (int64_t)8 * p.ldres;
             auto res_request = [&](int i) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = cm0 + i * 32 + it * 8 + lrow;
-                    int64_t rr = m;
-                    if constexpr (SQD) rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
                     if constexpr (RES) {
-                        if (INT || (m < p.M && n_ok)) res8[i % NB][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                        if constexpr (SQD) {
+                            const int64_t rr = (int64_t)(m / p.res_rows) * p.res_gstride + (m % p.res_rows);
+                            if (INT || (m < p.M && n_ok)) res8[i % NB][it] = *reinterpret_cast<const bf16x8*>(r16 + rr * p.ldres + cn);
+                        } else {
+                            if (INT || (m < p.M && n_ok)) res8[i % NB][it] = *reinterpret_cast<const bf16x8*>(rrow);
+                            rrow += rstep;
+                        }
                     }
                     if constexpr (BNZ != 0) {
                         z8[0][it] = *reinterpret_cast<const bf16x8*>(z16 + (int64_t)m * p.N + cn);
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                     const int row = it * 8 + lrow;
                     const int m = cm0 + i * 32 + row;
                     if (INT || (m < p.M && n_ok)) {
-                        bf16x8 o;
+                        f32x4 ov[2];
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ((lcol + 4 * u) ^ (((row >> 1) & 1) << 2)));
@@ -370,8 +381,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                                 float tt = v[e];
                                 if constexpr (RES) tt = tt + (float)res8[i % NB][it][4 * u + e];
                                 else tt = tt + 0.f;
-                                tt = relu ? (tt > 0.f ? tt : 0.f) : tt;
-                                tv[e] = tt;
+                                // ReLU as ONE v_max against 0 / -inf (was v_cmp + v_cndmask + s_or per element; v_max_f32
+                                // orders -0 < +0, so max(t, +0) == (t > 0 ? t : 0) bit for bit)
+                                tv[e] = __builtin_fmaxf(tt, relu_floor);
                             }
                             if constexpr (BNZ != 0) {
                                 f32x4 zc;
@@ -388,11 +400,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                                 }
                                 ssum[u] += tv; ssq[u] += tv * (zc * bis[u]);
                             }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[4 * u + e] = (__bf16)tv[e];
+                            ov[u] = tv;
                         }
-                        *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                        // (one v_cvt_pk_bf16_f32 per pair: element-wise casts gave a convert and a v_perm per value)
+                        const f32x8 o32 = {ov[0][0], ov[0][1], ov[0][2], ov[0][3], ov[1][0], ov[1][1], ov[1][2], ov[1][3]};
+                        *reinterpret_cast<bf16x8*>(yrow) = __builtin_convertvector(o32, bf16x8);
                     }
+                    yrow += ystep;
                 }
             }
             if constexpr (STATS) {

@@ -40,6 +40,7 @@ namespace ring {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef GRL_RING_SCHED
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                     for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(shift + cn + 4 * u);
                 }
             }
-            const bool relu = p.relu != 0;
+            const float relu_floor = p.relu ? 0.f : -__builtin_inff();
             // residual rows: two 32-row blocks (8 x 1 KiB per wave) in flight -- block i+1 is requested before block i
             // goes through the slab
             bf16x8 res8[2][4];
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                             }
                         } else {
                             if (INT || (m < p.M && n_ok)) {
-                                bf16x8 o;
+                                f32x8 o32;
 #pragma unroll
                                 for (int u = 0; u < 2; ++u) {
                                     f32x4 w_ = v[u];
@@ -514,11 +515,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                                         float tt = w_[e];
                                         if constexpr (RES) tt = tt + (float)res8[i & 1][it][4 * u + e];
                                         else tt = tt + 0.f;
-                                        tt = relu ? (tt > 0.f ? tt : 0.f) : tt;
-                                        o[4 * u + e] = (__bf16)tt;
+                                        o32[4 * u + e] = __builtin_fmaxf(tt, relu_floor);   // (ReLU: one v_max against 0 / -inf)
                                     }
                                 }
-                                *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = o;
+                                *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = __builtin_convertvector(o32, bf16x8);
                             }
                         }
                     }

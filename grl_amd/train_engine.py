@@ -536,11 +536,13 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
-def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False, bits=None):
+def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False, bits=None,
+                out=None):
     """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
     same pass that writes dz).  ``mask_from_z``: y = relu(bn(z)) without a residual -- the ReLU mask is recomputed
-    from z with the forward's own operations (st.scale, st.beta) instead of reading the activation."""
-    dz = _newl((M, Cc), dy)
+    from z with the forward's own operations (st.scale, st.beta) instead of reading the activation.  ``out``: where dz
+    goes (a row block of a _WgradStack) instead of a fresh buffer."""
+    dz = _newl((M, Cc), dy) if out is None else out
     rows = _lib.load().grl_col_stats_rows(M)
     slab = _new((rows, 2, Cc), dy)
     coef = _new((2, Cc), dy)
@@ -553,6 +555,39 @@ def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc
 # ----------------------------------------------------------------------------
 # ops (forward now, backward closure on the tape)
 # ----------------------------------------------------------------------------
+class _WgradStack(object):
+    """Weight-gradient operands of a layer that one step applies ``steps`` times with the SAME weights (the TRL
+    recurrences, grl_model.py:186-205): step i's input and its output gradient are row block i of two buffers, and dW
+    is ONE product over all steps * M rows -- issued by the backward closure that fills the last block -- instead of
+    ``steps`` products over M = B * 128 rows each (at 32 clips a quarter of the pixel range the weight-gradient kernels
+    reach their rate on: 4096 x 2048 x 512 ran at 100 TFLOP/s, 16384 x 2048 x 512 runs at 123) and ``steps`` slab
+    reductions.  ``extra``: input blocks past the last step (the recurrence's final output lives in the same buffer)."""
+
+    def __init__(self, steps, rows_in, K, like, extra=0):
+        self.steps, self.rows_in = steps, rows_in
+        self.x = _newl(((steps + extra) * rows_in, K), like)
+        self.dz, self.left = None, steps
+
+    def x_block(self, i):
+        return self.x[i * self.rows_in:(i + 1) * self.rows_in]
+
+    def dz_block(self, i, M, N, like):
+        if self.dz is None:
+            self.dz = _newl((self.steps * M, N), like)
+        return self.dz[i * M:(i + 1) * M]
+
+    def filled(self):
+        """One more block of dz is written; True when that was the last one."""
+        self.left -= 1
+        return self.left == 0
+
+    def inputs(self):
+        return self.x[:self.steps * self.rows_in]
+
+
+WGRAD_STACK = os.environ.get('GRL_WGRAD_STACK', '1') != '0'             # A/B and tests only
+
+
 class _BNRec(object):
     """What the data-gradient GEMM that completes grad(a), a = relu?(bn(z) (+res)), needs to run that BatchNorm's
     backward reduce in its epilogue (GrlGemm.bn_z): ``uses`` counts the contributions still to come."""
@@ -570,10 +605,12 @@ def _bn_use(tp, t, n=1):
     return r
 
 
-def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kcols=None, ldw=None):
+def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kcols=None, ldw=None, out=None, wstack=None):
     """Conv (1x1 / 3x3, stride 1 / 2) + train-mode BN (+residual) (+ReLU).
     x: channels-last [n_img*H*W][cin].  ``kcols``/``ldw``: use only the first kcols input
-    channels of a wider 1x1 weight (GCE split weight)."""
+    channels of a wider 1x1 weight (GCE split weight).  ``out``: the activation's buffer (a block of the NEXT layer's
+    _WgradStack); ``wstack`` = (stack, i): x IS block i of the stack and this layer's dz goes to the stack's block i --
+    the weight gradient is one product over the whole stack."""
     w = conv.weight
     N, k = w.shape[0], (w.shape[2] if w.dim() == 4 else 1)
     stride = conv.stride[0] if hasattr(conv, 'stride') else 1
@@ -591,7 +628,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
     _, slab = gemm(x, wf, z, M, N, K, ldw=ldw or wf.shape[1], gbias=gbias, rows_per_group=rpg,
                    stats=True, conv=geom)
     st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
-    a = _newl((M, N), x)
+    a = _newl((M, N), x) if out is None else out
     # y = relu(bn(z) + res): the backward needs the mask (y > 0); recorded as one bit per output here, it is read
     # back instead of the whole activation (1/16 of the bytes of the widest BatchNorms of the step)
     bits = None
@@ -614,6 +651,11 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
     def bwd():
         da = tp.take(a)
         if da is None:
+            if wstack is not None:          # no gradient reaches this step: its block of the stacked product is zero
+                wstack[0].dz_block(wstack[1], M, N, a).zero_()
+                if wstack[0].filled():
+                    wgrad_async(tp, wstack[0].dz, wstack[0].inputs(), tp.pgrad(conv.weight), wstack[0].steps * M, N, K,
+                                conv=geom)
             return
         act = a if relu else None
         gres, gacc = None, 0
@@ -627,7 +669,7 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             _bn_use(tp, res, -1)
         if rec is not None and rec.slab is not None:
             # the GEMM that completed grad(a) masked it and left the two column sums (rec.slab): finalize + apply only
-            dz = _newl((M, N), da)
+            dz = _newl((M, N), da) if wstack is None else wstack[0].dz_block(wstack[1], M, N, da)
             coef = _new((2, N), da)
             _call(_k('grl_bn_bwd_finish', da), ptr(da), ptr(z), ptr(st.mean), ptr(st.invstd), ptr(bn.weight), ptr(dz),
                   ptr(tp.pgrad(bn.weight)), ptr(tp.pgrad(bn.bias)), ptr(rec.slab), rec.slab.shape[0], ptr(coef), M, N,
@@ -635,9 +677,10 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             rec.slab = None
         else:
             dz = bn_backward(da, z, act, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), M, N,
-                             gres=gres, gres_acc=gacc, mask_from_z=relu and res is None, bits=bits)
+                             gres=gres, gres_acc=gacc, mask_from_z=relu and res is None, bits=bits,
+                             out=None if wstack is None else wstack[0].dz_block(wstack[1], M, N, da))
         conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
-                                   kcols=kcols, ldw=ldw)
+                                   kcols=kcols, ldw=ldw, wstack=wstack)
         if gbias is not None:
             tp.g[('gbias', id(z))] = dz          # the caller's closure reduces it per clip
     tp.ops.append(bwd)
@@ -645,12 +688,16 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
 
 
 def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, stride, geom,
-                               kcols=None, ldw=None):
+                               kcols=None, ldw=None, wstack=None):
     """dW += dz^T . X (gathered), dx = dz . W (data gradient)."""
     w = conv.weight
     M = n_img * Ho * Wo
     K = k * k * cin
-    if kcols is None:
+    if wstack is not None:
+        stk = wstack[0]                     # (images are independent: the stacked steps are just more of them)
+        if stk.filled():
+            wgrad_async(tp, stk.dz, stk.inputs(), tp.pgrad(w), stk.steps * M, N, K, conv=geom)
+    elif kcols is None:
         wgrad_async(tp, dz, x, tp.pgrad(w), M, N, K, conv=geom)
     else:                                   # first kcols columns of a wider weight
         tmp = torch.empty(N, kcols, dtype=torch.float32, device=tp.dev)
@@ -709,22 +756,35 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
         tp.g[id(x)] = dx
 
 
-def biased_conv_relu(tp, x, M, conv):
-    """1x1 conv with bias + ReLU (TRL f1/f2, grl_model.py:95-121)."""
+def biased_conv_relu(tp, x, M, conv, wstack=None):
+    """1x1 conv with bias + ReLU (TRL f1/f2, grl_model.py:95-121).  ``wstack`` = (stack, i): as in conv_bn (the bias
+    gradient is one column sum over the whole stack too)."""
     w = conv.weight
     N, K = w.shape[0], w.shape[1]
     w2d = w.detach().view(N, K)
     a = _newl((M, N), x)
     gemm(x, tp.w16(w2d, w), a, M, N, K, shift=conv.bias.detach(), relu=True)
 
+    def stack_done():
+        stk = wstack[0]
+        if stk.filled():
+            colsum_into(stk.dz, stk.steps * M, N, tp.pgrad(conv.bias))
+            wgrad_async(tp, stk.dz, stk.inputs(), tp.pgrad(w), stk.steps * M, N, K)
+
     def bwd():
         da = tp.take(a)
         if da is None:
+            if wstack is not None:          # no gradient reaches this step: its block of the stacked product is zero
+                wstack[0].dz_block(wstack[1], M, N, a).zero_()
+                stack_done()
             return
-        g = _newl((M, N), da)
+        g = _newl((M, N), da) if wstack is None else wstack[0].dz_block(wstack[1], M, N, da)
         _call(_k('grl_relu_bwd', da), ptr(da), ptr(a), ptr(g), da.numel(), 0)
-        colsum_into(g, M, N, tp.pgrad(conv.bias))
-        wgrad_async(tp, g, x, tp.pgrad(w), M, N, K)
+        if wstack is None:
+            colsum_into(g, M, N, tp.pgrad(conv.bias))
+            wgrad_async(tp, g, x, tp.pgrad(w), M, N, K)
+        else:
+            stack_done()
         cur = tp.g.get(id(x))
         if cur is not None and tuple(cur.shape) != (M, K):
             cur = cur.view(M, K)
@@ -1006,19 +1066,22 @@ def trl_train(tp, model, xu, xc, b, t):
             (trl.backward_f1, trl.backward_f2, trl.channel_atte_backward_corr, trl.uncorr_memo_backward))
     tp.mark('trl')
     fk = engine._TrlFork(tp.dev, tp.taps is None)
-    memo0 = _newl((Mb, Cc), xu)
-    _call(_k('grl_temporal_mean', xu), ptr(xu), ptr(memo0), b, t, frame)
     # per-direction aliases: same storage, their own gradient slots on the tape
     xu_d = (xu, xu.view_as(xu)) if fk.two else (xu, xu)
-    memo_d = (memo0, memo0.view_as(memo0)) if fk.two else (memo0, memo0)
+    memo_d = []             # the initial memo, one copy per direction (filled below: block 0 of the direction's f1 stack)
 
     def bwd_memo0():
         if fk.two:
-            for al, base in ((xu_d[1], xu), (memo_d[1], memo0)):
-                g1 = tp.take(al)
-                if g1 is not None:
-                    tp.add_grad(base, g1)
-        dm = tp.take(memo0)
+            g1 = tp.take(xu_d[1])
+            if g1 is not None:
+                tp.add_grad(xu, g1)
+        dm = None
+        for m0 in memo_d:
+            g1 = tp.take(m0)
+            if g1 is not None and dm is not None:
+                _call(_k('grl_axpby', dm), ptr(dm), ptr(g1), ptr(dm), C.c_float(1.0), C.c_float(1.0), dm.numel())
+            elif g1 is not None:
+                dm = g1
         if dm is None:
             return
         g = tp.full_grad(xu)
@@ -1041,16 +1104,29 @@ def trl_train(tp, model, xu, xc, b, t):
     tp.ops.append(bwd_join)
     fk.fork()
     fc = []
-    for di in range(2):
+    # Each direction applies f1 and its bottleneck t times with the same weights: the operands of their weight gradients
+    # are stacked step by step (_WgradStack) and every layer gets ONE product over t * Mb rows.  stk[di] = stacks of
+    # (f1, conv1, conv2, conv3); f1's input stack is the memo sequence memo_0 .. memo_t (t + 1 blocks).
+    stk = []
+    for di, (_, _, _, blk) in enumerate(dirs):
         with fk.on(di):
             fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=tp.dev) if (fk.two or di == 0) else fc[0])
+            if WGRAD_STACK:
+                stk.append((_WgradStack(t, Mb, Cc, xu, extra=1), _WgradStack(t, Mb, Cc, xu),
+                            _WgradStack(t, Mb, blk.conv2.weight.shape[1], xu), _WgradStack(t, Mb, blk.conv3.weight.shape[1], xu)))
+                memo_d.append(stk[di][0].x_block(0))
+            else:
+                stk.append(None)
+                memo_d.append(_newl((Mb, Cc), xu))
+            _call(_k('grl_temporal_mean', xu), ptr(xu), ptr(memo_d[di]), b, t, frame)
     memo = list(memo_d)
     for i in range(t):
         for di, (f1m, _, mlp, blk) in enumerate(dirs):
             with fk.on(di):
                 tp.side = fk.side if (fk.two and di == 1) else None
                 ti = i if di == 0 else t - 1 - i
-                f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0])
+                sk = stk[di]
+                f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0], wstack=(sk[0], i) if sk else None)
                 dvec = _new((b, Cc), xu)
                 f2t = f2[di]
                 _call(_k('grl_sqdiff_mean', f1), ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
@@ -1089,7 +1165,7 @@ def trl_train(tp, model, xu, xc, b, t):
                 if tp.taps is not None:
                     tp.taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte)
 
-                s = _newl((Mb, Cc), xu)
+                s = sk[1].x_block(i) if sk else _newl((Mb, Cc), xu)
                 _call(_k('grl_add_strided', xu), ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
                 prev = memo[di]
 
@@ -1100,9 +1176,15 @@ def trl_train(tp, model, xu, xc, b, t):
                     _axpy_frame(tp.full_grad(xu_al), ti, dsum, b, t, frame)
                     tp.add_grad(prev, dsum)
                 tp.ops.append(bwd_add)
-                o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
-                o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
-                memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
+                if sk:
+                    o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True, out=sk[2].x_block(i), wstack=(sk[1], i))
+                    o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True, out=sk[3].x_block(i), wstack=(sk[2], i))
+                    memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s, out=sk[0].x_block(i + 1),
+                                                wstack=(sk[3], i))
+                else:
+                    o, _, _, _ = conv_bn(tp, s, b, 16, 8, blk.conv1, blk.bn1, True)
+                    o2, _, _, _ = conv_bn(tp, o, b, 16, 8, blk.conv2, blk.bn2, True)
+                    memo[di], _, _, _ = conv_bn(tp, o2, b, 16, 8, blk.conv3, blk.bn3, True, res=s)
                 tp.fuse_ok.update((id(o), id(o2)))       # single conv_bn consumers: fused BatchNorm-backward reduce
                 tp.side = None
     mf, mb_ = memo

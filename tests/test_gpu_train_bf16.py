@@ -686,3 +686,56 @@ def test_statistics_slabs_are_written_completely():
                 TE.set_math(old)
     finally:
         engine.SLAB_CHECK = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math,only_corr", [("f32", False), ("f32", True), ("bf16s", False)])
+def test_trl_stacked_weight_gradients_equal_per_step_products(golden, math, only_corr):
+    """train_engine.WGRAD_STACK (round 5): the TRL recurrences apply f1 and their bottleneck T times with the same weights;
+    the operands of the T weight gradients are row blocks of one buffer and dW is one product over T * B * 128 rows.  Same
+    sums in another order: the forward and every activation gradient are bit-identical (the stacks only move buffers),
+    the parameter gradients agree to 2e-4 relative L2 (fp32 accumulation, bf16s too) -- and 24 + 24 launches of the
+    weight-gradient kernels and their slab reductions become 6 + 6.  ``only_corr``: only f_corr carries a gradient, so the
+    LAST step's bottleneck of each direction gets none -- its block of the stack must count as zeros, not stall the product."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    B, T = 4, 4
+    clip = synth_clips_structured(B, T, seed=99).cuda()
+    g = torch.Generator().manual_seed(9)
+    r1, r2 = torch.randn(B, 2048, generator=g).cuda(), torch.randn(B, T, 2048, generator=g).cuda()
+    outs, launches = [], []
+    old = TE.set_math(math)
+    orig = TE.wgrad
+    try:
+        for stacked in (True, False):
+            TE.WGRAD_STACK = stacked
+            n = [0]
+
+            def spy(*a, _n=n, **kw):
+                _n[0] += 1
+                return orig(*a, **kw)
+            TE.wgrad = spy
+            cnn = _fresh()
+            xu, xc = cnn(clip)
+            ((xc * r2).sum() if only_corr else (xu * r1).sum() + (xc * r2).sum()).backward()
+            launches.append(n[0])
+            outs.append(([xu.detach().clone(), xc.detach().clone()],
+                         {k: p.grad.clone() for k, p in cnn.named_parameters() if p.grad is not None}))
+    finally:
+        TE.wgrad = orig
+        TE.WGRAD_STACK = True
+        TE.set_math(old)
+    torch.cuda.synchronize()
+    assert launches[1] - launches[0] == 2 * 4 * (T - 1), launches
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    live = [str(k) for k in golden('grl_train_cond_b8t4.npz')['meta.keys']]
+    worst = 0.0
+    for k in live:
+        ga, gb = outs[0][1][k], outs[1][1][k]
+        if 'temporal_learning_block' not in k:
+            assert torch.equal(ga, gb), k            # (everything upstream of the TRL sees the same activation gradients)
+            continue
+        e = float((ga.double() - gb.double()).norm() / gb.double().norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+    print('stacked TRL weight gradients: %d -> %d launches, worst deviation %.1e' % (launches[1], launches[0], worst))

@@ -545,6 +545,180 @@ __global__ __launch_bounds__(256) void stem_pool_b16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Stem + max-pool, second form (round 5): no im2col tile, no weight reads, no fp32 staging.  The product is formed as
+// D[channel][pixel] = W . patch^T: the 64 x 176 weight image lives in REGISTERS as the A fragments of
+// v_mfma_f32_32x32x16_bf16 (2 channel blocks x 11 k-steps, loaded once per wave), and the B fragment of a k-step -- a
+// pixel's eight kx taps of one (channel, ky) -- is eight consecutive bf16 of the staged input row, read straight from the
+// patch (two ds_read2_b32; 4-byte aligned because a stem pixel is two input pixels).  In that orientation a lane holds
+// four CONSECUTIVE channels of one pixel per accumulator quad: folded BatchNorm + ReLU run in registers and the row goes
+// to LDS as bf16 [pixel][channel] (8-byte writes, 16-byte chunks XOR-swizzled by the pixel pair), from where the pooling
+// threads read 3 x 3 windows as 16-byte vectors and take the maximum with v_pk_max_u16 (post-ReLU bf16 values are
+// non-negative: their bit patterns order like unsigned integers; rounding commutes with max).  One iteration = 4 stem rows
+// (wave w: row w, both 32-column halves) = 2 pooled rows, two barriers; the input rows live in a 16-row ring per channel
+// and the next iteration's 8 new rows are requested before the MFMAs and written to the ring after them.  Same k order
+// and the same products as stem_pool_b16_kernel: bit-identical (tested).  512 frames: 414 -> ~150 us.
+constexpr int S2_ROWB = SP_PWP * 2;                   // 268 bytes: one input row, columns -3 .. 130 as bf16
+constexpr int S2_RING = 16;                           // input-row slots per channel (13 live + 8 incoming - 5 shared)
+constexpr int S2_CHB = (S2_RING + 1) * S2_ROWB;       // bytes per channel (+ one row: slot 16 of channel 0 stays zero)
+constexpr int S2_PATCHB = (3 * S2_CHB + 15) / 16 * 16;
+constexpr int S2_ROWBUF = SP_TW * 128;                // one stem row as bf16 [64 px][64 ch]
+constexpr int S2_LDS = 5 * S2_ROWBUF + S2_PATCHB + 512;       // + folded BatchNorm scale / shift (64 floats each)
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_s2 __attribute__((ext_vector_type(4)));
+typedef float f32x2_s2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ y,
+    int H, const __bf16* __restrict__ wp, const float* __restrict__ norm, int strip_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    char* const rowbuf = smb;                                  // [5][64][128 B]
+    char* const patch = smb + 5 * S2_ROWBUF;                   // [3][17][268 B]
+    float* const scs = reinterpret_cast<float*>(smb + 5 * S2_ROWBUF + S2_PATCHB);     // scale[64], shift[64]
+    constexpr int W = 2 * SP_TW;
+    const int Ho = H >> 1, Hp = Ho >> 1, Wp = SP_TW / 2;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pxl = lane & 31, hf = lane >> 5;
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
+    // Input rows are addressed by ry = iy + 3 >= 0 (stem row oy, tap ky: ry = 2 oy + ky); ring slot = ry & 15.  A wave
+    // stages whole rows: lane l loads the input pixels 2 l, 2 l + 1 (one 8-byte load; the loads are unconditional -- a row
+    // outside the image reads row 0 and is zeroed by a select -- so hipcc can count them) and writes two bf16 cells at
+    // columns 2 l + 3, 2 l + 4; the six pad cells of a row are zeroed once and never written again.
+    auto load_row = [&](int c, int ry, auto u8_) {
+        constexpr bool U8 = decltype(u8_)::value;
+        const int iy = ry - 3;
+        const bool ok = (unsigned)iy < (unsigned)H;
+        const int64_t o = ((int64_t)c * H + (ok ? iy : 0)) * W + 2 * lane;
+        f32x2_s2 v;
+        if constexpr (U8) {
+            const unsigned short u = *reinterpret_cast<const unsigned short*>(xu + o);
+            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
+            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+        } else {
+            v = *reinterpret_cast<const f32x2_s2*>(xi + o);
+        }
+        const f32x2_s2 z = {0.f, 0.f};
+        return ok ? v : z;
+    };
+    auto store_row = [&](int c, int ry, const f32x2_s2 v) {
+        __bf16* const d = reinterpret_cast<__bf16*>(patch + c * S2_CHB + (ry & (S2_RING - 1)) * S2_ROWB) + 2 * lane + 3;
+        d[0] = (__bf16)v[0];
+        d[1] = (__bf16)v[1];
+    };
+    const int strip0 = blockIdx.x * strip_rows;                 // first stem row whose pooled rows this workgroup emits
+    int oyb = strip0 > 0 ? strip0 - 4 : 0;                      // (one warm-up iteration above the strip fills the carry row)
+    const int oy_end = min(Ho, strip0 + strip_rows);
+    // prologue: zero patch (pads, the zero row) and carry; then the 13 input rows of the first iteration
+    for (int i = tid; i < S2_PATCHB / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < S2_ROWBUF / 16; i += 256) reinterpret_cast<uint4*>(rowbuf + 4 * S2_ROWBUF)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 128) scs[tid] = tid < 64 ? scale[tid] : shift[tid - 64];      // (read back as broadcast 16-byte vectors: 64 VGPRs otherwise)
+    __syncthreads();
+    for (int rr = wave; rr < 3 * 13; rr += 4) {
+        const int c = rr / 13, r = rr - 13 * c;
+        if (norm) store_row(c, 2 * oyb + r, load_row(c, 2 * oyb + r, std::true_type{}));
+        else store_row(c, 2 * oyb + r, load_row(c, 2 * oyb + r, std::false_type{}));
+    }
+    // weights: A fragments (lane: channel 32 j + pxl, k chunk 2 s + hf) of the packed image [64][368 B]
+    bf16x8 wf[2][SB_CH / 2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < SB_CH / 2; ++s)
+            wf[j][s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(wp) + (32 * j + pxl) * SB_ROWB + (2 * s + hf) * 16);
+    constexpr int P_IT = 6;                                     // rows per wave of the 3 x 8 new input rows of an iteration
+    f32x2_s2 pv[P_IT];
+    const int c8 = tid & 7, ppx = tid >> 3;                     // pooling: this thread's pooled column and 8 channels
+    __syncthreads();
+    for (int it = 0; oyb < oy_end; oyb += 4, ++it) {
+        const bool more = oyb + 4 < oy_end;
+        if (more) {
+            auto pre = [&](auto u8_) {
+#pragma unroll
+                for (int k = 0; k < P_IT; ++k) {
+                    const int rr = wave + 4 * k;               // (channel rr >> 3, new row rr & 7)
+                    pv[k] = load_row(rr >> 3, 2 * oyb + 13 + (rr & 7), u8_);
+                }
+            };
+            if (norm) pre(std::true_type{});
+            else pre(std::false_type{});
+        }
+        // row slots of this iteration: rows 0..2 -> slots 0..2, row 3 -> slot 3 (even) / 4 (odd); the carry (previous
+        // iteration's row 3) is the other one of 3 / 4
+        const int slot3 = 3 + (it & 1), carry = 4 - (it & 1);
+        const int oy = oyb + wave;
+        const int myslot = wave < 3 ? wave : slot3;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int px = 32 * cb + pxl;
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < SB_CH / 2; ++s) {
+                const int ch0 = 2 * s, ch1 = 2 * s + 1;
+                const int off0 = (ch0 / 7) * S2_CHB + ((2 * oy + ch0 % 7) & (S2_RING - 1)) * S2_ROWB;
+                const int off1 = ch1 < 21 ? (ch1 / 7) * S2_CHB + ((2 * oy + ch1 % 7) & (S2_RING - 1)) * S2_ROWB : S2_RING * S2_ROWB;
+                const uint32_t* s2 = reinterpret_cast<const uint32_t*>(patch + (hf ? off1 : off0) + 4 * px);
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = s2[e];
+                const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s], b, acc[j], 0, 0, 0);
+            }
+            char* const dst = rowbuf + myslot * S2_ROWBUF + px * 128 + 8 * hf;
+            const int sw = (px >> 1) & 7;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // (this lane's channels 32 j + 8 q + 4 hf + (0..3))
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scs + 32 * j + 8 * q + 4 * hf);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(scs + 64 + 32 * j + 8 * q + 4 * hf);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tv = acc[j][4 * q + e] * sc[e] + sh[e];
+                        v[e] = tv > 0.f ? tv : 0.f;
+                    }
+                    *reinterpret_cast<bf16x4_s2*>(dst + (((4 * j + q) ^ sw) << 4)) = __builtin_convertvector(v, bf16x4_s2);
+                }
+        }
+        __syncthreads();                                       // the four stem rows are in rowbuf; nobody reads the patch any more
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < P_IT; ++k) {
+                const int rr = wave + 4 * k;
+                store_row(rr >> 3, 2 * oyb + 13 + (rr & 7), pv[k]);
+            }
+        }
+        // two pooled rows: (carry, row 0, row 1) and (row 1, row 2, row 3) x stem columns 2 ppx - 1 .. 2 ppx + 1
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            u16x8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int slot = pr == 0 ? (rr == 0 ? carry : rr - 1) : (rr == 2 ? slot3 : rr + 1);
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int cx = 2 * ppx + dx;
+                    if (cx >= 0) {
+                        const u16x8 v = *reinterpret_cast<const u16x8*>(rowbuf + slot * S2_ROWBUF + cx * 128 + ((c8 ^ ((cx >> 1) & 7)) << 4));
+                        mx = __builtin_elementwise_max(mx, v);
+                    }
+                }
+            }
+            if (oyb >= strip0)
+                *reinterpret_cast<u16x8*>(y + (((int64_t)img * Hp + (oyb >> 1) + pr) * Wp + ppx) * 64 + c8 * 8) = mx;
+        }
+        __syncthreads();                                       // rowbuf rows 0..2 (+ the old carry) free, the ring holds the next rows
+    }
+}
+
 extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_std, const float* scale, const float* shift,
                                   void* y, int n, int H, int W, const void* wp, void* stream) {
     GRL_REQUIRE(x && scale && shift && y && wp && n > 0, "stem_pool_bf16: null/empty");
@@ -557,6 +731,17 @@ extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_
         return true;
     }();
     (void)attr;
+    static const bool form2 = [] { const char* e = getenv("GRL_STEM_POOL2"); return !e || atoi(e) != 0; }();       // (0: A/B and tests)
+    if (form2 && Ho % 4 == 0) {
+        // strips of whole iterations (4 stem rows); enough workgroups for two per CU, as few warm-up iterations as possible
+        int strips = 1;
+        while (strips * 2 <= Ho / 8 && (int64_t)n * strips < 512) strips *= 2;
+        const int strip_rows = (Ho / 4 + strips - 1) / strips * 4;
+        hipLaunchKernelGGL(stem_pool2_b16_kernel, dim3(grl_ceil_div(Ho, strip_rows), n), dim3(256), (size_t)S2_LDS, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(x), scale, shift, B16(y), H, CB16(wp), x_is_u8 ? mean_std : nullptr,
+                           strip_rows);
+        return grl_check_launch("grl_stem_pool_bf16 (form 2)");
+    }
     hipLaunchKernelGGL(stem_pool_b16_kernel, dim3(grl_ceil_div(Ho, SP_TPW * SP_TH), n), dim3(256), lds, (hipStream_t)stream,
                        reinterpret_cast<const float*>(x), scale, shift, B16(y), H, W, CB16(wp), x_is_u8 ? mean_std : nullptr);
     return grl_check_launch("grl_stem_pool_bf16");

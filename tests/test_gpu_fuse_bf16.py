@@ -203,16 +203,20 @@ def test_conv3x3_c64_matches_the_generic_kernel_and_torch(dev, n, H):
     assert float((y == y0).float().mean()) > 0.99
 
 
-@pytest.mark.parametrize('n,u8', [(3, False), (5, True)])
+@pytest.mark.parametrize('n,u8', [(3, False), (5, True), (40, False), (130, True), (512, False)])
 def test_stem_with_the_max_pool_in_the_same_launch_is_bit_identical(dev, synth_models, n, u8):
     """grl_stem_pool_bf16 (stem 7x7/s2 + folded BN + ReLU + 3x3/s2 max-pool, one launch, the stem map never written)
     against the two launches it replaces: rounding commutes with max, so the pooled map is the same bits -- float and raw
-    uint8 inputs, every strip (top strip without / lower strips with a warm-up tile)."""
+    uint8 inputs, every strip (top strip without / lower strips with a warm-up tile).  Round 5: the launch is the second
+    form (stem_pool2_b16_kernel: weights in registers, fragments straight from the staged rows, pooling on bf16 bit
+    patterns); strips of 8 (n < 32), 16 / 32 / 64 and 128 (n = 512: one workgroup per frame) stem rows; GRL_STEM_POOL2=0 in
+    the environment runs the first form through the same test."""
     from grl_amd import engine
     from grl_amd.synthetic import synth_clips
     cnn = synth_models[0].to(dev).eval()
     plan = engine._plan(cnn, engine.GrlEvalPlan)
     x = synth_clips(1, n, seed=11, raw=u8)[0].to(dev).contiguous()
+    assert x.shape[0] == n
     H, W = 256, 128
     stem = torch.empty(n * 128 * 64, 64, dtype=BF, device=dev)
     if u8:

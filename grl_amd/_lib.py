@@ -171,6 +171,8 @@ _SIGNATURES = {
     'grl_bottleneck_tail_bf16_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'grl_bneck_perm32': ([_fp, C.c_int, _fp, C.c_int, C.c_int, _fp], C.c_int),
     'grl_stem_pool_bf16': ([_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_stem_pack_weight_pool': ([_fp, _fp, _fp], C.c_int),
+    'grl_stem_pool_f32': ([_fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_conv3x3_c64_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bottleneck_tail_f32': ([C.POINTER(GrlBneckTailF32), _fp], C.c_int),
     'grl_bottleneck_tail_f32_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),

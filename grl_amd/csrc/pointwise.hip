@@ -882,6 +882,222 @@ static int stem_launch(const float* x, const float* norm, const float* w, const 
     return grl_check_launch("grl_stem_conv7x7");
 }
 
+// ---------------------------------------------------------------------------------
+// Stem + 3x3 / stride-2 max-pool in ONE launch, exact fp32 (round 5; eval: resnets1.py:101-104, basebranch.py:27-36):
+// the post-ReLU stem map (268 MB per 128 frames, written and read back by the two-launch form) never reaches HBM.
+// Orientation D[channel][pixel] = W . patch^T on v_mfma_f32_32x32x2_f32: a wave owns ONE 32-channel block, its 84
+// weight values per lane (k = (c, ky, kx) with kx padded to 8; lane half h takes kx = 4 h + u in k-step u of a
+// (c, ky) chunk) stay in registers for the whole launch, and a chunk's four B operands are four consecutive floats of
+// the staged input row (8-byte aligned: a stem pixel is two input pixels).  Input rows live in a 16-row ring per channel
+// (4 new rows per iteration, written under the MFMAs); one iteration = 2 stem rows (wave: row w >> 1, channel block
+// w & 1, both 32-column halves, interleaved accumulators) = 1 pooled row.  Folded BatchNorm + ReLU in registers, the two
+// rows go to LDS as [pixel][channel] fp32 (16-byte chunks XOR-swizzled), the pooling threads read 3 x 3 windows
+// against the carried previous row.  The k order differs from stem_mfma_kernel's (c, ky, kx) walk: same products,
+// another fp32 summation order (tested against torch at 1e-5 like the stem itself).  128 frames: 239 + 75 us -> ~170.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+constexpr int FP_TW = 64;                              // stem columns = the full width of a 128-pixel-wide frame
+constexpr int FP_ROWP = 2 * FP_TW + 6;                 // cells per staged input row: columns -3 .. 130
+constexpr int FP_ROWB = FP_ROWP * 4;                   // 536 bytes
+constexpr int FP_RING = 16;
+constexpr int FP_CHB = FP_RING * FP_ROWB;
+constexpr int FP_PATCHB = 3 * FP_CHB;                  // 25728
+constexpr int FP_ROWBUF = FP_TW * 256;                 // one stem row [64 px][64 ch] fp32
+constexpr int FP_LDS = 3 * FP_ROWBUF + FP_PATCHB;      // 74880: two workgroups per CU
+constexpr int FP_WK = 84;                              // weight values per (channel, lane half): 21 chunks x 4 k-steps
+
+__global__ void stem_pack_weight_pool_kernel(const float* __restrict__ w, float* __restrict__ wq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // [64][2][84]: (channel, half h, chunk (c, ky), k-step u) <- kx = 4 h + u
+    if (i >= 64 * 2 * FP_WK) return;
+    const int ch = i / (2 * FP_WK), r = i - ch * 2 * FP_WK, h = r / FP_WK, t = r - h * FP_WK, chunk = t >> 2, kx = 4 * h + (t & 3);
+    wq[i] = kx < 7 ? w[ch * 147 + chunk * 7 + kx] : 0.f;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_pool_f32_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y,
+    int H, const float* __restrict__ wq, const float* __restrict__ norm, int strip_prows) {
+    extern __shared__ __attribute__((aligned(16))) char smf[];
+    char* const rowbuf = smf;                                  // [3][64][256 B]
+    char* const patch = smf + 3 * FP_ROWBUF;                   // [3][16][536 B]
+    constexpr int W = 2 * FP_TW;
+    const int Ho = H >> 1, Hp = Ho >> 1, Wp = FP_TW / 2;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pxl = lane & 31, hf = lane >> 5;
+    const int jb = wave & 1, wrow = wave >> 1;                  // this wave's channel block and stem row of the iteration
+    const float* xi = x + (int64_t)img * 3 * H * W;
+    const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
+    // input rows by ry = iy + 3 (stem row oy, tap ky: ry = 2 oy + ky); lane l stages the input pixels 2 l, 2 l + 1 of a row
+    // (unconditional 8-byte load, a row outside the image is zeroed by a select) at cells 2 l + 3, 2 l + 4
+    auto load_row = [&](int c, int ry, auto u8_) {
+        constexpr bool U8 = decltype(u8_)::value;
+        const int iy = ry - 3;
+        const bool ok = (unsigned)iy < (unsigned)H;
+        const int64_t o = ((int64_t)c * H + (ok ? iy : 0)) * W + 2 * lane;
+        f32x2 v;
+        if constexpr (U8) {
+            const unsigned short u = *reinterpret_cast<const unsigned short*>(xu + o);
+            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
+            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+        } else {
+            v = *reinterpret_cast<const f32x2*>(xi + o);
+        }
+        const f32x2 z = {0.f, 0.f};
+        return ok ? v : z;
+    };
+    auto store_row = [&](int c, int ry, const f32x2 v) {
+        float* const d = reinterpret_cast<float*>(patch + c * FP_CHB + (ry & (FP_RING - 1)) * FP_ROWB) + 2 * lane + 3;
+        d[0] = v[0];
+        d[1] = v[1];
+    };
+    const int strip0 = blockIdx.x * strip_prows;                // first pooled row of this workgroup
+    int py = strip0 > 0 ? strip0 - 1 : 0;                       // (one warm-up iteration above the strip fills the carry row)
+    const int py_end = min(Hp, strip0 + strip_prows);
+    for (int i = tid; i < FP_PATCHB / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 3 * FP_ROWBUF / 16; i += 256) reinterpret_cast<uint4*>(rowbuf)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (int rr = wave; rr < 3 * 9; rr += 4) {                 // the 9 input rows of the first iteration
+        const int c = rr / 9, r = rr - 9 * c;
+        if (norm) store_row(c, 4 * py + r, load_row(c, 4 * py + r, std::true_type{}));
+        else store_row(c, 4 * py + r, load_row(c, 4 * py + r, std::false_type{}));
+    }
+    // weights: lane (channel 32 jb + pxl, half hf): 21 chunks x 4 k-steps
+    f32x4 wr[FP_WK / 4];
+#pragma unroll
+    for (int k = 0; k < FP_WK / 4; ++k) {
+        wr[k] = *reinterpret_cast<const f32x4*>(wq + ((32 * jb + pxl) * 2 + hf) * FP_WK + 4 * k);
+        asm volatile("" : "+v"(wr[k]));                        // (pinned in registers)
+    }
+    f32x4 sc[4], sh[4];                                         // this lane's channels 32 jb + 8 q + 4 hf + (0..3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const f32x4*>(scale + 32 * jb + 8 * q + 4 * hf);
+        sh[q] = *reinterpret_cast<const f32x4*>(shift + 32 * jb + 8 * q + 4 * hf);
+    }
+    const int c8 = tid & 7, ppx = tid >> 3;                     // pooling: this thread's pooled column and 8 channels
+    int cs = 0;                                                 // row-buffer slot of the carried row (zeros at the top)
+    __syncthreads();
+    for (; py < py_end; ++py) {
+        const int oy = 2 * py + wrow;
+        const bool more = py + 1 < py_end;
+        f32x2 pv[3];
+        if (more) {                                             // the 4 new input rows x 3 channels of the next iteration: 3 per wave
+            auto pre = [&](auto u8_) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int rr = wave + 4 * k;               // (channel rr >> 2, new row rr & 3)
+                    pv[k] = load_row(rr >> 2, 4 * py + 9 + (rr & 3), u8_);
+                }
+            };
+            if (norm) pre(std::true_type{});
+            else pre(std::false_type{});
+        }
+        f32x16p acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+        for (int chunk = 0; chunk < 21; ++chunk) {
+            const int c = chunk / 7, ky = chunk - 7 * c;
+            const char* const rowp = patch + c * FP_CHB + ((2 * oy + ky) & (FP_RING - 1)) * FP_ROWB + 16 * hf + 8 * pxl;
+            f32x2 b[2][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                b[cb][0] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb);
+                b[cb][1] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb + 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[chunk][u], b[cb][u >> 1][u & 1], acc[cb], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int rr = wave + 4 * k;
+                store_row(rr >> 2, 4 * py + 9 + (rr & 3), pv[k]);
+            }
+        }
+        __syncthreads();                                       // everyone has pooled the previous iteration and read this one's patch rows
+        const int s0 = cs == 2 ? 0 : cs + 1, s1 = s0 == 2 ? 0 : s0 + 1;        // slots of this iteration's rows 0 / 1
+        const int myslot = wrow == 0 ? s0 : s1;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int px = 32 * cb + pxl;
+            char* const dst = rowbuf + myslot * FP_ROWBUF + px * 256;
+            const int sw = (px >> 1) & 15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tv = acc[cb][4 * q + e] * sc[q][e] + sh[q][e];
+                    v[e] = tv > 0.f ? tv : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(dst + (((8 * jb + 2 * q + hf) ^ sw) << 4)) = v;
+            }
+        }
+        __syncthreads();
+        // pooled row py: (carry, row 0, row 1) x stem columns 2 ppx - 1 .. 2 ppx + 1; post-ReLU values are >= 0
+        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int slot = rr == 0 ? cs : (rr == 1 ? s0 : s1);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = 2 * ppx + dx;
+                if (cx >= 0) {
+                    const char* const src = rowbuf + slot * FP_ROWBUF + cx * 256;
+                    const int sw = (cx >> 1) & 15;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (((2 * c8) ^ sw) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (((2 * c8 + 1) ^ sw) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m0[e] = v0[e] > m0[e] ? v0[e] : m0[e];
+                        m1[e] = v1[e] > m1[e] ? v1[e] : m1[e];
+                    }
+                }
+            }
+        }
+        if (py >= strip0) {
+            float* const o = y + (((int64_t)img * Hp + py) * Wp + ppx) * 64 + c8 * 8;
+            *reinterpret_cast<f32x4*>(o) = m0;
+            *reinterpret_cast<f32x4*>(o + 4) = m1;
+        }
+        cs = s1;
+    }
+}
+
+extern "C" int grl_stem_pack_weight_pool(const float* w, float* wq, void* stream) {
+    GRL_REQUIRE(w && wq, "stem_pack_weight_pool: null");
+    hipLaunchKernelGGL(stem_pack_weight_pool_kernel, dim3(grl_ceil_div(64 * 2 * FP_WK, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wq);
+    return grl_check_launch("grl_stem_pack_weight_pool");
+}
+
+extern "C" int grl_stem_pool_f32(const void* x, int x_is_u8, const float* mean_std, const float* scale, const float* shift,
+                                 float* y, int n, int H, int W, const float* wq, void* stream) {
+    GRL_REQUIRE(x && scale && shift && y && wq && n > 0, "stem_pool_f32: null/empty");
+    GRL_REQUIRE(W == 2 * FP_TW && H % 4 == 0, "stem_pool_f32: needs W == 128 and H % 4 == 0");
+    GRL_REQUIRE(!x_is_u8 || mean_std, "stem_pool_f32: u8 input needs mean_std");
+    GRL_REQUIRE(((uintptr_t)x & 7) == 0 || x_is_u8, "stem_pool_f32: x must be 8-byte aligned");
+    const int Hp = H / 4;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)stem_pool_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
+        return true;
+    }();
+    (void)attr;
+    // strips of pooled rows: enough workgroups for two per CU, as few warm-up iterations as possible
+    int strips = 1;
+    while (strips * 2 <= Hp / 4 && (int64_t)n * strips < 512) strips *= 2;
+    const int strip_prows = (Hp + strips - 1) / strips;
+    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grl_ceil_div(Hp, strip_prows), n), dim3(256), (size_t)FP_LDS, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(x), scale, shift, y, H, wq, x_is_u8 ? mean_std : nullptr, strip_prows);
+    return grl_check_launch("grl_stem_pool_f32");
+}
+
 extern "C" int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream) {
     GRL_REQUIRE(x && y && n > 0 && C % 4 == 0, "maxpool: bad args");
     const int64_t total = (int64_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);

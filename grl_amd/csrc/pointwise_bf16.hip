@@ -626,7 +626,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < SB_CH / 2; ++s)
+        {
             wf[j][s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(wp) + (32 * j + pxl) * SB_ROWB + (2 * s + hf) * 16);
+            asm volatile("" : "+v"(wf[j][s]));                 // (pinned: hipcc re-loaded all 22 fragments inside the row loop)
+        }
     constexpr int P_IT = 6;                                     // rows per wave of the 3 x 8 new input rows of an iteration
     f32x2_s2 pv[P_IT];
     const int c8 = tid & 7, ppx = tid >> 3;                     // pooling: this thread's pooled column and 8 channels
@@ -726,7 +729,7 @@ extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_
     GRL_REQUIRE(!x_is_u8 || mean_std, "stem_pool_bf16: u8 input needs mean_std");
     const int Ho = H / 2;
     const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)SP_PATCH * sizeof(__bf16);
-    static const bool attr = [lds] {
+    static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)stem_pool_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return true;
     }();

@@ -142,6 +142,7 @@ def augment_normalize_u8(clips, params):
 
 FUSE_BNECK = os.environ.get('GRL_FUSE_BNECK', '1') != '0'       # A/B and tests: 0 = one launch per convolution
 FUSE_STEM_POOL = os.environ.get('GRL_FUSE_STEM_POOL', '1') != '0'   # A/B and tests: 0 = stem and max-pool as two launches (bf16 storage)
+FUSE_STEM_POOL_F32 = os.environ.get('GRL_FUSE_STEM_POOL_F32', '1') != '0'   # ... the exact-fp32 path (round 5)
 FUSE_DOWN = os.environ.get('GRL_FUSE_DOWN', '1') != '0'         # A/B and tests: 0 = the downsample conv as its own launch
 SLAB_CHECK = False  # tests only: poison every statistics slab and verify that the GEMM wrote all of it
 SPLITK = True       # tests / A-B only: False = never hand the library split-K scratch (one workgroup per tile walks K)
@@ -365,6 +366,8 @@ class GrlEvalPlan(EvalPlan):
         _call('grl_stem_pack_weight', ptr(self.stem_w), ptr(self.stem_wp))
         self.stem_wpb = torch.empty(64 * 184, dtype=torch.bfloat16, device=self.dev)
         _call('grl_stem_pack_weight_bf16', ptr(self.stem_w), ptr(self.stem_wpb))
+        self.stem_wq = torch.empty(64 * 168, dtype=torch.float32, device=self.dev)
+        _call('grl_stem_pack_weight_pool', ptr(self.stem_w), ptr(self.stem_wq))
         self.stem_scale, self.stem_shift = self.fold(base[1])
         self.blocks = []
         for li in (4, 5, 6, 7):
@@ -452,20 +455,26 @@ def trunk_eval(plan, x, taps=None):
     """x [n,3,H,W] NCHW -> channels-last [n*16*8][2048] (for 256x128 input)."""
     n, _, H, W = x.shape
     Hs, Ws = H // 2, W // 2
-    stem = _new((n * Hs * Ws, 64), x)
-    if x.dtype == torch.uint8:           # raw pixels: normalised while the stem stages its patch
-        _call('grl_stem_conv7x7_u8', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
-              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
-    else:
-        _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
-              ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
-    _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)
-    if taps is not None:
-        taps['stem'] = _to_nchw(stem, n, Hs, Ws)
-        taps['pool'] = _to_nchw(cur, n, Hp, Wp)
-    del stem
+    if FUSE_STEM_POOL_F32 and taps is None and W == 128 and H % 4 == 0:
+        # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_f32)
+        u8 = x.dtype == torch.uint8
+        _call('grl_stem_pool_f32', ptr(x), 1 if u8 else 0, ptr(input_mean_std(x.device)) if u8 else None,
+              ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(cur), n, H, W, ptr(plan.stem_wq))
+    else:
+        stem = _new((n * Hs * Ws, 64), x)
+        if x.dtype == torch.uint8:           # raw pixels: normalised while the stem stages its patch
+            _call('grl_stem_conv7x7_u8', ptr(x), ptr(input_mean_std(x.device)), ptr(plan.stem_w),
+                  ptr(plan.stem_scale), ptr(plan.stem_shift), ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
+        else:
+            _call('grl_stem_conv7x7', ptr(x), ptr(plan.stem_w), ptr(plan.stem_scale), ptr(plan.stem_shift),
+                  ptr(stem), n, H, W, 1, ptr(plan.stem_wp))
+        _call('grl_maxpool3x3s2', ptr(stem), ptr(cur), n, Hs, Ws, 64)
+        if taps is not None:
+            taps['stem'] = _to_nchw(stem, n, Hs, Ws)
+            taps['pool'] = _to_nchw(cur, n, Hp, Wp)
+        del stem
     H, W = Hp, Wp
     counts = (3, 4, 6, 3)
     bi = 0

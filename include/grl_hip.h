@@ -201,6 +201,15 @@ int grl_stem_pack_weight(const float* w, float* wp /* 64*164 floats */, void* st
 /* 3x3 stride-2 pad-1 max pool, channels-last (resnets1.py:104). */
 int grl_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream);
 
+/* Stem + max-pool in ONE launch, exact fp32 (round 5; eval: resnets1.py:101-104, basebranch.py:27-36): NCHW input
+ * [n][3][H][128] (fp32, or raw u8 with mean_std as in grl_stem_conv7x7_u8) -> y = maxpool3x3s2(relu(conv7x7s2 * scale +
+ * shift)) channels-last [n][H/4][32][64]; the stem map is neither written nor re-read.  W must be 128, H % 4 == 0.
+ * wq: the register image of the weights from grl_stem_pack_weight_pool (64 * 168 floats).  Same products as
+ * grl_stem_conv7x7 in another fp32 summation order (k-steps pair kx with kx + 4). */
+int grl_stem_pack_weight_pool(const float* w /*[64][3][7][7]*/, float* wq /* 64*168 floats */, void* stream);
+int grl_stem_pool_f32(const void* x, int x_is_u8, const float* mean_std, const float* scale, const float* shift, float* y,
+                      int n, int H, int W, const float* wq, void* stream);
+
 /* mean over `rows` consecutive rows: x [groups][rows][C] -> y [groups][ldy>=C]
  * (x.mean(-1).mean(-1)[.mean(1)] in basebranch.py:58, grl_model.py:151,165,178). */
 int grl_group_mean(const float* x, float* y, int groups, int rows, int C, int ldy,

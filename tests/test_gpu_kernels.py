@@ -200,6 +200,49 @@ def test_stem_and_maxpool_vs_torch(dev):
     assert torch.equal(pooled.view(n, H // 4, W // 4, 64).permute(0, 3, 1, 2).cpu(), refp)
 
 
+@pytest.mark.parametrize('n,u8', [(2, False), (3, True), (40, False), (128, False)])
+def test_stem_with_the_max_pool_in_one_launch_fp32(dev, n, u8):
+    """grl_stem_pool_f32 (round 5: stem 7x7/s2 + folded BN + ReLU + 3x3/s2 max-pool in one launch, exact fp32 MFMA, the
+    stem map never written) against torch (conv2d + max_pool2d in float64, 1e-5 like the stem itself) and against the two
+    launches it replaces (same products, another fp32 summation order: 2e-6 of the map's scale) -- float and raw uint8
+    input, strips of 4 / 8 / 16 pooled rows with their warm-up iteration (n = 128: the bench's 16-row strips)."""
+    from grl_amd import engine
+    from grl_amd._lib import ptr
+    rng = np.random.default_rng(19)
+    H, W = 256, 128
+    if u8:
+        xr = torch.from_numpy(rng.integers(0, 256, (n, 3, H, W), dtype=np.uint8))
+        ms = engine.input_mean_std(dev)
+        xf = ((xr.float() / 255.0) - ms[:3].cpu().view(1, 3, 1, 1)) / ms[3:].cpu().view(1, 3, 1, 1)
+    else:
+        xr = torch.from_numpy(rng.standard_normal((n, 3, H, W)).astype(np.float32))
+        xf = xr
+    w = torch.from_numpy((rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(-1.5, 1.5, 64).astype(np.float32))           # (negative scales too: max and BN do not commute)
+    sh = torch.from_numpy(rng.standard_normal(64).astype(np.float32) * 0.1)
+    xd, wd, scd, shd = xr.to(dev).contiguous(), w.to(dev), sc.to(dev), sh.to(dev)
+    wq = torch.empty(64 * 168, device=dev)
+    engine._call('grl_stem_pack_weight_pool', ptr(wd), ptr(wq))
+    got = torch.full((n * 64 * 32, 64), -1.0, device=dev)
+    engine._call('grl_stem_pool_f32', ptr(xd), 1 if u8 else 0, ptr(engine.input_mean_std(dev)) if u8 else None, ptr(scd), ptr(shd),
+                 ptr(got), n, H, W, ptr(wq))
+    stem = torch.empty(n * 128 * 64, 64, device=dev)
+    if u8:
+        engine._call('grl_stem_conv7x7_u8', ptr(xd), ptr(engine.input_mean_std(dev)), ptr(wd), ptr(scd), ptr(shd), ptr(stem), n, H, W, 1, None)
+    else:
+        engine._call('grl_stem_conv7x7', ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(stem), n, H, W, 1, None)
+    two = torch.empty(n * 64 * 32, 64, device=dev)
+    engine._call('grl_maxpool3x3s2', ptr(stem), ptr(two), n, 128, 64, 64)
+    scale = float(two.abs().max())
+    assert float((got - two).abs().max()) < 2e-6 * scale, float((got - two).abs().max()) / scale
+    m = min(n, 4)                                              # (torch reference on the first and last frames)
+    for sl in (slice(0, m), slice(n - m, n)):
+        ref = F.max_pool2d(F.relu(F.conv2d(xf[sl].double(), w.double(), stride=2, padding=3) * sc.double().view(1, -1, 1, 1) +
+                                  sh.double().view(1, -1, 1, 1)), 3, stride=2, padding=1)
+        g = got.view(n, 64, 32, 64)[sl].permute(0, 3, 1, 2).cpu().double()
+        assert _rel(g.numpy(), ref.numpy()) < 1e-5
+
+
 def test_pointwise_kernels_vs_torch(dev):
     from grl_amd import engine
     from grl_amd._lib import ptr

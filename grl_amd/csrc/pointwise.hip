@@ -913,6 +913,7 @@ __global__ void stem_pack_weight_pool_kernel(const float* __restrict__ w, float*
     wq[i] = kx < 7 ? w[ch * 147 + chunk * 7 + kx] : 0.f;
 }
 
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_pool_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y,
     int H, const float* __restrict__ wq, const float* __restrict__ norm, int strip_prows) {
@@ -929,26 +930,32 @@ __global__ __launch_bounds__(256, 2) void stem_pool_f32_kernel(
     const uint8_t* xu = reinterpret_cast<const uint8_t*>(x) + (int64_t)img * 3 * H * W;
     // input rows by ry = iy + 3 (stem row oy, tap ky: ry = 2 oy + ky); lane l stages the input pixels 2 l, 2 l + 1 of a row
     // (unconditional 8-byte load, a row outside the image is zeroed by a select) at cells 2 l + 3, 2 l + 4
-    auto load_row = [&](int c, int ry, auto u8_) {
-        constexpr bool U8 = decltype(u8_)::value;
+    // (the RAW load is returned; the out-of-image select and the u8 conversion happen in store_row, after the MFMAs: a
+    //  select right behind the load -- or any branch between the load and its use -- makes hipcc wait for the load on the spot)
+    auto load_row = [&](int c, int ry) {
         const int iy = ry - 3;
         const bool ok = (unsigned)iy < (unsigned)H;
         const int64_t o = ((int64_t)c * H + (ok ? iy : 0)) * W + 2 * lane;
         f32x2 v;
         if constexpr (U8) {
             const unsigned short u = *reinterpret_cast<const unsigned short*>(xu + o);
-            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
-            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+            v[0] = __builtin_bit_cast(float, (uint32_t)u);
+            v[1] = 0.f;
         } else {
             v = *reinterpret_cast<const f32x2*>(xi + o);
         }
-        const f32x2 z = {0.f, 0.f};
-        return ok ? v : z;
+        return v;
     };
-    auto store_row = [&](int c, int ry, const f32x2 v) {
+    auto store_row = [&](int c, int ry, f32x2 v) {
+        const bool ok = (unsigned)(ry - 3) < (unsigned)H;
+        if constexpr (U8) {
+            const uint32_t u = __builtin_bit_cast(uint32_t, v[0]);
+            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
+            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+        }
         float* const d = reinterpret_cast<float*>(patch + c * FP_CHB + (ry & (FP_RING - 1)) * FP_ROWB) + 2 * lane + 3;
-        d[0] = v[0];
-        d[1] = v[1];
+        d[0] = ok ? v[0] : 0.f;
+        d[1] = ok ? v[1] : 0.f;
     };
     const int strip0 = blockIdx.x * strip_prows;                // first pooled row of this workgroup
     int py = strip0 > 0 ? strip0 - 1 : 0;                       // (one warm-up iteration above the strip fills the carry row)
@@ -958,8 +965,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_f32_kernel(
     __syncthreads();
     for (int rr = wave; rr < 3 * 9; rr += 4) {                 // the 9 input rows of the first iteration
         const int c = rr / 9, r = rr - 9 * c;
-        if (norm) store_row(c, 4 * py + r, load_row(c, 4 * py + r, std::true_type{}));
-        else store_row(c, 4 * py + r, load_row(c, 4 * py + r, std::false_type{}));
+        store_row(c, 4 * py + r, load_row(c, 4 * py + r));
     }
     // weights: lane (channel 32 jb + pxl, half hf): 21 chunks x 4 k-steps
     f32x4 wr[FP_WK / 4];
@@ -979,46 +985,48 @@ __global__ __launch_bounds__(256, 2) void stem_pool_f32_kernel(
     __syncthreads();
     for (; py < py_end; ++py) {
         const int oy = 2 * py + wrow;
-        const bool more = py + 1 < py_end;
+        // the 4 new input rows x 3 channels of the next iteration, 3 per wave: requested here, written to the ring behind the
+        // MFMAs, no branch in between (past the last iteration they are loaded and stored all the same: nobody reads them)
         f32x2 pv[3];
-        if (more) {                                             // the 4 new input rows x 3 channels of the next iteration: 3 per wave
-            auto pre = [&](auto u8_) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int rr = wave + 4 * k;               // (channel rr >> 2, new row rr & 3)
-                    pv[k] = load_row(rr >> 2, 4 * py + 9 + (rr & 3), u8_);
-                }
-            };
-            if (norm) pre(std::true_type{});
-            else pre(std::false_type{});
+        for (int k = 0; k < 3; ++k) {
+            const int rr = wave + 4 * k;                       // (channel rr >> 2, new row rr & 3)
+            pv[k] = load_row(rr >> 2, 4 * py + 9 + (rr & 3));
         }
+        __builtin_amdgcn_sched_barrier(0);                     // (hipcc otherwise sinks the loads below the MFMAs, next to their use)
         f32x16p acc[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-#pragma unroll
-        for (int chunk = 0; chunk < 21; ++chunk) {
+        // B operands double-buffered in registers: the reads of chunk + 1 go out in front of the MFMAs of this chunk
+        f32x2 bb[2][2][2];                                      // [buffer][column half][float pair]
+        auto read_chunk = [&](int chunk, f32x2 (&dst)[2][2]) {
             const int c = chunk / 7, ky = chunk - 7 * c;
             const char* const rowp = patch + c * FP_CHB + ((2 * oy + ky) & (FP_RING - 1)) * FP_ROWB + 16 * hf + 8 * pxl;
-            f32x2 b[2][2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                b[cb][0] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb);
-                b[cb][1] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb + 8);
+                dst[cb][0] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb);
+                dst[cb][1] = *reinterpret_cast<const f32x2*>(rowp + 256 * cb + 8);
             }
+        };
+        read_chunk(0, bb[0]);
+#pragma unroll
+        for (int chunk = 0; chunk < 21; ++chunk) {
+            if (chunk + 1 < 21) read_chunk(chunk + 1, bb[(chunk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[chunk][u], b[cb][u >> 1][u & 1], acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[chunk][u], bb[chunk & 1][cb][u >> 1][u & 1], acc[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
+        __builtin_amdgcn_sched_barrier(0);                     // (... and hoists the ring stores, with their wait, up between the MFMAs)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int rr = wave + 4 * k;
-                store_row(rr >> 2, 4 * py + 9 + (rr & 3), pv[k]);
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int rr = wave + 4 * k;
+            store_row(rr >> 2, 4 * py + 9 + (rr & 3), pv[k]);
         }
         __syncthreads();                                       // everyone has pooled the previous iteration and read this one's patch rows
         const int s0 = cs == 2 ? 0 : cs + 1, s1 = s0 == 2 ? 0 : s0 + 1;        // slots of this iteration's rows 0 / 1
@@ -1085,7 +1093,8 @@ extern "C" int grl_stem_pool_f32(const void* x, int x_is_u8, const float* mean_s
     GRL_REQUIRE(((uintptr_t)x & 7) == 0 || x_is_u8, "stem_pool_f32: x must be 8-byte aligned");
     const int Hp = H / 4;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)stem_pool_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
+        (void)hipFuncSetAttribute((const void*)stem_pool_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
+        (void)hipFuncSetAttribute((const void*)stem_pool_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);
         return true;
     }();
     (void)attr;
@@ -1093,8 +1102,12 @@ extern "C" int grl_stem_pool_f32(const void* x, int x_is_u8, const float* mean_s
     int strips = 1;
     while (strips * 2 <= Hp / 4 && (int64_t)n * strips < 512) strips *= 2;
     const int strip_prows = (Hp + strips - 1) / strips;
-    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grl_ceil_div(Hp, strip_prows), n), dim3(256), (size_t)FP_LDS, (hipStream_t)stream,
-                       reinterpret_cast<const float*>(x), scale, shift, y, H, wq, x_is_u8 ? mean_std : nullptr, strip_prows);
+    if (x_is_u8)
+        hipLaunchKernelGGL(stem_pool_f32_kernel<true>, dim3(grl_ceil_div(Hp, strip_prows), n), dim3(256), (size_t)FP_LDS, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(x), scale, shift, y, H, wq, mean_std, strip_prows);
+    else
+        hipLaunchKernelGGL(stem_pool_f32_kernel<false>, dim3(grl_ceil_div(Hp, strip_prows), n), dim3(256), (size_t)FP_LDS, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(x), scale, shift, y, H, wq, (const float*)nullptr, strip_prows);
     return grl_check_launch("grl_stem_pool_f32");
 }
 

@@ -564,10 +564,14 @@ constexpr int S2_CHB = (S2_RING + 1) * S2_ROWB;       // bytes per channel (+ on
 constexpr int S2_PATCHB = (3 * S2_CHB + 15) / 16 * 16;
 constexpr int S2_ROWBUF = SP_TW * 128;                // one stem row as bf16 [64 px][64 ch]
 constexpr int S2_LDS = 5 * S2_ROWBUF + S2_PATCHB + 512;       // + folded BatchNorm scale / shift (64 floats each)
+#ifndef GRL_SP2_KO
+#define GRL_SP2_KO 0      // timing-only knock-outs (1: no fragment reads / MFMAs, 2: no epilogue, 4: no pooling reads, 8: no input staging); wrong results
+#endif
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_s2 __attribute__((ext_vector_type(4)));
 typedef float f32x2_s2 __attribute__((ext_vector_type(2)));
 
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ y,
     int H, const __bf16* __restrict__ wp, const float* __restrict__ norm, int strip_rows) {
@@ -586,26 +590,32 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
     // stages whole rows: lane l loads the input pixels 2 l, 2 l + 1 (one 8-byte load; the loads are unconditional -- a row
     // outside the image reads row 0 and is zeroed by a select -- so hipcc can count them) and writes two bf16 cells at
     // columns 2 l + 3, 2 l + 4; the six pad cells of a row are zeroed once and never written again.
-    auto load_row = [&](int c, int ry, auto u8_) {
-        constexpr bool U8 = decltype(u8_)::value;
+    // (the RAW load is returned; the out-of-image select and the conversion happen in store_row, after the MFMAs: a select
+    //  right behind the load -- or any branch between the load and its use -- makes hipcc wait for the load on the spot)
+    auto load_row = [&](int c, int ry) {
         const int iy = ry - 3;
         const bool ok = (unsigned)iy < (unsigned)H;
         const int64_t o = ((int64_t)c * H + (ok ? iy : 0)) * W + 2 * lane;
         f32x2_s2 v;
         if constexpr (U8) {
             const unsigned short u = *reinterpret_cast<const unsigned short*>(xu + o);
-            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
-            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+            v[0] = __builtin_bit_cast(float, (uint32_t)u);
+            v[1] = 0.f;
         } else {
             v = *reinterpret_cast<const f32x2_s2*>(xi + o);
         }
-        const f32x2_s2 z = {0.f, 0.f};
-        return ok ? v : z;
+        return v;
     };
-    auto store_row = [&](int c, int ry, const f32x2_s2 v) {
+    auto store_row = [&](int c, int ry, f32x2_s2 v) {
+        const bool ok = (unsigned)(ry - 3) < (unsigned)H;
+        if constexpr (U8) {
+            const uint32_t u = __builtin_bit_cast(uint32_t, v[0]);
+            v[0] = ((float)(u & 255u) / 255.f - norm[c]) / norm[3 + c];
+            v[1] = ((float)(u >> 8) / 255.f - norm[c]) / norm[3 + c];
+        }
         __bf16* const d = reinterpret_cast<__bf16*>(patch + c * S2_CHB + (ry & (S2_RING - 1)) * S2_ROWB) + 2 * lane + 3;
-        d[0] = (__bf16)v[0];
-        d[1] = (__bf16)v[1];
+        d[0] = (__bf16)(ok ? v[0] : 0.f);
+        d[1] = (__bf16)(ok ? v[1] : 0.f);
     };
     const int strip0 = blockIdx.x * strip_rows;                 // first stem row whose pooled rows this workgroup emits
     int oyb = strip0 > 0 ? strip0 - 4 : 0;                      // (one warm-up iteration above the strip fills the carry row)
@@ -617,8 +627,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
     __syncthreads();
     for (int rr = wave; rr < 3 * 13; rr += 4) {
         const int c = rr / 13, r = rr - 13 * c;
-        if (norm) store_row(c, 2 * oyb + r, load_row(c, 2 * oyb + r, std::true_type{}));
-        else store_row(c, 2 * oyb + r, load_row(c, 2 * oyb + r, std::false_type{}));
+        store_row(c, 2 * oyb + r, load_row(c, 2 * oyb + r));
     }
     // weights: A fragments (lane: channel 32 j + pxl, k chunk 2 s + hf) of the packed image [64][368 B]
     bf16x8 wf[2][SB_CH / 2];
@@ -635,76 +644,88 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_b16_kernel(
     const int c8 = tid & 7, ppx = tid >> 3;                     // pooling: this thread's pooled column and 8 channels
     __syncthreads();
     for (int it = 0; oyb < oy_end; oyb += 4, ++it) {
-        const bool more = oyb + 4 < oy_end;
-        if (more) {
-            auto pre = [&](auto u8_) {
+        // the next iteration's 8 new rows x 3 channels, 6 per wave: requested here, written to the ring behind the MFMAs.
+        // No branch between the two (past the last iteration the rows are loaded and stored all the same: nobody reads them)
 #pragma unroll
-                for (int k = 0; k < P_IT; ++k) {
-                    const int rr = wave + 4 * k;               // (channel rr >> 3, new row rr & 7)
-                    pv[k] = load_row(rr >> 3, 2 * oyb + 13 + (rr & 7), u8_);
-                }
-            };
-            if (norm) pre(std::true_type{});
-            else pre(std::false_type{});
+        for (int k = 0; k < P_IT; ++k) {
+            const int rr = wave + 4 * k;                       // (channel rr >> 3, new row rr & 7)
+            if (!(GRL_SP2_KO & 8)) pv[k] = load_row(rr >> 3, 2 * oyb + 13 + (rr & 7));
         }
+        __builtin_amdgcn_sched_barrier(0);                     // (hipcc otherwise sinks the loads below the MFMAs, next to their use)
         // row slots of this iteration: rows 0..2 -> slots 0..2, row 3 -> slot 3 (even) / 4 (odd); the carry (previous
         // iteration's row 3) is the other one of 3 / 4
         const int slot3 = 3 + (it & 1), carry = 4 - (it & 1);
         const int oy = oyb + wave;
         const int myslot = wave < 3 ? wave : slot3;
+        // both 32-column halves of the row together: four independent accumulator chains, and the folded BatchNorm
+        // vectors of a channel quad are read once for both
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int px = 32 * cb + pxl;
-            f32x16 acc[2];
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
+        // fragments double-buffered in registers: the reads of k-step s + 1 go out in front of the MFMAs of step s (hipcc's own
+        // order -- read, wait, four MFMAs, next read into the same registers -- exposed the LDS latency eleven times per row)
+        bf16x8 bfr[2][2];
+        auto read_frag = [&](int s, bf16x8 (&dst)[2]) {
+            const int ch0 = 2 * s, ch1 = 2 * s + 1;
+            const int off0 = (ch0 / 7) * S2_CHB + ((2 * oy + ch0 % 7) & (S2_RING - 1)) * S2_ROWB;
+            const int off1 = ch1 < 21 ? (ch1 / 7) * S2_CHB + ((2 * oy + ch1 % 7) & (S2_RING - 1)) * S2_ROWB : S2_RING * S2_ROWB;
+            const uint32_t* s2 = reinterpret_cast<const uint32_t*>(patch + (hf ? off1 : off0) + 4 * pxl);
 #pragma unroll
-            for (int s = 0; s < SB_CH / 2; ++s) {
-                const int ch0 = 2 * s, ch1 = 2 * s + 1;
-                const int off0 = (ch0 / 7) * S2_CHB + ((2 * oy + ch0 % 7) & (S2_RING - 1)) * S2_ROWB;
-                const int off1 = ch1 < 21 ? (ch1 / 7) * S2_CHB + ((2 * oy + ch1 % 7) & (S2_RING - 1)) * S2_ROWB : S2_RING * S2_ROWB;
-                const uint32_t* s2 = reinterpret_cast<const uint32_t*>(patch + (hf ? off1 : off0) + 4 * px);
+            for (int cb = 0; cb < 2; ++cb) {
                 uint32_t o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = s2[e];
-                const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s], b, acc[j], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) o[e] = s2[32 * cb + e];
+                dst[cb] = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
             }
-            char* const dst = rowbuf + myslot * S2_ROWBUF + px * 128 + 8 * hf;
-            const int sw = (px >> 1) & 7;
+        };
+        if (!(GRL_SP2_KO & 1)) read_frag(0, bfr[0]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int s = 0; s < ((GRL_SP2_KO & 1) ? 0 : SB_CH / 2); ++s) {
+            if (s + 1 < SB_CH / 2) read_frag(s + 1, bfr[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // (this lane's channels 32 j + 8 q + 4 hf + (0..3))
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scs + 32 * j + 8 * q + 4 * hf);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(scs + 64 + 32 * j + 8 * q + 4 * hf);
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][s], bfr[s & 1][cb], acc[cb][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < ((GRL_SP2_KO & 2) ? 0 : 2); ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // (this lane's channels 32 j + 8 q + 4 hf + (0..3))
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scs + 32 * j + 8 * q + 4 * hf);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(scs + 64 + 32 * j + 8 * q + 4 * hf);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int px = 32 * cb + pxl;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float tv = acc[j][4 * q + e] * sc[e] + sh[e];
+                        const float tv = acc[cb][j][4 * q + e] * sc[e] + sh[e];
                         v[e] = tv > 0.f ? tv : 0.f;
                     }
-                    *reinterpret_cast<bf16x4_s2*>(dst + (((4 * j + q) ^ sw) << 4)) = __builtin_convertvector(v, bf16x4_s2);
+                    *reinterpret_cast<bf16x4_s2*>(rowbuf + myslot * S2_ROWBUF + px * 128 + 8 * hf + (((4 * j + q) ^ ((px >> 1) & 7)) << 4)) =
+                        __builtin_convertvector(v, bf16x4_s2);
                 }
-        }
-        __syncthreads();                                       // the four stem rows are in rowbuf; nobody reads the patch any more
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < P_IT; ++k) {
-                const int rr = wave + 4 * k;
-                store_row(rr >> 3, 2 * oyb + 13 + (rr & 7), pv[k]);
             }
+        __syncthreads();                                       // the four stem rows are in rowbuf; nobody reads the patch any more
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < P_IT; ++k) {
+            const int rr = wave + 4 * k;
+            if (!(GRL_SP2_KO & 8)) store_row(rr >> 3, 2 * oyb + 13 + (rr & 7), pv[k]);
         }
         // two pooled rows: (carry, row 0, row 1) and (row 1, row 2, row 3) x stem columns 2 ppx - 1 .. 2 ppx + 1
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             u16x8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
+            for (int rr = 0; rr < ((GRL_SP2_KO & 4) ? 0 : 3); ++rr) {
                 const int slot = pr == 0 ? (rr == 0 ? carry : rr - 1) : (rr == 2 ? slot3 : rr + 1);
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
@@ -740,9 +761,13 @@ extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_
         int strips = 1;
         while (strips * 2 <= Ho / 8 && (int64_t)n * strips < 512) strips *= 2;
         const int strip_rows = (Ho / 4 + strips - 1) / strips * 4;
-        hipLaunchKernelGGL(stem_pool2_b16_kernel, dim3(grl_ceil_div(Ho, strip_rows), n), dim3(256), (size_t)S2_LDS, (hipStream_t)stream,
-                           reinterpret_cast<const float*>(x), scale, shift, B16(y), H, CB16(wp), x_is_u8 ? mean_std : nullptr,
-                           strip_rows);
+        if (x_is_u8)
+            hipLaunchKernelGGL(stem_pool2_b16_kernel<true>, dim3(grl_ceil_div(Ho, strip_rows), n), dim3(256), (size_t)S2_LDS,
+                               (hipStream_t)stream, reinterpret_cast<const float*>(x), scale, shift, B16(y), H, CB16(wp), mean_std, strip_rows);
+        else
+            hipLaunchKernelGGL(stem_pool2_b16_kernel<false>, dim3(grl_ceil_div(Ho, strip_rows), n), dim3(256), (size_t)S2_LDS,
+                               (hipStream_t)stream, reinterpret_cast<const float*>(x), scale, shift, B16(y), H, CB16(wp),
+                               (const float*)nullptr, strip_rows);
         return grl_check_launch("grl_stem_pool_bf16 (form 2)");
     }
     hipLaunchKernelGGL(stem_pool_b16_kernel, dim3(grl_ceil_div(Ho, SP_TPW * SP_TH), n), dim3(256), lds, (hipStream_t)stream,

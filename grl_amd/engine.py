@@ -543,22 +543,51 @@ def gce_eval(plan, x4, b, t, taps=None):
 # (GRL_TRL_STREAMS=0, or taps requested).
 TRL_STREAMS = os.environ.get('GRL_TRL_STREAMS', '1') != '0'
 TRL_GROUP = os.environ.get('GRL_TRL_GROUP', '0') != '0'       # bf16 storage: conv1 / conv2 of both directions as grouped launches (measured slower: see below)
+# Round 5 (eval): each direction's ATTENTION branch of a step -- the f1 GEMM with its squared-difference epilogue and the
+# three latency-bound kernels behind it (partial-sum GAP, the two channel-attention layers) -- only reads the step's memo
+# and feeds f_corr, never the recurrence; in stream order it still sat in front of the step's add / conv1 / conv2 / conv3.
+# It goes to a stream of its own (one per direction), forked from the direction's stream where the memo is ready, so the
+# recurrence's GEMMs run next to it (knock-out bound: the small kernels cost 0.27 ms of configs[2] although nothing waits
+# for their results before the join; measured configs[2] 10.03 -> 9.93-9.97 ms).  bf16 storage only: the exact-fp32 step
+# LOSES 1 % to it (14.47 -> 14.63 ms; with only the small kernels moved 14.60) -- its f1 GEMMs are four times longer and
+# sharing CUs costs them more than the bubbles they fill.  Same kernels on the same operands: bit-identical.
+# GRL_TRL_ATT_STREAMS=0: the attention branch stays on its direction's stream.
+TRL_ATT_STREAMS = os.environ.get('GRL_TRL_ATT_STREAMS', '1') != '0'
 _side_streams = {}
+_att_streams = {}
 
 
 class _TrlFork(object):
-    """streams[di] for the two TRL directions; ``with fork.on(di):`` routes launches and allocations."""
+    """streams[di] for the two TRL directions; ``with fork.on(di):`` routes launches and allocations;
+    ``with fork.att_on(di):`` routes to the direction's attention stream (ordered after everything issued so far on
+    the direction's own stream)."""
 
-    def __init__(self, dev, enable):
+    def __init__(self, dev, enable, att=False):
         self.main = torch.cuda.current_stream(dev)
         self.two = bool(enable and TRL_STREAMS)
+        self.att = None
+        self.held = []          # tensors an attention stream reads: kept alive until the join
         if self.two:
             key = (dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in _side_streams:
                 _side_streams[key] = torch.cuda.Stream(dev)
             self.side = _side_streams[key]
+            if att and TRL_ATT_STREAMS:
+                if key not in _att_streams:
+                    _att_streams[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+                self.att = _att_streams[key]
         else:
             self.side = self.main
+
+    def att_on(self, di, *reads):
+        """``reads``: tensors of the direction's stream the branch reads (held until the join)."""
+        if self.att is None:
+            return self.on(di)
+        ev = torch.cuda.Event()
+        ev.record(self.side if di == 1 else self.main)
+        self.att[di].wait_event(ev)
+        self.held.extend(r for r in reads if r is not None)
+        return torch.cuda.stream(self.att[di])
 
     def fork(self):
         if self.two:
@@ -585,11 +614,13 @@ class _TrlFork(object):
 
     def join(self, *side_tensors):
         if self.two:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.main.wait_event(ev)
+            for st in (self.side,) + (tuple(self.att) if self.att is not None else ()):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.main.wait_event(ev)
             for x in side_tensors:
                 x.record_stream(self.main)
+            self.held = []
 
 
 def trl_eval(plan, xu, xc, b, t, taps=None):
@@ -618,8 +649,8 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     catte = _new((b, Cc), xu) if taps is not None else None
     for i in range(t):
         for di, d in enumerate(plan.dirs):
+            ti = i if di == 0 else t - 1 - i
             with fk.on(di):
-                ti = i if di == 0 else t - 1 - i
                 dvec, dpart, hid = scr[di]
                 fcorr = fc[di]
                 # d = GAP((ReLU(conv_f1(memo)) - f2_t)^2): the squared difference is reduced in the GEMM
@@ -636,6 +667,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
                       ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
                 if taps is not None:
                     taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
+            with fk.on(di):                                     # the recurrence
                 s = _new((Mb, Cc), xu)
                 _call('grl_add_strided', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s), b, frame, t * frame)
                 o = _new((Mb, 512), xu)
@@ -863,7 +895,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     # two workgroups per CU, so the two streams' launches already share every CU -- and the hand-offs cost their bubbles.
     # Off by default (GRL_TRL_GROUP=1 switches it on; kept tested: test_trl_grouped_launches_equal_two_stream_form).
     grouped = TRL_GROUP and len(plan.dirs) == 2
-    fk = _TrlFork(x.device, taps is None and len(plan.dirs) == 2)
+    fk = _TrlFork(x.device, taps is None and len(plan.dirs) == 2, att=not grouped)
     bufs = None
     if grouped:
         bufs = [dict(s=_newb((Mb, Cc), x), o=_newb((Mb, 512), x), o2=_newb((Mb, 512), x),
@@ -879,21 +911,29 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             scr.append((_new((b, Cc), x), _new((b, 128), x)))
     memo = [memo0, memo0]
 
-    def f1_branch(di, d, ti):
-        dvec, hid = scr[di]
+    def f1_gemm(di, d, ti):
         if FUSE_TRL_SQDIFF and Mb % 256 == 0:
             # the squared difference reduced in the f1 GEMM's epilogue (32-row partial sums): conv_f1's output
             # never reaches HBM -- round 3: the bf16 256 x 256 kernel has the epilogue too
             dpart = _new((Mb // 32, Cc), x)
             gemm(memo[di], d['f1'].wb(), dpart, Mb, Cc, Cc, shift=d['f1'].shift, epilogue=EPI_SQDIFF,
                  res=f2[di][ti * PIX:], res_rows=PIX, res_gstride=t * PIX, math=MATH_BF16S)
+            return dpart, None
+        f1 = _newb((Mb, Cc), x)
+        gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
+        return None, f1
+
+    def f1_tail(di, d, ti, dpart, f1):
+        dvec, hid = scr[di]
+        if dpart is not None:
             _call('grl_group_mean', ptr(dpart), ptr(dvec), b, PIX // 32, Cc, Cc, C.c_float(1.0 / 32.0), 0)
         else:
-            f1 = _newb((Mb, Cc), x)
-            gemm(memo[di], d['f1'].wb(), f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True, math=MATH_BF16S)
             _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
         _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
               None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+
+    def f1_branch(di, d, ti):
+        f1_tail(di, d, ti, *f1_gemm(di, d, ti))
 
     for i in range(t):
         tis = [i, t - 1 - i]
@@ -918,9 +958,10 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
                     memo[di] = nm
             continue
         for di, d in enumerate(plan.dirs):
-            with fk.on(di):
-                ti = tis[di]
+            ti = tis[di]
+            with fk.att_on(di, memo[di]):                       # the attention branch (its own stream: see _TrlFork)
                 f1_branch(di, d, ti)
+            with fk.on(di):
                 s_ = _newb((Mb, Cc), x)
                 _call('grl_add_strided_bf16', ptr(memo[di]), ptr(xu.view(-1)[ti * frame:]), ptr(s_), b, frame, t * frame)
                 c1, c2_, c3 = d['c1'], d['c2'], d['c3']

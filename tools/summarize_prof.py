@@ -21,7 +21,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
+    for tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel', 'stem_pool_f32', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
                 'temporal_mean', 'add_strided', 'channel_hidden', 'channel_atte_out', 'affine_l2norm',
                 'siamese_attn', 'mean_T', 'row_sqnorm', 'pair_verify', 'bn_fold', 'pack_conv_weight'):
         if tag in name:
@@ -59,7 +59,7 @@ def main():
         k = short(row['Kernel_Name'])
         dur[k] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
         calls[k] += 1
-    stem = 'stem_mfma' if calls.get('stem_mfma') else 'stem_conv7x7'
+    stem = 'stem_pool_f32' if calls.get('stem_pool_f32') else ('stem_mfma' if calls.get('stem_mfma') else 'stem_conv7x7')
     steps = calls[stem]
     fetch, fcalls = read_pmc(d_fetch)
     write, wcalls = read_pmc(d_write)

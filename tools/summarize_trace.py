@@ -24,7 +24,7 @@ def main():
     out_csv = sys.argv[4] if len(sys.argv) > 4 else None
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    stems = [i for i, r in enumerate(rows) if 'stem_' in r['Kernel_Name'] and 'im2col' not in r['Kernel_Name']
+    stems = [i for i, r in enumerate(rows) if 'stem_' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name'] and 'im2col' not in r['Kernel_Name']
              and 'pack' not in r['Kernel_Name']]
     skip = 2 if len(stems) > 3 else 0
     body = rows[stems[skip]:]

@@ -61,6 +61,16 @@ def main():
         calls[k] += 1
     stem = 'stem_pool_f32' if calls.get('stem_pool_f32') else ('stem_mfma' if calls.get('stem_mfma') else 'stem_conv7x7')
     steps = calls[stem]
+    # launches that are not this library's, INSIDE the steps (between the first and the last stem launch) -- the kernel-stats
+    # file also counts the model's host->device weight upload before the first step (hundreds of __amd_rocclr_copyBuffer)
+    trows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
+    tnames = [short(r['Kernel_Name']) for r in trows]
+    sidx = [i for i, n in enumerate(tnames) if n == stem]
+    foreign = defaultdict(int)
+    for i in range(sidx[0], sidx[-1]):
+        if tnames[i].startswith('other:'):
+            foreign[trows[i]['Kernel_Name'].split('(')[0][:60]] += 1
+    before = sum(1 for i in range(0, sidx[0]) if 'copyBuffer' in trows[i]['Kernel_Name'])
     fetch, fcalls = read_pmc(d_fetch)
     write, wcalls = read_pmc(d_write)
     mfma, mcalls = read_pmc(d_mfma)
@@ -89,6 +99,7 @@ def main():
     lines += ['', 'HBM GB/s = (FETCH_SIZE x2 + WRITE_SIZE bytes) / kernel time, against ~8000 GB/s HBM3E peak '
               '(MI355X_MICROARCH.md); MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.',
               '', 'sum of kernel time: %.3f ms/step over %d profiled steps' % (tot_ms, steps), '',
+              'launches inside the steps that are not this library\'s: %s per step (%d __amd_rocclr_copyBuffer launches of the stats file precede the first step: the weight upload)' % (', '.join('%s %.2f' % (k, v / max(steps - 1, 1)) for k, v in sorted(foreign.items())) or 'none', before), '',
               'gemm_f32_kernel + bneck_tail_f32_kernel (all instantiations): %.3f ms/step, %.0f launches/step, HBM read %.0f MB + write %.0f MB '
               'per step (FETCH_SIZE x2 gfx950 correction applied), MFMA busy %.1f %% of kernel-active cycles' % (
                   gem['ms'], gem['launches'], gem['rd'], gem['wr'],

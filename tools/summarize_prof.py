@@ -23,7 +23,7 @@ from collections import defaultdict
 def short(name):
     for tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel', 'stem_pool_f32', 'stem_mfma', 'stem_conv7x7', 'maxpool3x3s2', 'group_mean', 'sqdiff_mean', 'gce_gate',
                 'temporal_mean', 'add_strided', 'channel_hidden', 'channel_atte_out', 'affine_l2norm',
-                'siamese_attn', 'mean_T', 'row_sqnorm', 'pair_verify', 'bn_fold', 'pack_conv_weight'):
+                'siamese_attn', 'mean_T', 'row_sqnorm', 'pair_verify', 'bn_fold', 'pack_conv_weight', 'splitk_finish'):
         if tag in name:
             if tag in ('gemm_f32_kernel', 'bneck_tail_f32_kernel'):
                 return name[name.index(tag):].split('(')[0]
@@ -69,7 +69,7 @@ def main():
     foreign = defaultdict(int)
     for i in range(sidx[0], sidx[-1]):
         if tnames[i].startswith('other:'):
-            foreign[trows[i]['Kernel_Name'].split('(')[0][:60]] += 1
+            foreign[trows[i]['Kernel_Name'].replace('void ', '').replace('at::native::', '').replace('(anonymous namespace)::', '').split('<')[0].split('(')[0][:48]] += 1
     before = sum(1 for i in range(0, sidx[0]) if 'copyBuffer' in trows[i]['Kernel_Name'])
     fetch, fcalls = read_pmc(d_fetch)
     write, wcalls = read_pmc(d_write)

@@ -643,7 +643,9 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
             f2.append(y)
             # per-direction accumulators / scratch (a + b == b + a: summing the two directions' f_corr
             # contributions at the join gives the bits the shared accumulator got in either arrival order)
-            fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device) if (fk.two or di == 0) else fc[0])
+            # (two streams: each direction has its own accumulator and writes every (clip, frame) row exactly once -- no
+            #  zero fill, the attention kernel stores instead of accumulating)
+            fc.append(_new((b, t, Cc), xu) if fk.two else (torch.zeros((b, t, Cc), dtype=torch.float32, device=xu.device) if di == 0 else fc[0]))
             scr.append((_new((b, Cc), xu), _new((Mb // 32, Cc), xu), _new((b, 128), xu)))
     memo = [memo0, memo0]
     catte = _new((b, Cc), xu) if taps is not None else None
@@ -664,7 +666,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
                     gemm(memo[di], d['f1'].w, f1, Mb, Cc, Cc, shift=d['f1'].shift, relu=True)
                     _call('grl_sqdiff_mean', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
                 _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-                      ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+                      ptr(catte), ptr(fcorr.view(b * t, Cc)[ti:]), t * Cc, 0 if fk.two else 1, b, Cc, d['w1'].shape[0], ptr(hid))
                 if taps is not None:
                     taps.setdefault(('fwd', 'bwd')[di] + '_catte', []).append(catte.clone())
             with fk.on(di):                                     # the recurrence
@@ -907,7 +909,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
             y = _newb((b * t * PIX, Cc), x)
             gemm(xc, d['f2'].wb(), y, b * t * PIX, Cc, Cc, shift=d['f2'].shift, relu=True, math=MATH_BF16S)
             f2.append(y)
-            fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device) if (fk.two or di == 0) else fc[0])
+            fc.append(_new((b, t, Cc), x) if fk.two else (torch.zeros((b, t, Cc), dtype=torch.float32, device=x.device) if di == 0 else fc[0]))
             scr.append((_new((b, Cc), x), _new((b, 128), x)))
     memo = [memo0, memo0]
 
@@ -930,7 +932,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
         else:
             _call('grl_sqdiff_mean_bf16', ptr(f1), ptr(f2[di][ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
         _call('grl_channel_atte', ptr(dvec), ptr(d['w1']), ptr(d['w2t']), ptr(gapc[ti:]), t * Cc,
-              None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, d['w1'].shape[0], ptr(hid))
+              None, ptr(fc[di].view(b * t, Cc)[ti:]), t * Cc, 0 if fk.two else 1, b, Cc, d['w1'].shape[0], ptr(hid))
 
     def f1_branch(di, d, ti):
         f1_tail(di, d, ti, *f1_gemm(di, d, ti))

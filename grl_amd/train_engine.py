@@ -1107,7 +1107,7 @@ def trl_train(tp, model, xu, xc, b, t):
     # Each direction applies f1 and its bottleneck t times with the same weights: the operands of their weight gradients
     # are stacked step by step (_WgradStack) and every layer gets ONE product over t * Mb rows.  stk[di] = stacks of
     # (f1, conv1, conv2, conv3); f1's input stack is the memo sequence memo_0 .. memo_t (t + 1 blocks).
-    stk = []
+    stk, att = [], []
     for di, (_, _, _, blk) in enumerate(dirs):
         with fk.on(di):
             fc.append(torch.zeros((b, t, Cc), dtype=torch.float32, device=tp.dev) if (fk.two or di == 0) else fc[0])
@@ -1119,6 +1119,9 @@ def trl_train(tp, model, xu, xc, b, t):
                 stk.append(None)
                 memo_d.append(_newl((Mb, Cc), xu))
             _call(_k('grl_temporal_mean', xu), ptr(xu), ptr(memo_d[di]), b, t, frame)
+            # (the channel-attention MLP is applied t times per direction with the same two weights: its operands are
+            #  stacked like the recurrence's -- 2 x 2 weight-gradient products per direction instead of 2 x 2 x t tiny ones)
+            att.append(dict(dvec=_new((t * b, Cc), xu), hid=_new((t * b, 128), xu), ds=None, dhp=None, left=t) if WGRAD_STACK else None)
     memo = list(memo_d)
     for i in range(t):
         for di, (f1m, _, mlp, blk) in enumerate(dirs):
@@ -1127,10 +1130,11 @@ def trl_train(tp, model, xu, xc, b, t):
                 ti = i if di == 0 else t - 1 - i
                 sk = stk[di]
                 f1 = biased_conv_relu(tp, memo[di], Mb, f1m[0], wstack=(sk[0], i) if sk else None)
-                dvec = _new((b, Cc), xu)
+                at = att[di]
+                dvec = at['dvec'][i * b:(i + 1) * b] if at else _new((b, Cc), xu)
                 f2t = f2[di]
                 _call(_k('grl_sqdiff_mean', f1), ptr(f1), ptr(f2t[ti * PIX:]), ptr(dvec), b, PIX, Cc, t * frame)
-                hid = _new((b, 128), xu)
+                hid = at['hid'][i * b:(i + 1) * b] if at else _new((b, 128), xu)
                 catte = _new((b, Cc), xu)
                 w1, w2 = mlp[0].weight, mlp[2].weight
                 w2t = tp.w_t(w2.detach(), w2)                   # [128][2048]
@@ -1139,20 +1143,28 @@ def trl_train(tp, model, xu, xc, b, t):
                       ptr(catte), ptr(fcd.view(b * t, Cc)[ti:]), t * Cc, 1, b, Cc, 128, ptr(hid))
 
                 def bwd_atte(f1=f1, f2t=f2t, ti=ti, dvec=dvec, hid=hid, catte=catte, w1=w1, w2=w2, w2t=w2t, fcd=fcd,
-                             gap_al=gap_al):
+                             gap_al=gap_al, at=at, i=i):
                     dfc = tp.g.get(id(fcd))
                     if dfc is None:
-                        return
-                    ds = _new((b, Cc), xu)
+                        return                  # (the same for every step of the direction: nothing is left half-stacked)
+                    if at and at['ds'] is None:
+                        at['ds'], at['dhp'] = _new((t * b, Cc), xu), _new((t * b, 128), xu)
+                    ds = at['ds'][i * b:(i + 1) * b] if at else _new((b, Cc), xu)
                     dgap = tp.full_grad(gap_al)
                     _call('grl_catte_bwd', ptr(dfc.view(b * t, Cc)[ti:]), t * Cc, ptr(gapc[ti:]), t * Cc,
                           ptr(catte), ptr(ds), ptr(dgap[ti:]), t * Cc, 1, b, Cc)
                     dhid = _new((b, 128), xu)
                     gemm(ds, w2t, dhid, b, 128, Cc)
-                    wgrad(ds, hid, tp.pgrad(w2), b, Cc, 128)
-                    dhp = _new((b, 128), xu)
+                    dhp = at['dhp'][i * b:(i + 1) * b] if at else _new((b, 128), xu)
                     _call('grl_relu_bwd', ptr(dhid), ptr(hid), ptr(dhp), dhid.numel(), 0)
-                    wgrad(dhp, dvec, tp.pgrad(w1), b, 128, Cc)
+                    if not at:
+                        wgrad(ds, hid, tp.pgrad(w2), b, Cc, 128)
+                        wgrad(dhp, dvec, tp.pgrad(w1), b, 128, Cc)
+                    else:
+                        at['left'] -= 1
+                        if at['left'] == 0:
+                            wgrad(at['ds'], at['hid'], tp.pgrad(w2), t * b, Cc, 128)
+                            wgrad(at['dhp'], at['dvec'], tp.pgrad(w1), t * b, 128, Cc)
                     dd = _new((b, Cc), xu)
                     gemm(dhp, tp.w_t(w1.detach(), w1), dd, b, Cc, 128)
                     # through d = mean (f1 - f2)^2

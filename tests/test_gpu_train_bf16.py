@@ -694,8 +694,8 @@ def test_trl_stacked_weight_gradients_equal_per_step_products(golden, math, only
     """train_engine.WGRAD_STACK (round 5): the TRL recurrences apply f1 and their bottleneck T times with the same weights;
     the operands of the T weight gradients are row blocks of one buffer and dW is one product over T * B * 128 rows.  Same
     sums in another order: the forward and every activation gradient are bit-identical (the stacks only move buffers),
-    the parameter gradients agree to 2e-4 relative L2 (fp32 accumulation, bf16s too) -- and 24 + 24 launches of the
-    weight-gradient kernels and their slab reductions become 6 + 6.  ``only_corr``: only f_corr carries a gradient, so the
+    the parameter gradients agree to 2e-4 relative L2 (fp32 accumulation, bf16s too) -- and 48 + 48 launches of the
+    weight-gradient kernels and their slab reductions (recurrence 24, channel-attention MLP 16 ... per T = 4) become 12 + 12.  ``only_corr``: only f_corr carries a gradient, so the
     LAST step's bottleneck of each direction gets none -- its block of the stack must count as zeros, not stall the product."""
     from grl_amd import train_engine as TE
     from grl_amd.synthetic import synth_clips_structured
@@ -726,7 +726,7 @@ def test_trl_stacked_weight_gradients_equal_per_step_products(golden, math, only
         TE.WGRAD_STACK = True
         TE.set_math(old)
     torch.cuda.synchronize()
-    assert launches[1] - launches[0] == 2 * 4 * (T - 1), launches
+    assert launches[1] - launches[0] == 2 * (4 + 2) * (T - 1), launches      # per direction: f1 + three convs + the attention MLP's two layers
     assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
     live = [str(k) for k in golden('grl_train_cond_b8t4.npz')['meta.keys']]
     worst = 0.0

@@ -751,9 +751,17 @@ def _conv_b16(x, c, n_img, H, W, stride=1, relu=True, res=None, **kw):
     return y, Ho, Wo
 
 
+FUSE_TAIL_L23 = os.environ.get('GRL_FUSE_TAIL_L23', '0') != '0'   # the layer 2 -> 3 tail (P 128, 4P 512, P' 256) fused too: measured slower
+
+
 def _bneck_tail_ok(c3, c1n, M):
     # (the fused kernels address with 32-bit byte offsets: M * C4 * 2 bytes must stay below 4 GiB, else the per-conv
     #  launches -- 64-bit row addressing -- take the block)
+    # (round 5: the P' = 256 variant -- layer 2's last block + layer 3's first conv1 -- runs 263 us against 240 us for the
+    #  two launches it replaces (tools/bneck_tail_ab.py): a 256-wide second product leaves the kernel neither the
+    #  registers (spills in its chunk loop at 16 waves) nor the occupancy; it stays available behind GRL_FUSE_TAIL_L23=1)
+    if (c3.K, c3.N, c1n.N) == (128, 512, 256) and not FUSE_TAIL_L23:
+        return False
     return (c3.k == 1 and c1n.k == 1 and c1n.K == c3.N and M * c3.N * 2 < (1 << 32) and
             bool(_lib.load().grl_bottleneck_tail_bf16_supported(c3.K, c3.N, c1n.N)))
 

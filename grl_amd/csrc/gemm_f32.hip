@@ -1476,6 +1476,10 @@ TileChoice legacy_tile(const GrlGemm& d) {
     if (wide_on && !bnz_narrow && (!d.stats || d.bn_z) && (d.math == GRL_MATH_F32 || (wide3_on && d.math != GRL_MATH_BF16S)) && d.N >= 128 &&
         tiles(128, 128) >= (d.conv ? 448 : 256) && !(d.res && d.K <= (d.stats ? 128 : 512)))     // (conv with 256..447 wide tiles: 512+ tiles of 128 x 64 -- 16384x256x2304: 159 -> 152 us)
         return {128, 128};
+    // (round 5, per shape with grl_gemm_force_tile: the K <= 128 expansion layer that carries a residual and fills the chip
+    //  with wide tiles -- 65536x512x128 +res: 64x64 140.7, 128x64 129.4, 128x128 125.7 us; 262144x256x64 +res 188.8 / 174.2 /
+    //  167.9 -- eval form only: the statistics GEMMs' tile is part of their partial sums' order)
+    if (d.K <= 128 && d.res && !d.stats && d.math == GRL_MATH_F32 && d.N >= 128 && tiles(128, 128) >= 448) return {128, 128};
     if (d.K <= 128) return {64, 64};
     // (round 4, re-measured per shape with grl_gemm_force_tile after the hand-scheduled loop: a residual-carrying K <= 512
     // layer is better off on the 128 x 64 tile, which requests its residual rows before the LDS round trip -- 16384x2048x512

@@ -556,75 +556,7 @@ def distmat_bench(args, dev, rank):
                                        "frac": round(flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}}))
 
 
-EXIT_TRAIN_BLOCK_FAILED = 3
-
-
-class TrainBlockGuard(object):
-    """N > 1: the `train` block is the only part of the line with collectives in it.  The headline must not depend on
-    them, and a hung or failed all-reduce step must be VISIBLE in the launcher's exit code: rank 0 prints the line
-    with `train: {"error": ...}` and every rank then leaves with EXIT_TRAIN_BLOCK_FAILED (never 0, never a re-exec:
-    these processes have touched the GPU; a retry, if any, is a fresh `bench.py --gpus N` from the GPU-less parent).
-
-    The ranks of one node tell each other through two files in the temp directory (keyed by the rendezvous port):
-    `.err` = some rank's block raised or timed out (its text is the reason), `.out` = rank 0 has printed the line.
-    A watchdog thread per rank polls them, so a healthy rank that sits in a collective whose peer has failed leaves
-    within a second instead of waiting for the time limit -- but only after rank 0 has printed."""
-
-    def __init__(self, rank, world, limit, emit_error_line, tag='train'):
-        import tempfile
-        self.rank, self.world, self.limit, self.emit_error_line = rank, world, limit, emit_error_line
-        # (GRL_BENCH_NONCE: set per launch by launch_ranks -- with a reused port / run id a rank could otherwise read the
-        #  .err file of an EARLIER failed run; bare torchrun launches fall back to the launcher's pid, shared by its ranks)
-        key = 'grl_bench_%s_%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'),
-                                         os.environ.get('GRL_BENCH_NONCE') or os.getppid(), tag)
-        self.err = os.path.join(tempfile.gettempdir(), key + '.err')
-        self.out = os.path.join(tempfile.gettempdir(), key + '.out')
-        self.done = threading.Event()
-        self.lock = threading.Lock()
-        self.thread = None
-
-    def start(self):
-        if self.world > 1:
-            if self.rank == 0:
-                for f in (self.err, self.out):
-                    with contextlib.suppress(OSError):
-                        os.remove(f)
-            self.thread = threading.Thread(target=self._watch, daemon=True)
-            self.thread.start()
-
-    def _watch(self):
-        t0 = time.time()
-        while not self.done.wait(0.25):
-            if os.path.exists(self.err):
-                with contextlib.suppress(OSError):
-                    self.leave(open(self.err).read() or 'a rank failed')
-            if time.time() - t0 > self.limit:
-                self.leave("train block (RCCL all-reduce step) did not finish within %.0f s on rank %d" % (self.limit, self.rank))
-
-    def leave(self, reason):
-        """Publish the reason, let rank 0 print the line, exit non-zero.  Called from the watchdog thread (peer
-        failed / time limit) or from the main thread (this rank's block raised)."""
-        with self.lock:
-            if self.done.is_set():
-                return
-            if not os.path.exists(self.err):
-                with contextlib.suppress(OSError):
-                    with open(self.err, 'w') as fh:
-                        fh.write(reason)
-            if self.rank == 0:
-                self.emit_error_line(reason)
-                with contextlib.suppress(OSError):
-                    open(self.out, 'w').close()
-            else:
-                t0 = time.time()
-                while not os.path.exists(self.out) and time.time() - t0 < 20:
-                    time.sleep(0.1)
-            sys.stderr.write('bench.py rank %d: %s -- exit %d\n' % (self.rank, reason, EXIT_TRAIN_BLOCK_FAILED))
-            sys.stderr.flush()
-            os._exit(EXIT_TRAIN_BLOCK_FAILED)
-
-    def finished(self):
-        self.done.set()
+from grl_amd.rank_guard import EXIT_TRAIN_BLOCK_FAILED, TrainBlockGuard   # noqa: E402 (no torch, no GPU: files + a thread)
 
 
 def run_guarded(guard, world, fn):

@@ -34,6 +34,7 @@ struct GrlGemm;
 int grl_gemm_bf16_256(const GrlGemm& d, hipStream_t s);
 bool grl_gemm_bf16_256_takes(const GrlGemm& d);        // would it?  (same predicate)
 int grl_gemm_bf16_256_stat_rows(const GrlGemm& d);     // rows of the statistics slab it writes (2 per 256-row tile)
+int grl_gemm_validate(const GrlGemm& d);               // gemm_f32.hip: the argument checks of grl_conv_gemm_f32 (GRL_OK or grl_fail)
 
 // train.hip: BatchNorm-backward finalize over an fp32 partial slab (shared with the bf16-storage kernels of train_bf16.hip)
 int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,

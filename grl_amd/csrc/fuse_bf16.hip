@@ -53,9 +53,14 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 // lgkmcnt wait it inserts becomes (0), so a DMA issued inside the steady-state loop serialises the loop's residual-load
 // ring and its fragment reads.  Issued this way the compiler's counted waits only ever over-wait (the hidden pieces are
 // extra outstanding operations), and the kernel waits for the pieces itself in front of the chunk barrier.
+// ("m0" is on the clobber list: the statement overwrites it, and the compiler keeps its own LDS-DMA / indexing state there.
+//  hipcc accepts the clobber with a -Winline-asm note about reserved registers, silenced for these statements only.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16_hidden(const char* sbase, uint32_t voff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // rows (16 lanes) 1 and 3 of `a` trade places with rows 0 and 2 of `b`
 __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {

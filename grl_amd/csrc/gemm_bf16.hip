@@ -271,7 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                     for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(p.shift + cn + 4 * u);
                 }
             }
-            const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+            float relu_floor;      // 0 (ReLU) or a quiet NaN (no ReLU: v_max returns the other operand, a NaN accumulator stays NaN);
+            {                       // through an asm move: told the constant, hipcc folds max(t, NaN) into a select per element
+                const uint32_t floor_bits = p.relu ? 0u : 0x7fc00000u;
+                asm("v_mov_b32 %0, %1" : "=v"(relu_floor) : "s"(floor_bits));
+            }
             __bf16* yrow = SQD ? nullptr : y16 + (int64_t)(cm0 + lrow) * p.ldy + cn;
             const int64_t ystep = (int64_t)8 * p.ldy;
             f32x4 ssum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -381,7 +385,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, 
                                 float tt = v[e];
                                 if constexpr (RES) tt = tt + (float)res8[i % NB][it][4 * u + e];
                                 else tt = tt + 0.f;
-                                // ReLU as ONE v_max against 0 / -inf (was v_cmp + v_cndmask + s_or per element; v_max_f32
+                                // ReLU as ONE v_max against 0 / NaN (v_max returns the other operand for a quiet NaN: no ReLU = identity,
+                                // and a NaN accumulator stays NaN as in the edge tiles' select; was v_cmp + v_cndmask + s_or per element; v_max_f32
                                 // orders -0 < +0, so max(t, +0) == (t > 0 ? t : 0) bit for bit)
                                 tv[e] = __builtin_fmaxf(tt, relu_floor);
                             }

@@ -58,12 +58,17 @@ __device__ uint4 g_zero_row16[8];             // 128 zero bytes: source of out-o
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // LDS-DMA piece the compiler does not see: lane l's 16 bytes at sbase + voff land at lds + 16 * l
+// ("m0" is on the clobber list: the statement overwrites it, and the compiler keeps its own LDS-DMA / indexing state there.
+//  hipcc accepts the clobber with a -Winline-asm note about reserved registers, silenced for these statements only.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16(const char* sbase, uint32_t voff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16_v(const char* vaddr, uint32_t lds) {       // per-lane 64-bit address (conv gather)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // wave-uniform pointer held in SGPRs (the "s" operand of dma16 must not end up in a VGPR pair)
 template <class T> __device__ __forceinline__ T* uniform_ptr(T* q) {
@@ -447,7 +452,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                     for (int u = 0; u < 2; ++u) sh[u] = *reinterpret_cast<const f32x4*>(shift + cn + 4 * u);
                 }
             }
-            const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+            float relu_floor;      // 0 (ReLU) or a quiet NaN (no ReLU: v_max returns the other operand, a NaN accumulator stays NaN);
+            {                       // through an asm move: told the constant, hipcc folds max(t, NaN) into a select per element
+                const uint32_t floor_bits = p.relu ? 0u : 0x7fc00000u;
+                asm("v_mov_b32 %0, %1" : "=v"(relu_floor) : "s"(floor_bits));
+            }
             // residual rows: two 32-row blocks (8 x 1 KiB per wave) in flight -- block i+1 is requested before block i
             // goes through the slab
             bf16x8 res8[2][4];
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(const GrlGemm p,
                                         float tt = w_[e];
                                         if constexpr (RES) tt = tt + (float)res8[i & 1][it][4 * u + e];
                                         else tt = tt + 0.f;
-                                        o32[4 * u + e] = __builtin_fmaxf(tt, relu_floor);   // (ReLU: one v_max against 0 / -inf)
+                                        o32[4 * u + e] = __builtin_fmaxf(tt, relu_floor);   // (ReLU: one v_max against 0 / NaN = identity, NaN-preserving)
                                     }
                                 }
                                 *reinterpret_cast<bf16x8*>(y16 + (int64_t)m * p.ldy + cn) = __builtin_convertvector(o32, bf16x8);
@@ -660,6 +669,10 @@ int launch_variant(const GrlGemm& d, const Group& grp, hipStream_t s, int varian
 // launch of 256 x 128 tiles that fills the chip: 8192 x 512 x 2048 x 2: 2 x 35 us -> 44 us.
 extern "C" int grl_conv_gemm_f32_group(const GrlGemm* descs, int n, void* stream) {
     if (!descs || n < 1 || n > 4) return grl_fail(GRL_EINVAL, "gemm_group: 1..4 descriptors");
+    // every descriptor passes the single-launch checks BEFORE anything is grouped (the grouped path used to
+    // reach the DMA loader with null operands or K == 0; the fallback path validated, so the two accepted different inputs)
+    for (int g = 0; g < n; ++g)
+        if (const int e = grl_gemm_validate(descs[g])) return e;
     const GrlGemm& d0 = descs[0];
     bool same = true;
     for (int g = 1; g < n; ++g) {

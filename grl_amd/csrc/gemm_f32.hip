@@ -61,12 +61,17 @@ typedef __attribute__((address_space(3))) char* lds_cptr_t;
 // and every fragment read behind a drained queue.  Hidden, the pieces sit between the MFMAs and the loop waits for them
 // itself (`s_waitcnt vmcnt(0)` in front of the stage barrier); counted waits the compiler emits for its own loads only
 // ever over-wait.
+// ("m0" is on the clobber list: the statement overwrites it, and the compiler keeps its own LDS-DMA / indexing state there.
+//  hipcc accepts the clobber with a -Winline-asm note about reserved registers, silenced for these statements only.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16_hidden(const char* sbase, uint32_t voff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) {       // per-lane 64-bit address (the conv gather)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 __device__ uint4 g_zero_chunks[8];        // 128 zero bytes: LDS-DMA source of out-of-image conv taps
 
@@ -743,7 +748,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                             for (int r = 0; r < 16; ++r)
                                 Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * BN + wn * WTN + j * 32 + col_l] = acc[i][j][r];
                 };
-                const float relu_floor = p.relu ? 0.f : -__builtin_inff();      // bf16 storage: ReLU as one v_max
+                float relu_floor;      // 0 (ReLU) or a quiet NaN (no ReLU: v_max returns the other operand, a NaN accumulator stays NaN);
+            {                       // through an asm move: told the constant, hipcc folds max(t, NaN) into a select per element
+                const uint32_t floor_bits = p.relu ? 0u : 0x7fc00000u;
+                asm("v_mov_b32 %0, %1" : "=v"(relu_floor) : "s"(floor_bits));
+            }      // bf16 storage: ReLU as one v_max
                 const bool relu = p.relu != 0;
                 auto run = [&](auto has_res_, auto bnz_) {
                     constexpr bool HAS_RES = decltype(has_res_)::value;
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, co
                                         float t = v[e];
                                         if constexpr (HAS_RES) t = t + (float)r8[c & 1][k][4 * u + e];
                                         else t = t + 0.f;
-                                        // ReLU: one v_max against 0 / -inf (v_max_f32 orders -0 < +0: == (t > 0 ? t : 0) bit for bit)
+                                        // ReLU: one v_max against 0 / NaN (no ReLU: v_max(t, NaN) == t, NaN stays NaN; v_max_f32 orders -0 < +0: == (t > 0 ? t : 0) bit for bit)
                                         tv[e] = __builtin_fmaxf(t, relu_floor);
                                     }
                                     if constexpr (BNZ) {
@@ -1679,6 +1688,8 @@ extern "C" int grl_conv_gemm_f32_stat_rows(const GrlGemm* desc) {
     const int rows_per = t.smode == 1 ? 64 : t.bm;          // (smode 1: the 64 x 64 tile's slab, one row per 64 rows)
     return (desc->M + rows_per - 1) / rows_per;
 }
+
+int grl_gemm_validate(const GrlGemm& d) { return validate(d); }      // (common.h: the grouped entry point checks every descriptor)
 
 extern "C" int64_t grl_conv_gemm_f32_workspace_floats(const GrlGemm* desc) {
     return desc ? splitk_floats(*desc) : 0;

@@ -1091,6 +1091,8 @@ extern "C" int grl_stem_pool_f32(const void* x, int x_is_u8, const float* mean_s
     GRL_REQUIRE(W == 2 * FP_TW && H % 4 == 0, "stem_pool_f32: needs W == 128 and H % 4 == 0");
     GRL_REQUIRE(!x_is_u8 || mean_std, "stem_pool_f32: u8 input needs mean_std");
     GRL_REQUIRE(((uintptr_t)x & 7) == 0 || x_is_u8, "stem_pool_f32: x must be 8-byte aligned");
+    GRL_REQUIRE(!x_is_u8 || ((uintptr_t)x & 1) == 0, "stem_pool_f32: u8 input must be 2-byte aligned (2-byte row loads)");
+    GRL_REQUIRE(n <= 65535, "stem_pool_f32: at most 65535 frames per launch (gridDim.y)");
     const int Hp = H / 4;
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)stem_pool_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS);

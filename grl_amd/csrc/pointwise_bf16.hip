@@ -748,6 +748,8 @@ extern "C" int grl_stem_pool_bf16(const void* x, int x_is_u8, const float* mean_
     GRL_REQUIRE(x && scale && shift && y && wp && n > 0, "stem_pool_bf16: null/empty");
     GRL_REQUIRE(W == 2 * SP_TW && H % 4 == 0, "stem_pool_bf16: needs W == 128 and H % 4 == 0");
     GRL_REQUIRE(!x_is_u8 || mean_std, "stem_pool_bf16: u8 input needs mean_std");
+    GRL_REQUIRE(!x_is_u8 || ((uintptr_t)x & 1) == 0, "stem_pool_bf16: u8 input must be 2-byte aligned (2-byte row loads)");
+    GRL_REQUIRE(n <= 65535, "stem_pool_bf16: at most 65535 frames per launch (gridDim.y)");
     const int Ho = H / 2;
     const size_t lds = (size_t)(128 + 64) * SB_ROWB + (size_t)SP_PATCH * sizeof(__bf16);
     static const bool attr = [] {

@@ -864,9 +864,14 @@ __device__ uint4 g_wgrad_zero_chunk;       // 16 zero bytes: LDS-DMA source of r
 typedef __attribute__((address_space(3))) char* lds_cptr_t;
 // LDS-DMA piece hipcc does not see (see gemm_f32.hip: a VISIBLE global_load_lds makes every later LDS read wait vmcnt(0));
 // the loop waits for its pieces itself in front of the stage barrier
+// ("m0" is on the clobber list: the statement overwrites it, and the compiler keeps its own LDS-DMA / indexing state there.
+//  hipcc accepts the clobber with a -Winline-asm note about reserved registers, silenced for these statements only.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16_hidden_v(const char* vaddr, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 #ifndef GRL_WGRAD_KO
 #define GRL_WGRAD_KO 0      // timing-only knock-outs (1: no in-loop staging, 2: no slab store); wrong results
 #endif

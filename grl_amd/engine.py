@@ -451,13 +451,19 @@ def _to_nchw(y, n, H, W):
     return y.view(n, H, W, -1).permute(0, 3, 1, 2)
 
 
+def _stem_pool_ok(x, n):
+    """what grl_stem_pool_{f32,bf16} require beyond the frame geometry (one grid row per frame; 2-byte loads of u8
+    rows, 8-byte loads of fp32 rows): otherwise the two-launch stem + max-pool path takes the batch"""
+    return n <= 65535 and x.data_ptr() % (2 if x.dtype == torch.uint8 else 8) == 0
+
+
 def trunk_eval(plan, x, taps=None):
     """x [n,3,H,W] NCHW -> channels-last [n*16*8][2048] (for 256x128 input)."""
     n, _, H, W = x.shape
     Hs, Ws = H // 2, W // 2
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
-    if FUSE_STEM_POOL_F32 and taps is None and W == 128 and H % 4 == 0:
+    if FUSE_STEM_POOL_F32 and taps is None and W == 128 and H % 4 == 0 and _stem_pool_ok(x, n):
         # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_f32)
         u8 = x.dtype == torch.uint8
         _call('grl_stem_pool_f32', ptr(x), 1 if u8 else 0, ptr(input_mean_std(x.device)) if u8 else None,
@@ -618,6 +624,11 @@ class _TrlFork(object):
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.main.wait_event(ev)
+                if st is not self.side:
+                    # blocks the attention streams read / write were allocated on the DIRECTION streams: once `held`
+                    # is dropped the allocator may hand a side-stream block to the side stream's next launch, so the
+                    # side stream is ordered behind the attention streams as well (main already is)
+                    self.side.wait_event(ev)
             for x in side_tensors:
                 x.record_stream(self.main)
             self.held = []
@@ -829,7 +840,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     Hs, Ws = h // 2, w // 2
     H, W = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _newb((n * H * W, 64), x)
-    if FUSE_STEM_POOL and taps is None and w == 128 and h % 4 == 0:
+    if FUSE_STEM_POOL and taps is None and w == 128 and h % 4 == 0 and _stem_pool_ok(x, n):
         # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_bf16)
         u8 = x.dtype == torch.uint8
         _call('grl_stem_pool_bf16', ptr(x), 1 if u8 else 0, ptr(input_mean_std(x.device)) if u8 else None,

@@ -233,6 +233,8 @@ class Tape(object):
         self.bnrec = {}         # id(activation of a conv_bn) -> _BNRec: what its BatchNorm backward needs (fused reduce)
         self.fuse_ok = set()    # ids of activations whose ONLY consumers are conv_bn ops (as input or residual)
         self.prep_event = None  # WeightPrep launched on the side stream: the launch stream joins it before layer 1
+        self.stacks = []        # _WgradStack objects / stacked attention-MLP records of this tape: each must be drained
+                                # (left == 0) or untouched when the backward ends, or a weight gradient was silently dropped
         self.foreign = {}       # storage data_ptr -> tensor: gradient buffers the tape does NOT own exclusively (handed in by
                                 # autograd, or registered for more than one forward tensor): never masked / overwritten
                                 # in place.  The tensors are held so that the address cannot be recycled within the step.
@@ -435,6 +437,14 @@ class Tape(object):
             _in_backward[0] = was
         self.wgrad_join()
         self.ops = _Ops(self)
+        # a stacked weight gradient is issued by the closure that fills the LAST block: a backward that skipped one of the
+        # closures (a partial re-run, a closure that returned early) would drop dW of that layer without an error
+        for st in self.stacks:
+            left, steps = (st['left'], st['steps']) if isinstance(st, dict) else (st.left, st.steps)
+            if left != 0 and left != steps:
+                raise _lib.GrlHipError('Tape.backward: a stacked weight gradient was left with %d of %d blocks unfilled -- '
+                                       'its dW was never issued' % (left, steps))
+        self.stacks = []
 
 
 STEM_WGRAD_FUSED = os.environ.get('GRL_STEM_WGRAD_FUSED', '1') != '0'   # A/B and tests only
@@ -585,6 +595,7 @@ class _WgradStack(object):
         return self.x[:self.steps * self.rows_in]
 
 
+ADOPT_STATS = [0, 0]       # residual-branch gradients adopted in place / copied (Tape.owns said 'foreign'); tests read it
 WGRAD_STACK = os.environ.get('GRL_WGRAD_STACK', '1') != '0'             # A/B and tests only
 
 
@@ -665,7 +676,9 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
             if gres is None:
                 # first contribution to grad(res): it IS the masked da -- the reduce pass of grl_bn_bwd masks da in
                 # place (gres == dy) and this tape entry adopts the buffer (da was popped: nobody else reads it)
-                gres = tp.g[id(res)] = da if (relu and tp.owns(da)) else _newl((M, N), da)
+                adopt = relu and tp.owns(da)
+                ADOPT_STATS[0 if adopt else 1] += 1
+                gres = tp.g[id(res)] = da if adopt else _newl((M, N), da)
             _bn_use(tp, res, -1)
         if rec is not None and rec.slab is not None:
             # the GEMM that completed grad(a) masked it and left the two column sums (rec.slab): finalize + apply only
@@ -1121,7 +1134,9 @@ def trl_train(tp, model, xu, xc, b, t):
             _call(_k('grl_temporal_mean', xu), ptr(xu), ptr(memo_d[di]), b, t, frame)
             # (the channel-attention MLP is applied t times per direction with the same two weights: its operands are
             #  stacked like the recurrence's -- 2 x 2 weight-gradient products per direction instead of 2 x 2 x t tiny ones)
-            att.append(dict(dvec=_new((t * b, Cc), xu), hid=_new((t * b, 128), xu), ds=None, dhp=None, left=t) if WGRAD_STACK else None)
+            att.append(dict(dvec=_new((t * b, Cc), xu), hid=_new((t * b, 128), xu), ds=None, dhp=None, left=t, steps=t) if WGRAD_STACK else None)
+            if WGRAD_STACK:
+                tp.stacks.extend(stk[di] + (att[di],))
     memo = list(memo_d)
     for i in range(t):
         for di, (f1m, _, mlp, blk) in enumerate(dirs):

@@ -438,6 +438,36 @@ def test_gemm_bf16_storage(dev, M, N, K, conv):
     assert torch.equal(y, y32.bfloat16())                               # one rounding on the store
 
 
+@pytest.mark.parametrize('M,N,K', [(4096 + 77, 512 + 40, 1024), (600, 200, 256)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_gemm_bf16_storage_nan_accumulator(dev, M, N, K, relu):
+    """the bf16-storage epilogues apply ReLU as one v_max against a floor.  Without ReLU a NaN accumulator
+    (a diverged data-gradient GEMM) must come out as NaN in the interior fast path exactly as in the edge tiles' select
+    (round 5 stored -inf there: floor -inf; now the floor is a quiet NaN, v_max returns the other operand); with ReLU
+    both paths give 0, as `t > 0 ? t : 0` always did.  Shapes: interior + ragged tiles of the 256x256 kernel and of the
+    128-row family; every other element equals the run without the poisoned row."""
+    from grl_amd import engine
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).bfloat16().to(dev)
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).bfloat16().to(dev)
+    sh = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    clean = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    engine.gemm(a, w, clean, M, N, K, shift=sh, relu=relu, math=2)
+    bad_rows = [3, 131, M - 1]                                             # first tile, an interior one, the ragged last
+    a2 = a.clone()
+    a2[bad_rows, 7] = float('nan')
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    engine.gemm(a2, w, y, M, N, K, shift=sh, relu=relu, math=2)
+    yb = y[bad_rows].float()
+    if relu:
+        assert bool((yb == 0).all())
+    else:
+        assert bool(torch.isnan(yb).all()), 'a NaN accumulator left the no-ReLU epilogue as %r' % yb.flatten()[:4].tolist()
+    keep = torch.ones(M, dtype=torch.bool, device=dev)
+    keep[bad_rows] = False
+    assert torch.equal(y[keep], clean[keep])
+
+
 @pytest.mark.parametrize('M,N,K,conv', [
     (512, 256, 2048, None), (300, 200, 256, None), (129, 72, 64, None), (5000, 136, 320, None), (8192, 512, 128, None),
     (5 * 16 * 8, 128, 9 * 64, (16, 8, 64, 16, 8, 3, 3, 1, 1)), (3 * 8 * 8, 96, 9 * 128, (16, 16, 128, 8, 8, 3, 3, 2, 1)),

@@ -140,6 +140,48 @@ def test_evaluator_matches_reference_golden(golden):
     assert _rel(e ** 2, g['euclid_dense'] ** 2) < 1e-5
 
 
+def test_gpu_ranking_against_the_reference_index_fixtures(golden, capsys):
+    """Verdict r5 item 1: the DEVICE ranking (grl_conv_gemm_f32 NEGDOT / EUCLID epilogue + grl_row_argsort)
+    against the reference's OWN rankings stored in the fixture -- ``indices`` (cosin_dist,
+    attevaluator.py:44-46), ``idx_dense`` (the non-unit-norm dense mode, attevaluator.py:84,95) and
+    ``idx_dense_euclid`` (pairwise_distance_tensor, attevaluator.py:33-41), each np.argsort'ed as
+    eva_functions.py:139 does.  Contract (tests/ranking_check.py): positions may differ only where the
+    reference's own distances of the two entries are within 3e-5 (neighbour swaps below fp32 noise), an
+    entry moves at most 3 places, and no query's CMC / AP input changes.  The mismatch counts are printed."""
+    from grl_amd import engine
+    from grl_amd.reid.evaluator.eva_functions import evaluate
+    import ranking_check as R
+    g = golden('evaluator_q40_g400.npz')
+    qf, gf, qp, qc, gp, gc = synth_eval_features(40, 400, seed=1, n_ids=24, noise=7.0)
+    qd, gd, qpd, qcd, gpd, gcd = R.dense_case(qf, gf, qp, qc, gp, gc)
+    cases = [
+        ('cosine  40x400 (indices)', engine.cosin_dist(qf.cuda(), gf.cuda()), g['indices'], g['dist'], qp, gp, qc, gc),
+        ('cosine  dense 20x220 (idx_dense)', engine.cosin_dist(qd.cuda(), gd.cuda()), g['idx_dense'], g['dist_dense'],
+         qpd, gpd, qcd, gcd),
+        ('euclid  dense 20x220 (idx_dense_euclid)', engine.pairwise_distance_tensor(qd.cuda(), gd.cuda()),
+         g['idx_dense_euclid'], g['euclid_dense'], qpd, gpd, qcd, gcd),
+    ]
+    report = []
+    for name, dmat, ref_idx, ref_dist, a, b, c, d in cases:
+        idx_dev = engine.rank_rows(dmat)                                    # device argsort of the device matrix
+        ours = idx_dev.cpu().numpy()
+        assert np.array_equal(ours, np.argsort(dmat.cpu().numpy(), axis=1, kind='stable'))
+        r = R.compare(ours, ref_idx, ref_dist, a, b, c, d, tol=3e-5)
+        report.append((name, r))
+        # and the metric computed ON THE DEVICE from the device ranking equals the one the reference's
+        # ranking gives on the host
+        cmc_ref, map_ref = evaluate(ref_dist, a, b, c, d, indices=ref_idx.astype(np.int64))
+        cmc_dev, map_dev = evaluate(None, a, b, c, d, indices=idx_dev)
+        assert np.array_equal(cmc_dev, cmc_ref) and abs(map_dev - map_ref) < 1e-12
+    with capsys.disabled():
+        for name, r in report:
+            print('\n[ranking vs reference] %-40s %d of %d positions differ (%d rows), worst reference gap %.2e, '
+                  'max shift %d, queries with a changed CMC/AP input: %d'
+                  % (name, r['differ'], r['positions'], r['rows_touched'], r['worst_ref_gap'], r['max_shift'],
+                     r['metric_changes']))
+    assert sum(r['differ'] for _, r in report) <= 16
+
+
 def test_evaluator_full_mars_size_properties():
     """BASELINE config 5: 1980 x 11310 x 6144.  Bit-exact against the C oracle on a
     row sample, symmetry D(q,g) == D(g,q)^T, self-distance and Euclid/-dot
@@ -188,6 +230,30 @@ def _fresh_cnn_conditioned():
         cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
     cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'))
     return cnn.cuda()
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16s'])
+def test_default_step_adopts_every_residual_gradient_in_place(math):
+    """Tape.owns() keys on storage identity; a tape-owned gradient that shared a storage with a foreign
+    tensor would silently lose in-place adoption (a perf cliff, not a wrong result).  On the default step every one of
+    the 16 trunk + 2 x T TRL residual blocks must adopt (grad(res) = the masked da buffer, no copy), and every stacked
+    weight gradient must have been issued (Tape.backward raises otherwise)."""
+    from grl_amd import train_engine as TE
+    from grl_amd.synthetic import synth_clips_structured
+    cnn = _fresh_cnn_conditioned()
+    cnn.train()
+    old = TE.set_math(math)
+    try:
+        TE.ADOPT_STATS[:] = [0, 0]
+        xu, xc = cnn(synth_clips_structured(4, 4, seed=3).cuda())
+        (xu.sum() + xc.sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        TE.set_math(old)
+    adopted, copied = TE.ADOPT_STATS
+    assert copied == 0 and adopted >= 16 + 2 * 4, TE.ADOPT_STATS
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for n, p in cnn.named_parameters()
+               if 'temporal_learning_block' in n and n.endswith('conv1.weight'))
 
 
 @pytest.mark.parametrize('fname,math', [('grl_train_cond_b8t4.npz', 'f32'), ('grl_train_cond_b8t4.npz', 'mixed'),

@@ -116,6 +116,18 @@ def test_evaluator_matches_reference(golden):
     resorted = np.take_along_axis(g['dist'], np.argsort(chain, axis=1), 1)
     assert (resorted[:, :-1] - resorted[:, 1:]).max() <= 3e-5
     assert (np.argsort(chain, axis=1) != g['indices']).mean() < 1e-3
+    # the same contract the -m gpu test holds the device to (tests/ranking_check.py), on the chain model:
+    import ranking_check as R
+    r = R.compare(np.argsort(chain, axis=1, kind='stable'), g['indices'], g['dist'], qp, gp, qc, gc)
+    assert r['differ'] <= 8 and r['metric_changes'] == 0
+    qd2, gd2, qpd, qcd, gpd, gcd = R.dense_case(qf, gf, qp, qc, gp, gc)
+    r = R.compare(np.argsort(-O.fma_chain_dot(qd2.numpy(), gd2.numpy()), axis=1, kind='stable'),
+                  g['idx_dense'], g['dist_dense'], qpd, gpd, qcd, gcd)
+    assert r['differ'] <= 8
+    # the reference's Euclidean ranking of the dense case is consistent with its own matrix
+    r = R.compare(np.argsort(g['euclid_dense'], axis=1, kind='stable'), g['idx_dense_euclid'], g['euclid_dense'],
+                  qpd, gpd, qcd, gcd)
+    assert r['worst_ref_gap'] == 0.0
 
 
 def test_losses_match_reference(golden):

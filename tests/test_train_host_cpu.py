@@ -257,6 +257,79 @@ def test_bench_train_block_failure_is_visible_in_the_exit_code(fault):
     assert ('did not finish' in line['train']['error']) if fault == 'hang' else ('injected failure' in line['train']['error'])
 
 
+_GUARD_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+from grl_amd.rank_guard import TrainBlockGuard
+rank, fault, d, key, delay = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5])
+time.sleep(delay)                                   # skew between the ranks' guard.start()
+g = TrainBlockGuard(rank, 2, 1.5, lambda reason: print(json.dumps({"error": reason}), flush=True), directory=d, key=key)
+g.start()
+if rank == 1 and fault == 'raise':
+    g.leave("train block raised on rank 1: RuntimeError('injected failure')")
+if rank == 1 and fault == 'hang':
+    time.sleep(60)
+# a healthy rank sits in the collective until the watchdog takes it out (peer failure or the limit)
+time.sleep(60)
+"""
+
+
+@pytest.mark.parametrize('fault', ['raise', 'hang'])
+def test_rank_guard_protocol_20_launches_under_load(fault, tmp_path):
+    """rank 0's guard used to delete `.err` / `.out` in start(); a peer that raised first
+    lost its reason and rank 0 printed the time-out text (1 of 8 full-suite runs).  20 launches of the two-rank
+    protocol (light children: grl_amd.rank_guard imports neither torch nor the GPU) with the failing rank AHEAD of
+    rank 0 by a random skew, while four busy loops load the machine: every launch must end with both ranks on exit
+    code 3 and rank 0's single line carrying the FIRST failure's reason."""
+    import json
+    import random
+    import subprocess
+    burners = [subprocess.Popen([sys.executable, '-c', 'while True: pass']) for _ in range(4)]
+    rnd = random.Random(7)
+    child = _GUARD_CHILD % {'root': ROOT}
+    try:
+        for it in range(20):
+            key = 'guard_%s_%d' % (fault, it)
+            skew = rnd.choice([0.0, 0.05, 0.3, 0.8])                      # rank 0 starts its guard this much LATER
+            procs = [subprocess.Popen([sys.executable, '-c', child, str(r), fault, str(tmp_path), key,
+                                       str(skew if r == 0 else 0.0)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                     for r in (0, 1)]
+            outs = [p.communicate(timeout=60) for p in procs]
+            assert [p.returncode for p in procs] == [3, 3], (it, outs)
+            lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+            assert len(lines) == 1 and outs[1][0].strip() == '', (it, outs)
+            err = json.loads(lines[0])['error']
+            if fault == 'raise':
+                assert err.startswith("train block raised on rank 1: RuntimeError('injected failure')"), (it, skew, err)
+            else:
+                assert 'did not finish' in err, (it, skew, err)
+    finally:
+        for b in burners:
+            b.kill()
+        for b in burners:
+            b.wait()
+
+
+def test_rank_guard_ignores_files_of_an_earlier_launch(tmp_path):
+    """A `.err` older than the launcher process is a leftover (same port / run id / pid reused): it neither takes a
+    healthy rank out nor shadows this launch's own reason."""
+    import time as _t
+    from grl_amd import rank_guard
+    got = []
+    g = rank_guard.TrainBlockGuard(0, 2, 30, got.append, directory=str(tmp_path), key='stale', exit_fn=lambda c: got.append(c))
+    with open(g.err, 'w') as fh:
+        fh.write('old failure')
+    old = g.not_before - 100
+    os.utime(g.err, (old, old))
+    assert not g._fresh(g.err)
+    g.start(); _t.sleep(0.6)
+    assert got == []                                               # the watchdog did not fire on the stale file
+    g.leave('new failure')
+    assert got == ['new failure', rank_guard.EXIT_TRAIN_BLOCK_FAILED]
+    assert open(g.err).read() == 'new failure'
+    g.finished()
+
+
 def test_bench_train_block_ok_path_exits_zero():
     import json
     import subprocess

@@ -69,21 +69,46 @@ def build_models(dev):
     return cnn.to(dev).eval(), siam.to(dev).eval(), sd, ssd
 
 
-def gemm_roofline(cnn, siam, clips, iters=3):
+PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def _nbytes(rows, cols, t):
+    return float(rows) * cols * t.element_size()
+
+
+def gemm_roofline(cnn, siam, clips, iters=3, stages=None):
     """Live per-launch timing of the dominant kernel (gemm_f32_kernel: every conv /
     linear of the path) with HIP events on the launch stream, outside the timed
     region.  achieved = algorithmic FLOPs of all its launches in one step (2*M*N*K per
-    launch, counted by the host wrapper) / sum of their measured durations."""
+    launch, counted by the host wrapper) / sum of their measured durations.
+    ``stages``: a dict to fill with the per-stage record (stem, layer1-4, gce, trl, tail): wall ms of the stage on one
+    stream (events at engine.STAGE_HOOK boundaries), the algorithmic FLOPs and the ALGORITHMIC bytes (operands read once,
+    outputs written once, weights once per launch) of the GEMM / fused-tail launches booked to it."""
     from grl_amd import engine
     recs = []
+    cur = ['pre']
+    marks = []
     orig, orig_tail, orig_tail32, orig_c64 = engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32, engine.conv3x3_c64_bf16
+
+    def hook(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e))
+        cur[0] = name
 
     def timed(a, w, y, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = orig(a, w, y, M, N, K, *args, **kw)
         e1.record()
-        recs.append((2.0 * M * N * K, e0, e1, (M, N, K, kw.get('conv'))))
+        conv = kw.get('conv')
+        rows_in, cin = (M, K) if conv is None else ((M // (conv[3] * conv[4])) * conv[0] * conv[1], conv[2])
+        by = _nbytes(rows_in, cin, a) + _nbytes(N, K, w)
+        sq = kw.get('epilogue', engine.EPI_AFFINE) == engine.EPI_SQDIFF
+        by += _nbytes(M // 32 if sq else M, N, y)
+        if kw.get('res') is not None:
+            by += _nbytes(M, N, kw['res'])
+        recs.append((2.0 * M * N * K, e0, e1, (M, N, K, conv), cur[0], by))
         return out
 
     def timed_tail_of(fn):
@@ -96,8 +121,11 @@ def gemm_roofline(cnn, siam, clips, iters=3):
             e1.record()
             pn = c1n.N if c1n is not None else 0
             kd = kw['down'].K if kw.get('down') is not None else 0         # (+ the block's downsample conv)
+            by = _nbytes(M, c3.K, t2) + _nbytes(M, c3.N, t2) + _nbytes(M, pn, t2)       # t2 in, 4P-wide out, conv1' out
+            by += _nbytes(M, kd, t2) if kd else _nbytes(M, c3.N, t2)                     # the block input x0, or the residual
+            by += (c3.N * (c3.K + pn + kd)) * t2.element_size()
             recs.append((2.0 * M * c3.N * (c3.K + pn + kd), e0, e1,
-                         (M, c3.N, c3.K, 'fused tail + conv1 -> %d%s' % (pn, ' + downsample' if kd else ''))))
+                         (M, c3.N, c3.K, 'fused tail + conv1 -> %d%s' % (pn, ' + downsample' if kd else '')), cur[0], by))
             return out
         return timed_tail
 
@@ -106,7 +134,8 @@ def gemm_roofline(cnn, siam, clips, iters=3):
         e0.record()
         out = orig_c64(x, c, n_img, H, W, relu)
         e1.record()
-        recs.append((2.0 * n_img * H * W * 64 * 576, e0, e1, (n_img * H * W, 64, 576, 'conv3x3_c64')))
+        recs.append((2.0 * n_img * H * W * 64 * 576, e0, e1, (n_img * H * W, 64, 576, 'conv3x3_c64'), cur[0],
+                     2 * _nbytes(n_img * H * W, 64, x) + 64 * 576 * x.element_size()))
         return out
 
     streams, engine.TRL_STREAMS = engine.TRL_STREAMS, False     # one stream: a launch's events bracket that launch alone
@@ -114,19 +143,39 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     torch.cuda.synchronize()                                    # (a hipMalloc between two events would count as GEMM time)
     engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32 = timed, timed_tail_of(orig_tail), timed_tail_of(orig_tail32)
     engine.conv3x3_c64_bf16 = timed_c64
+    engine.STAGE_HOOK = hook
     try:
         for _ in range(iters):
             engine.extract_features(cnn, siam, clips)
+            hook('end')
         torch.cuda.synchronize()
     finally:
         engine.gemm, engine.bneck_tail_bf16, engine.bneck_tail_f32, engine.conv3x3_c64_bf16 = orig, orig_tail, orig_tail32, orig_c64
         engine.TRL_STREAMS = streams
+        engine.STAGE_HOOK = None
     flops = sum(r[0] for r in recs) / iters
     ms = sum(r[1].elapsed_time(r[2]) for r in recs) / iters
     launches = len(recs) // iters
+    if stages is not None:
+        wall = {}
+        for (name, e), (_, e_next) in zip(marks[:-1], marks[1:]):
+            if name != 'end':
+                wall[name] = wall.get(name, 0.0) + e.elapsed_time(e_next) / iters
+        peak = SERIES_PEAK['bf16s' if engine.get_math() == 'bf16s' else 'f32']
+        for name, w_ms in wall.items():
+            sel = [r for r in recs if r[4] == name]
+            fl = sum(r[0] for r in sel) / iters
+            by = sum(r[5] for r in sel) / iters
+            k_ms = sum(r[1].elapsed_time(r[2]) for r in sel) / iters
+            stages[name] = {"wall_ms": round(w_ms, 3), "gemm_ms": round(k_ms, 3), "gemm_launches": len(sel) // iters,
+                            "gflop": round(fl / 1e9, 1), "tflops": round(fl / max(w_ms, 1e-9) / 1e9, 1),
+                            "mfma_util": round(fl / max(w_ms, 1e-9) / 1e9 / peak, 4),
+                            "mfma_util_in_gemm_time": round(fl / max(k_ms, 1e-9) / 1e9 / peak, 4) if sel else None,
+                            "algorithmic_gb": round(by / 1e9, 3), "hbm_gbs": round(by / max(w_ms, 1e-9) / 1e6, 1),
+                            "hbm_frac": round(by / max(w_ms, 1e-9) / 1e6 / PEAK_HBM_GBS, 4)}
     if os.environ.get('GRL_GEMM_REPORT'):
         agg = {}
-        for f, a, b2, shape in recs:
+        for f, a, b2, shape, _, _ in recs:
             e = agg.setdefault(str(shape), [0, 0.0, f])
             e[0] += 1
             e[1] += a.elapsed_time(b2)
@@ -137,29 +186,82 @@ def gemm_roofline(cnn, siam, clips, iters=3):
     return flops, ms, launches
 
 
-def series_roofline(math, clips, frames_per_clip, ms_per_step, train=False, kernel=None):
-    """`roofline` object of a secondary series: achieved = ALGORITHMIC FLOPs of one step (14.485 GFLOP
-    per frame forward, x 3 for a train step) / the step's measured wall time, against the dense MFMA peak of the
-    datapath; `kernel` = the dominant kernel family of that step timed live with HIP events (one stream)."""
+PMC_ROUND = 'r06'
+
+
+def pmc_record(series):
+    """Counter traffic of `series` from profiles/r06_pmc_<series>.json -- ONLY if that file was written by
+    tools/profile_round.sh on the library this process runs (sha256 of libgrl_hip.so, or of the sources it is built
+    from: tools/fingerprint.py).  Returns (record, None) or (None, reason): never an older round's file, never a file
+    of another build (VERDICT r5 measurement item 8)."""
+    path = os.path.join(ROOT, 'profiles', '%s_pmc_%s.json' % (PMC_ROUND, series))
+    if not os.path.isfile(path):
+        return None, 'no profiles/%s_pmc_%s.json' % (PMC_ROUND, series)
+    try:
+        rec = json.load(open(path))
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import fingerprint
+        fp = fingerprint.fingerprint()
+    except Exception as e:                              # noqa: BLE001
+        return None, 'unreadable: %r' % (e,)
+    if rec.get('lib_sha256') != fp['lib_sha256'] and rec.get('src_sha256') != fp['src_sha256']:
+        return None, ('profiles/%s_pmc_%s.json was taken on another build (library %s..., sources %s...; running %s... / %s...)'
+                      % (PMC_ROUND, series, str(rec.get('lib_sha256'))[:10], str(rec.get('src_sha256'))[:10],
+                         str(fp['lib_sha256'])[:10], fp['src_sha256'][:10]))
+    return rec, None
+
+
+def series_roofline(math, clips, frames_per_clip, ms_per_step, train=False, kernel=None, pmc=None, alg_bytes=None):
+    """`roofline` object of a secondary series.  MFMA view: ALGORITHMIC FLOPs of one step (14.485 GFLOP
+    per frame forward, x 3 for a train step) / the step's measured wall time against the dense MFMA peak of the datapath.
+    HBM view: `alg_bytes` (every GEMM / weight-gradient operand read once, every output written once: what a step with
+    every BatchNorm / pointwise pass fused away would move) / wall time against 8 TB/s.  `bound` = whichever of
+    traffic / 8 TB/s (counter traffic when a profile of THIS build is committed, else the algorithmic bytes) and
+    FLOPs / peak is larger; `achieved` / `peak` / `frac` are quoted in that bound's unit, the other view rides along.
+    `kernel` = the dominant kernel family of that step timed live with HIP events (one stream)."""
     gflop = clips * frames_per_clip * GFLOP_PER_FRAME * (TRAIN_FLOP_FACTOR if train else 1.0)
     achieved = gflop / ms_per_step          # GFLOP / ms = TFLOP/s
     peak = SERIES_PEAK[math]
-    r = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-         "frac": round(achieved / peak, 4), "algorithmic_gflop_per_step": round(gflop, 1), "traffic": None}
+    rec, why = pmc_record(pmc) if pmc else (None, 'no profiled series for this configuration')
+    traffic = rec['hbm_bytes_per_step'] if rec else None
+    mfma = {"achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4)}
+    t_mfma = gflop / peak                                                   # ms
+    byts = traffic if traffic is not None else alg_bytes
+    t_hbm = byts / (PEAK_HBM_GBS * 1e6) if byts else 0.0                    # ms
+    r = dict(mfma, bound="mfma")
+    if t_hbm > t_mfma and alg_bytes:
+        gbs = alg_bytes / ms_per_step / 1e6
+        r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+             "mfma_view": mfma}
+    r["algorithmic_gflop_per_step"] = round(gflop, 1)
+    r["algorithmic_gb_per_step"] = round(alg_bytes / 1e9, 2) if alg_bytes else None
+    r["min_ms_at_peak"] = {"mfma": round(t_mfma, 3), "hbm": round(t_hbm, 3),
+                           "hbm_from": "counter traffic" if traffic is not None else "algorithmic bytes"}
+    r["traffic"] = traffic
+    if rec:
+        r["traffic_source"] = "profiles/%s_pmc_%s.json (same build: fingerprint checked), %.2f x the algorithmic bytes" % (
+            PMC_ROUND, pmc, traffic / alg_bytes) if alg_bytes else "profiles/%s_pmc_%s.json (same build)" % (PMC_ROUND, pmc)
+        r["mfma_busy_dominant_kernels"] = rec.get('dominant', {}).get('mfma_busy_frac')
+    else:
+        r["traffic_reason_null"] = why
     if kernel is not None:
         r["kernel"] = kernel
     return r
 
 
 def eval_kernel_timing(cnn, siam, clips, math):
-    """Dominant-kernel record of an eval series: every GEMM launch (engine.gemm) of one step, HIP events."""
+    """Dominant-kernel record of an eval series: every GEMM launch (engine.gemm) of one step, HIP events; and the
+    per-stage table (north_star's 40 % target is per ResNet-50 stage)."""
     from grl_amd import engine
+    stages = {}
     with engine.math_mode(math):
-        flops, ms, launches = gemm_roofline(cnn, siam, clips)
+        flops, ms, launches = gemm_roofline(cnn, siam, clips, stages=stages)
     return {"name": "gemm_bf16_256_kernel / gemm_f32_kernel<.., bf16 storage> / bneck_tail_kernel (implicit-GEMM conv + linear, fused bottleneck tails)" if math == 'bf16s'
             else "gemm_f32_kernel", "launches_per_step": launches, "ms_per_step": round(ms, 3),
             "gflop_per_step": round(flops / 1e9, 1), "tflops": round(flops / ms / 1e9, 1),
-            "frac_of_peak": round(flops / ms / 1e9 / SERIES_PEAK[math], 4)}
+            "frac_of_peak": round(flops / ms / 1e9 / SERIES_PEAK[math], 4),
+            "algorithmic_bytes_per_step": sum(v["algorithmic_gb"] for v in stages.values()) * 1e9,
+            "stages (one stream; mfma_util = algorithmic FLOPs / stage wall time / MFMA peak, hbm_gbs = algorithmic bytes / stage wall time)": stages}
 
 
 def train_kernel_timing(tr, clips, pids, math, iters=2):
@@ -173,13 +275,20 @@ def train_kernel_timing(tr, clips, pids, math, iters=2):
     def tg(a, w, y, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = og(a, w, y, M, N, K, *args, **kw); e1.record()
-        recs.append(('gemm', 2.0 * M * N * K, e0, e1))
+        conv = kw.get('conv')
+        rows_in, cin = (M, K) if conv is None else ((M // (conv[3] * conv[4])) * conv[0] * conv[1], conv[2])
+        by = _nbytes(rows_in, cin, a) + _nbytes(N, K, w) + _nbytes(M, N, y)
+        if kw.get('res') is not None:
+            by += _nbytes(M, N, kw['res'])
+        recs.append(('gemm', 2.0 * M * N * K, e0, e1, by))
         return r
 
     def tw(dz, x, dw, M, N, K, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = ow(dz, x, dw, M, N, K, *args, **kw); e1.record()
-        recs.append(('wgrad', 2.0 * M * N * K, e0, e1))
+        conv = kw.get('conv')
+        rows_in, cin = (M, K) if conv is None else ((M // (conv[3] * conv[4])) * conv[0] * conv[1], conv[2])
+        recs.append(('wgrad', 2.0 * M * N * K, e0, e1, _nbytes(M, N, dz) + _nbytes(rows_in, cin, x) + 4.0 * N * K))
         return r
 
     def one():
@@ -208,12 +317,14 @@ def train_kernel_timing(tr, clips, pids, math, iters=2):
         ms = sum(r[2].elapsed_time(r[3]) for r in sel) / iters
         fl = sum(r[1] for r in sel) / iters
         out[kind] = {"launches_per_step": len(sel) // iters, "ms_per_step": round(ms, 3),
-                     "gflop_per_step": round(fl / 1e9, 1), "tflops": round(fl / max(ms, 1e-9) / 1e9, 1)}
+                     "gflop_per_step": round(fl / 1e9, 1), "tflops": round(fl / max(ms, 1e-9) / 1e9, 1),
+                     "algorithmic_gb_per_step": round(sum(r[4] for r in sel) / iters / 1e9, 2)}
     tot_ms = out['gemm']['ms_per_step'] + out['wgrad']['ms_per_step']
     tot_fl = out['gemm']['gflop_per_step'] + out['wgrad']['gflop_per_step']
     return {"name": "forward + data-gradient GEMMs (gemm_f32_kernel / gemm_bf16_256_kernel) and weight gradients "
                     "(wgrad_kernel / wgrad_b16in*), one stream",
             "forward_and_dgrad": out['gemm'], "wgrad": out['wgrad'], "ms_per_step": round(tot_ms, 3),
+            "algorithmic_bytes_per_step": sum(r[4] for r in recs) / iters,
             "tflops": round(tot_fl / max(tot_ms, 1e-9), 1),
             "frac_of_peak": round(tot_fl / max(tot_ms, 1e-9) / SERIES_PEAK[math], 4)}
 
@@ -315,6 +426,7 @@ def train_series(dev, math, steps=20, warmup=5, b=32, t=4, rank=0, world=1, dist
         for k in range(steps):
             loss = step()
             marks[k + 1].record()
+        t_issue = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
         per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
@@ -327,12 +439,15 @@ def train_series(dev, math, steps=20, warmup=5, b=32, t=4, rank=0, world=1, dist
            "steps": steps, "warmup": warmup,
            "step_ms_on_stream": {"median": round(per_step[len(per_step) // 2], 2), "min": round(per_step[0], 2),
                                  "max": round(per_step[-1], 2)},
-           "side_streams": side_streams_state()}
+           "side_streams": side_streams_state(),
+           "host": {"issue_ms_per_step": round(t_issue / steps * 1e3, 3), "launch_bound_frac": round(min(1.0, t_issue / dt), 3)}}
     if roofline:
         # per GPU: algorithmic FLOPs of this rank's step / the step time; the dominant kernels timed live (N = 1 only:
         # the timing pass runs extra steps, which at N > 1 would have to stay in lockstep over the collectives)
         kern = train_kernel_timing(tr, clips, pids, math) if (sync is None and not graph) else None
-        out["roofline"] = series_roofline(math, b, t, ms, train=True, kernel=kern)
+        pmc = {(32, 4, 'f32'): 'train_f32', (32, 4, 'bf16s'): 'train_bf16s', (64, 8, 'bf16s'): 'train_c3_bf16s'}.get((b, t, math))
+        out["roofline"] = series_roofline(math, b, t, ms, train=True, kernel=kern, pmc=pmc,
+                                          alg_bytes=kern["algorithmic_bytes_per_step"] if kern else None)
     if sync is not None:
         per_bucket = {}
         for w in waits:                                             # (the final barrier synchronised the device)
@@ -362,7 +477,7 @@ def train_step_ms(dev, math, steps=20, warmup=5, b=32, t=4, graph=False):
 
 def train_step_record(dev, math, steps=20, warmup=5, b=32, t=4):
     r = train_series(dev, math, steps, warmup, b, t, roofline=True)
-    return {k: r[k] for k in ("ms_per_step", "clips_per_sec", "steps", "warmup", "step_ms_on_stream", "side_streams", "roofline")}
+    return {k: r[k] for k in ("ms_per_step", "clips_per_sec", "steps", "warmup", "step_ms_on_stream", "side_streams", "host", "roofline")}
 
 
 def train_block(dev, rank, world, dist, backend):
@@ -420,7 +535,8 @@ def secondary_block(dev, cnn, siam, steps):
         ms = (time.perf_counter() - t0) / steps * 1e3
     out["configs[2] bf16s, 64 clips x 8 frames"] = {
         "clip_features_per_sec": round(64 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "frames_per_sec": round(512 / ms * 1e3),
-        "roofline": series_roofline('bf16s', 64, 8, ms, kernel=eval_kernel_timing(cnn, siam, c3, 'bf16s'))}
+        "roofline": (lambda k: series_roofline('bf16s', 64, 8, ms, kernel=k, pmc='eval_c3_bf16s',
+                                               alg_bytes=k["algorithmic_bytes_per_step"]))(eval_kernel_timing(cnn, siam, c3, 'bf16s'))}
     del c3
 
     def fresh(m, **kw):
@@ -435,14 +551,18 @@ def secondary_block(dev, cnn, siam, steps):
     out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = v
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
     qd, gd = qf.to(dev), gf.to(dev)
-    for _ in range(2):
+    # 15 warm-ups / 20 timed launches (round 6): generating the 13290 feature rows on the host above leaves the GPU idle for
+    # about a second, and the first ~10 launches after an idle gap run on the clock ramp -- 2.7 -> 2.3 ms per launch,
+    # 2.14 from the 15th on (tools/distmat_gap.py, profiles/r06_distmat_gap.txt).  Rounds 3-5 timed 5 launches after 2
+    # warm-ups here (2.40-2.42 ms) against 20 after 5 in `--mode distmat` (2.17): the whole "gap" between the two.
+    for _ in range(15):
         d = engine.cosin_dist(qd, gd)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(20):
         d = engine.cosin_dist(qd, gd)
     torch.cuda.synchronize()
-    dms = (time.perf_counter() - t0) / 5 * 1e3
+    dms = (time.perf_counter() - t0) / 20 * 1e3
     engine.rank_rows(d)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -499,7 +619,7 @@ def distmat_bench(args, dev, rank):
     from grl_amd.synthetic import synth_eval_features
     qf, gf, qp, qc, gp, gc = synth_eval_features(1980, 11310, seed=1, noise=6.0)
     qd, gd = qf.to(dev), gf.to(dev)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 15)):          # (the first ~10 launches after an idle gap run on the clock ramp: secondary_block)
         d = engine.cosin_dist(qd, gd)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -761,6 +881,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         feat = engine.extract_features(cnn, siam, clips)
+    t_issue = time.perf_counter() - t0          # host time to ISSUE the steps (nothing in a step waits for the device)
     barrier()
     dt = max_over_ranks(dist, dev, time.perf_counter() - t0)
     assert bool(torch.isfinite(feat).all())
@@ -770,17 +891,17 @@ def main():
     if rank == 0:
         n = max(world, 1)
         value = n * B * args.steps / dt
-        flops, gemm_ms, launches = gemm_roofline(cnn, siam, clips)
+        stages = {}
+        flops, gemm_ms, launches = gemm_roofline(cnn, siam, clips, stages=stages)
         achieved = flops / (gemm_ms * 1e-3) / 1e12
         # dense MFMA peak of the datapath (MI355X_MICROARCH.md): fp32 157.3, bf16 2500; bf16x3
         # issues three bf16 MFMAs per product, so its fp32-equivalent peak is 2500/3
         peak = {'f32': PEAK_FP32_MFMA_TFLOPS, 'bf16': 2500.0, 'bf16s': 2500.0, 'bf16x3': 2500.0 / 3}[args.math]
-        traffic, pmc_name = None, None
-        for pmc_name in ('r05_gemm_pmc.json', 'r04_gemm_pmc.json', 'r03_gemm_pmc.json', 'r02_gemm_pmc.json'):
-            pmc = os.path.join(ROOT, 'profiles', pmc_name)
-            if os.path.isfile(pmc):
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_step')
-                break
+        # counter traffic of the SAME kernels (GEMM + fused-tail launches of one step): only from a profile of this build
+        pmc_series = {(32, 4, 'f32'): 'eval_f32', (64, 8, 'bf16s'): 'eval_c3_bf16s'}.get((B, T, args.math))
+        prec, pwhy = pmc_record(pmc_series) if pmc_series else (None, 'no profiled series for this configuration')
+        traffic = prec['dominant']['hbm_bytes_per_step'] if prec else None
+        alg_bytes = sum(v["algorithmic_gb"] for v in stages.values()) * 1e9
         out = {
             "metric": "clip-features/sec", "value": round(value, 2), "unit": "clip-features/sec",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -796,16 +917,25 @@ def main():
                                        '2' if (B, T) == (64, 8) and args.math in ('bf16', 'bf16s') else '1 (variant)'),
                        "clips_per_gpu": B, "seq_len": T, "frame": "256x128",
                        "parallelism": "replicas x%d (no collective)" % n},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic if args.math == 'f32' else None,
-                         "traffic_note": "NOT measured by this run: read from profiles/%s (rocprofv3 FETCH_SIZE x2 + "
-                                         "WRITE_SIZE, separate passes, summed over the kernel's launches of ONE "
-                                         "step like the GFLOP figure)" % pmc_name,
+            "roofline": {"bound": "mfma" if flops / (peak * 1e12) >= (traffic or alg_bytes) / (PEAK_HBM_GBS * 1e9) else "hbm",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_note": ("profiles/%s_pmc_%s.json, taken on THIS build (fingerprint checked): rocprofv3 FETCH_SIZE x2 + "
+                                          "WRITE_SIZE, separate passes, summed over the same kernels' launches of ONE step "
+                                          "like the GFLOP figure; %.2f x their algorithmic bytes; MFMA busy %s" % (
+                                              PMC_ROUND, pmc_series, traffic / alg_bytes, prec['dominant'].get('mfma_busy_frac')))
+                         if prec else "null: %s" % pwhy,
+                         "algorithmic_gb_per_step": round(alg_bytes / 1e9, 2),
                          "kernel": "gemm_f32_kernel + fused bottleneck tails (%s MFMA implicit-GEMM conv), %d launches/step, "
                                    "%.3f ms/step, %.1f algorithmic GFLOP/step" % (
-                                       'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9)},
+                                       'fp32' if args.math == 'f32' else 'bf16', launches, gemm_ms, flops / 1e9),
+                         "stages (one stream; mfma_util = algorithmic FLOPs / stage wall time / MFMA peak; hbm_gbs = algorithmic bytes / stage wall time)": stages},
             "end_to_end_tflops": round(value / n * GFLOP_PER_FRAME * T / 1e3, 2),
+            # strong-scaling readiness: how much of a step's wall time the host needs just to issue its
+            # launches.  >= 1: the step is launch-bound (the GPU waits for the host) -- what `--clips 4` (configs[1] split
+            # over 8 GPUs) is about.
+            "host": {"issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+                     "launch_bound_frac": round(min(1.0, t_issue / dt), 3)},
         }
         out["config"]["math"] = args.math
         if dist is not None:

@@ -451,6 +451,14 @@ def _to_nchw(y, n, H, W):
     return y.view(n, H, W, -1).permute(0, 3, 1, 2)
 
 
+STAGE_HOOK = None      # bench.py's per-stage timing pass: callable(stage name) at every stage boundary of the eval forward
+
+
+def _stage(name):
+    if STAGE_HOOK is not None:
+        STAGE_HOOK(name)
+
+
 def _stem_pool_ok(x, n):
     """what grl_stem_pool_{f32,bf16} require beyond the frame geometry (one grid row per frame; 2-byte loads of u8
     rows, 8-byte loads of fp32 rows): otherwise the two-launch stem + max-pool path takes the batch"""
@@ -463,6 +471,7 @@ def trunk_eval(plan, x, taps=None):
     Hs, Ws = H // 2, W // 2
     Hp, Wp = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _new((n * Hp * Wp, 64), x)
+    _stage('stem')
     if FUSE_STEM_POOL_F32 and taps is None and W == 128 and H % 4 == 0 and _stem_pool_ok(x, n):
         # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_f32)
         u8 = x.dtype == torch.uint8
@@ -486,6 +495,7 @@ def trunk_eval(plan, x, taps=None):
     bi = 0
     o1 = None
     for li, nb in enumerate(counts):
+        _stage('layer%d' % (li + 1))       # (a fused tail computes the NEXT block's conv1: the first conv1 of layers 2 / 3 is booked here)
         for _ in range(nb):
             e = plan.blocks[bi]
             bi += 1
@@ -514,6 +524,7 @@ def trunk_eval(plan, x, taps=None):
 def gce_eval(plan, x4, b, t, taps=None):
     """x4 [b*t*128][2048] -> (x_uncorr, x_corr) same shape, corr_map [b*t*128]."""
     M = x4.shape[0]
+    _stage('gce')
     x_glo = _new((b, 2048), x4)
     _call('grl_group_mean', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
     g = plan.glo_fc
@@ -639,6 +650,7 @@ def trl_eval(plan, xu, xc, b, t, taps=None):
     Cc = 2048
     frame = PIX * Cc
     Mb = b * PIX
+    _stage('trl')
     memo0 = _new((Mb, Cc), xu)
     _call('grl_temporal_mean', ptr(xu), ptr(memo0), b, t, frame)
     gapc = _new((b * t, Cc), xu)
@@ -716,6 +728,7 @@ def _grl_eval(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     xu, xc, _ = gce_eval(plan, x4, b, t, taps)
     del x4
     f_uncorr, f_corr = trl_eval(plan, xu, xc, b, t, taps)
+    _stage('tail')
     x_corr = _new((b, t, 2048), inputs)
     _call('grl_affine_l2norm', ptr(f_corr), ptr(plan.corr_bn[0]), ptr(plan.corr_bn[1]), ptr(x_corr),
           b * t, 2048, 2048)
@@ -840,6 +853,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     Hs, Ws = h // 2, w // 2
     H, W = (Hs + 1) // 2, (Ws + 1) // 2
     cur = _newb((n * H * W, 64), x)
+    _stage('stem')
     if FUSE_STEM_POOL and taps is None and w == 128 and h % 4 == 0 and _stem_pool_ok(x, n):
         # stem + max-pool in one launch: the stem map never reaches HBM (grl_stem_pool_bf16)
         u8 = x.dtype == torch.uint8
@@ -857,6 +871,8 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
         del stem
     o1 = None
     for bi, e in enumerate(plan.blocks):
+        if bi in (0, 3, 7, 13):
+            _stage('layer%d' % ((0, 3, 7, 13).index(bi) + 1))
         s = e['stride']
         if o1 is None:
             o1, _, _ = _conv_b16(cur, e['c1'], n, H, W)
@@ -879,6 +895,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     x4 = cur
     M = x4.shape[0]
     # GCE
+    _stage('gce')
     x_glo = _new((b, 2048), x)
     _call('grl_group_mean_bf16', ptr(x4), ptr(x_glo), b, t * PIX, 2048, 2048, C.c_float(1.0), 0)
     g = plan.glo_fc
@@ -901,6 +918,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     if taps is not None:
         taps['corr_map'] = cmap.view(b * t, 1, 16, 8)
     # TRL
+    _stage('trl')
     Cc, frame, Mb = 2048, PIX * 2048, b * PIX
     memo0 = _newb((Mb, Cc), x)
     _call('grl_temporal_mean_bf16', ptr(xu), ptr(memo0), b, t, frame)
@@ -1003,6 +1021,7 @@ def _grl_eval_bf16s(model, inputs, taps=None, out_uncorr=None, ld_uncorr=2048):
     _call('grl_group_mean_bf16', ptr(memo[1]), ptr(f_uncorr), b, PIX, Cc, Cc, C.c_float(1.0), 1)
     if taps is not None:
         taps['f_uncorr'], taps['f_corr'] = f_uncorr, fcorr
+    _stage('tail')
     x_corr = _new((b, t, 2048), inputs)
     _call('grl_affine_l2norm', ptr(fcorr), ptr(plan.corr_bn[0]), ptr(plan.corr_bn[1]), ptr(x_corr),
           b * t, 2048, 2048)

@@ -3,6 +3,7 @@ every symbol include/grl_hip.h declares, the Python surface has the reference's
 names, and the product path refuses to run without a HIP device."""
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -201,3 +202,37 @@ def test_raw_video_dataset_decodes_and_samples_like_the_reference(tmp_path):
     random.seed(3); np.random.seed(3)
     item = RawVideoDataset([(tuple(paths), 7, 2)], seq_len=4, sample='rrs_train', augment=True, height=64, width=32)[0]
     assert len(item) == 4 and item[3].dtype == torch.int32 and tuple(item[3].shape) == (1 + 8 * 4,)
+
+
+def test_bench_quotes_counter_traffic_only_from_a_profile_of_this_build(tmp_path, monkeypatch):
+    """VERDICT r5 measurement item 8: `roofline.traffic` comes from profiles/r06_pmc_<series>.json ONLY when that file
+    carries the fingerprint of the running library (or of its sources); a missing file or another build's file gives
+    traffic null with the reason in the line -- never an older round's file."""
+    import json
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import fingerprint
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles')
+    os.makedirs(tmp_path / 'tools')
+    rec, why = bench.pmc_record('eval_f32')
+    assert rec is None and 'no profiles/' in why
+    fp = fingerprint.fingerprint()
+    good = dict(fp, hbm_bytes_per_step=123, dominant={"hbm_bytes_per_step": 100, "mfma_busy_frac": 0.8})
+    (tmp_path / 'profiles' / ('%s_pmc_eval_f32.json' % bench.PMC_ROUND)).write_text(json.dumps(good))
+    rec, why = bench.pmc_record('eval_f32')
+    assert why is None and rec['hbm_bytes_per_step'] == 123
+    other = dict(good, lib_sha256='0' * 64, src_sha256='1' * 64)
+    (tmp_path / 'profiles' / ('%s_pmc_eval_f32.json' % bench.PMC_ROUND)).write_text(json.dumps(other))
+    rec, why = bench.pmc_record('eval_f32')
+    assert rec is None and 'another build' in why
+    # a rebuilt library from the same sources still matches (source fingerprint)
+    same_src = dict(good, lib_sha256='0' * 64)
+    (tmp_path / 'profiles' / ('%s_pmc_eval_f32.json' % bench.PMC_ROUND)).write_text(json.dumps(same_src))
+    assert bench.pmc_record('eval_f32')[0] is not None
+    # the roofline object: bound from max(bytes / 8 TB/s, FLOPs / peak), HBM view when the bytes win
+    r = bench.series_roofline('bf16s', 32, 4, 18.0, train=True, pmc=None, alg_bytes=40e9)
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['traffic'] is None and 'traffic_reason_null' in r
+    assert abs(r['achieved'] - 40e9 / 18.0 / 1e6) < 1 and r['mfma_view']['unit'] == 'TFLOP/s'
+    r = bench.series_roofline('f32', 32, 4, 53.0, train=True, pmc=None, alg_bytes=40e9)
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'

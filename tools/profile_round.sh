@@ -7,6 +7,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
+python3 $R/tools/fingerprint.py > $O/fingerprint.json      # the build these passes run on (bench.py checks it before quoting them)
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations and counters are only additive when kernels do not overlap: one stream for the profile passes
 export GRL_TRL_STREAMS=0 GRL_WGRAD_STREAM=0

@@ -44,8 +44,22 @@ def load(d):
 
 
 def main():
+    # optional: --json <out.json> --series <name> [--dominant <regex>]: the totals bench.py reads back (with the
+    # fingerprint of the library the passes ran on, tools/fingerprint.py)
+    opts = {}
+    argv = list(sys.argv)
+    for flag in ('--json', '--series', '--dominant'):
+        if flag in argv:
+            i = argv.index(flag)
+            opts[flag] = argv[i + 1]
+            del argv[i:i + 2]
+    sys.argv = argv
     title, steps = sys.argv[1], int(sys.argv[2])
     sq, cnt, dur = load(sys.argv[3])
+    if steps <= 0:
+        # auto: the forward stem kernel runs exactly once per step (warm-up, timed and live-timing steps alike)
+        stems = [k for k in cnt if 'stem' in k and 'wgrad' not in k and 'pack' not in k and 'tail' not in k and 'bwd' not in k]
+        steps = int(max(cnt[k] for k in stems)) if stems else 1
     fe, _, _ = load(sys.argv[4])
     wr, _, _ = load(sys.argv[5])
     rows = []
@@ -75,6 +89,27 @@ def main():
     print()
     print('sum of kernel time %.2f ms/step; read %.1f GB + write %.1f GB per step' % (
         tot, sum(r[4] for r in rows) / 1e9, sum(r[5] for r in rows) / 1e9))
+    if '--json' in opts:
+        import json
+        import re
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import fingerprint
+        pat = re.compile(opts.get('--dominant', 'gemm_|bneck_tail|wgrad|conv3x3_c64'))
+        dom = [r for r in rows if pat.search(r[1])]
+        gui = sum(sq[r[1]].get('GRBM_GUI_ACTIVE', 0.0) for r in dom)
+        mf = sum(sq[r[1]].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for r in dom)
+        rec = {"series": opts.get('--series', title), "title": title, "steps_profiled": steps,
+               "hbm_read_bytes_per_step": int(sum(r[4] for r in rows)), "hbm_write_bytes_per_step": int(sum(r[5] for r in rows)),
+               "hbm_bytes_per_step": int(sum(r[4] + r[5] for r in rows)), "kernel_ms_per_step": round(tot, 4),
+               "dominant": {"pattern": pat.pattern, "launches_per_step": round(sum(r[2] for r in dom), 1),
+                            "ms_per_step": round(sum(r[0] for r in dom), 4),
+                            "hbm_bytes_per_step": int(sum(r[4] + r[5] for r in dom)),
+                            "mfma_busy_frac": round((mf / 1024.0) / (gui / 8.0), 4) if gui else None},
+               "note": "three separate rocprofv3 --pmc passes (MFMA busy; FETCH_SIZE; WRITE_SIZE), single stream; HBM bytes = "
+                       "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, summed over every kernel of a step"}
+        rec.update(fingerprint.fingerprint())
+        with open(opts['--json'], 'w') as fh:
+            json.dump(rec, fh, indent=1)
     if DROPPED[0]:
         print()
         print('(%d dispatches over the three passes took more than 10 ms (one-off stalls inside the profiled pass) and were left out, their '

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GRL_HIP_LIB') or os.path.join(_HERE, 'libgrl_hip.so')     # (override: A/B builds, tools/gemm_ko.sh)
 
-ABI_VERSION = 8       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
+ABI_VERSION = 9       # = GRL_ABI_VERSION of include/grl_hip.h this binding was written against
 
 EPI_AFFINE, EPI_NEGDOT, EPI_EUCLID, EPI_SQDIFF = 0, 1, 2, 3
 
@@ -57,8 +57,20 @@ class GrlPrepEntry(C.Structure):
                 ('tiled', _i32), ('out_bf16', _i32)]
 
 
+class GrlJpegFrame(C.Structure):
+    """include/grl_hip.h: one parsed JPEG frame (filled by grl_jpeg_parse on the host, read by the decode kernels)"""
+    _fields_ = [('scan_off', C.c_uint32), ('scan_len', C.c_uint32), ('width', C.c_uint16), ('height', C.c_uint16),
+                ('restart_interval', C.c_uint16), ('ncomp', C.c_uint8), ('hmax', C.c_uint8), ('vmax', C.c_uint8),
+                ('rgb', C.c_uint8), ('hs', C.c_uint8 * 4), ('vs', C.c_uint8 * 4), ('tq', C.c_uint8 * 4),
+                ('td', C.c_uint8 * 4), ('ta', C.c_uint8 * 4), ('pad_', C.c_uint8 * 10), ('q', (C.c_uint16 * 64) * 4),
+                ('maxcode', (C.c_int32 * 18) * 4), ('valoff', (C.c_int32 * 18) * 4), ('vals', (C.c_uint8 * 256) * 4)]
+
+
+GRL_EUNSUPPORTED = -3
+
 _SIGNATURES = {
     'grl_abi_version': ([], C.c_int),
+    'grl_stream_wait_stream': ([_fp, _fp], C.c_int),
     'grl_conv_gemm_f32': ([C.POINTER(GrlGemm), _fp], C.c_int),
     'grl_conv_gemm_f32_stat_rows': ([C.POINTER(GrlGemm)], C.c_int),
     'grl_conv_gemm_f32_group': ([C.POINTER(GrlGemm), C.c_int, _fp], C.c_int),
@@ -176,6 +188,10 @@ _SIGNATURES = {
     'grl_conv3x3_c64_bf16': ([_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bottleneck_tail_f32': ([C.POINTER(GrlBneckTailF32), _fp], C.c_int),
     'grl_bottleneck_tail_f32_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
+    # frame decode on the device (jpeg.hip)
+    'grl_jpeg_parse': ([_fp, _i64, _i64, C.POINTER(GrlJpegFrame)], C.c_int),
+    'grl_jpeg_workspace_bytes': ([C.POINTER(GrlJpegFrame), C.c_int], _i64),
+    'grl_jpeg_decode_batch': ([_fp, _fp, C.POINTER(GrlJpegFrame), C.c_int, _fp, _fp, _i64, _fp], C.c_int),
 }
 
 _lib = None
@@ -219,6 +235,8 @@ def ptr(t):
     """Device pointer of a tensor (or None -> NULL)."""
     if t is None:
         return None
+    if t.__class__ is int:               # a raw device address (e.g. a row of a BatchNorm state block: train_engine.bn_finalize)
+        return t
     return t.data_ptr()
 
 

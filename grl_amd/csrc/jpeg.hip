@@ -1,0 +1,533 @@
+// Baseline-JPEG frame decode on gfx950 (include/grl_hip.h, "Frame decode on the device"): replaces the per-frame
+// `Image.open(img_path).convert('RGB')` of /root/reference/reid/data/video_loader.py:124-141, bit-identical to Pillow /
+// libjpeg-turbo with libjpeg's defaults (JDCT_ISLOW, fancy upsampling).  Integer / byte work throughout -- no MFMA here:
+//   1. jpeg_entropy_kernel   Huffman decoding (ITU-T T.81 F.2.2).  A scan is ONE serial bit stream, so the parallelism is
+//                            across frames: a lane owns a frame, a 64-lane workgroup owns 64 frames whose Huffman tables sit
+//                            in LDS lane-minor ([entry][lane]: 4-byte entries are bank-conflict-free whatever each lane
+//                            indexes).  The byte stream is read as aligned dwords (one global load per 4 stream bytes),
+//                            0xFF00 stuffing / fill bytes / RSTn handled in registers.  Only NON-ZERO coefficients are
+//                            written (the coefficient array is zero-filled by a memset node in front of the kernel).
+//   2. jpeg_idct_kernel      dequantisation + jidctint.c's jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2), one lane per 8 x 8
+//                            block, both passes in registers, eight 8-byte row stores into the component plane.
+//   3. jpeg_color_kernel     jdsample.c's triangle-filter ("fancy") chroma upsampling + jdcolor.c's fixed-point YCbCr -> RGB,
+//                            one lane per output pixel, planar uint8 out ([n][3][H][W]: the clip tensor's layout).
+// All frames of a batch share one geometry (MARS: 256 x 128, 4:2:0), so every loop bound is wave-uniform; the only
+// divergence is inside a symbol's code-length search.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#include "../../include/grl_hip.h"
+#include "common.h"
+
+namespace {
+
+__device__ __constant__ uint8_t kNaturalDev[80] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+    63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+const uint8_t kNaturalHost[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// geometry shared by every frame of a batch (from frame 0, checked on the host for the others)
+struct Geo {
+    int width, height, ncomp, hmax, vmax;
+    int mcux, mcuy, bpm, blocks;          // MCUs per row / column, blocks per MCU, blocks per frame
+    int hs[3], vs[3];
+    int pw[3], ph[3];                     // plane sizes (whole blocks)
+    int cw[3], ch[3];                     // real samples per component (downsampled_width / height)
+    int poff[3];                          // byte offset of each component plane inside a frame's plane block
+    int plane_bytes;                      // planes of one frame
+};
+
+Geo make_geo(const GrlJpegFrame& f) {
+    Geo g;
+    memset(&g, 0, sizeof(g));
+    g.width = f.width; g.height = f.height; g.ncomp = f.ncomp; g.hmax = f.hmax; g.vmax = f.vmax;
+    g.mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax);
+    g.mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
+    int off = 0;
+    for (int c = 0; c < f.ncomp; ++c) {
+        g.hs[c] = f.hs[c]; g.vs[c] = f.vs[c];
+        g.bpm += f.hs[c] * f.vs[c];
+        g.pw[c] = g.mcux * f.hs[c] * 8;
+        g.ph[c] = g.mcuy * f.vs[c] * 8;
+        g.cw[c] = (f.width * f.hs[c] + f.hmax - 1) / f.hmax;
+        g.ch[c] = (f.height * f.vs[c] + f.vmax - 1) / f.vmax;
+        g.poff[c] = off;
+        off += g.pw[c] * g.ph[c];
+    }
+    g.blocks = g.mcux * g.mcuy * g.bpm;
+    g.plane_bytes = (off + 15) & ~15;
+    return g;
+}
+
+// ---- 1. entropy decoding ----------------------------------------------------------------------------------------------
+constexpr int EW = 64;                                   // frames per workgroup (one wave)
+// LDS, lane-minor: [4 tables][16 lengths][EW] maxcode, the same for valoff, then the symbols [DC0 16][DC1 16][AC0 256][AC1 256][EW]
+constexpr int E_MAX_INTS = 4 * 16 * EW;
+constexpr int E_VALS = (16 + 16 + 256 + 256) * EW;
+constexpr size_t E_LDS = (size_t)2 * E_MAX_INTS * sizeof(int32_t) + E_VALS;
+
+struct BitReader {
+    const uint8_t* base;      // the batch's byte buffer
+    uint32_t pos, end;        // next stream byte, one past the scan
+    uint32_t limit;           // bytes that may be read as whole dwords (buffer length rounded down to 4)
+    uint64_t acc;             // bits, MSB first, in the low `cnt` bits
+    int cnt;
+    int marker;               // a marker was met: zero bits from here on (libjpeg's "insufficient data" behaviour)
+};
+
+__device__ __forceinline__ uint32_t load_dword(const BitReader& b, uint32_t a) {
+    if (a + 4 <= b.limit) return *reinterpret_cast<const uint32_t*>(b.base + a);
+    uint32_t v = 0;                                                       // the buffer's last, partial dword
+    for (int i = 0; i < 4; ++i)
+        if (a + i < b.end) v |= (uint32_t)b.base[a + i] << (8 * i);
+    return v;
+}
+
+// stream byte at p, through the one-dword cache (cur_addr = the aligned address `cur` was loaded from)
+struct ByteCache { uint32_t addr; uint32_t word; };
+__device__ __forceinline__ int byte_at(const BitReader& b, ByteCache& c, uint32_t p) {
+    const uint32_t a = p & ~3u;
+    if (a != c.addr) { c.word = load_dword(b, a); c.addr = a; }
+    return (int)((c.word >> (8 * (p & 3u))) & 255u);
+}
+
+__device__ __forceinline__ void fill_bits(BitReader& b, ByteCache& c) {
+    while (b.cnt <= 48) {
+        int byte = 0;
+        if (!b.marker && b.pos < b.end) {
+            byte = byte_at(b, c, b.pos);
+            if (byte == 0xFF) {
+                uint32_t q = b.pos + 1;
+                while (q < b.end && byte_at(b, c, q) == 0xFF) ++q;          // fill bytes
+                if (q < b.end && byte_at(b, c, q) == 0x00) {
+                    b.pos = q + 1;                                           // stuffed zero: a data byte 0xFF
+                } else {
+                    b.marker = 1;                                            // RSTn / EOI / anything else: stays unread
+                    byte = 0;
+                }
+            } else {
+                b.pos++;
+            }
+        } else if (b.pos >= b.end) {
+            b.marker = 1;
+        }
+        b.acc = (b.acc << 8) | (uint64_t)byte;
+        b.cnt += 8;
+    }
+}
+
+__device__ __forceinline__ int get_bits(BitReader& b, int s) {              // s <= 16, cnt >= s guaranteed by the caller's fill
+    b.cnt -= s;
+    return (int)((b.acc >> b.cnt) & ((1u << s) - 1u));
+}
+
+__device__ __forceinline__ int extend(int x, int s) { return x < (1 << (s - 1)) ? x + (int)((~0u) << s) + 1 : x; }
+
+__global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restrict__ bytes, uint32_t nbytes,
+                                                          const GrlJpegFrame* __restrict__ frames, int n,
+                                                          int16_t* __restrict__ coef, Geo g) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    int32_t* const s_max = reinterpret_cast<int32_t*>(lds);
+    int32_t* const s_off = s_max + E_MAX_INTS;
+    uint8_t* const s_val = reinterpret_cast<uint8_t*>(s_off + E_MAX_INTS);
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * EW + lane;
+    const bool live = f < n;
+    const GrlJpegFrame* fr = frames + (live ? f : n - 1);
+    // this lane's tables -> LDS [entry][lane]
+    for (int t = 0; t < 4; ++t) {
+        for (int l = 1; l <= 16; ++l) {
+            s_max[(t * 16 + l - 1) * EW + lane] = fr->maxcode[t][l];
+            s_off[(t * 16 + l - 1) * EW + lane] = fr->valoff[t][l];
+        }
+        const int nv = t < 2 ? 16 : 256, vbase = t < 2 ? t * 16 : 32 + (t - 2) * 256;
+        for (int i = 0; i < nv; i += 4) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(&fr->vals[t][i]);
+            for (int e = 0; e < 4; ++e) s_val[(vbase + i + e) * EW + lane] = (uint8_t)(w >> (8 * e));
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    BitReader b;
+    b.base = bytes;
+    b.pos = fr->scan_off;
+    b.end = fr->scan_off + fr->scan_len;
+    b.limit = nbytes & ~3u;
+    b.acc = 0; b.cnt = 0; b.marker = 0;
+    ByteCache bc = {0xffffffffu, 0u};
+    int pred[3] = {0, 0, 0};
+    const int ri = fr->restart_interval;
+    int left = ri;
+    int td[3], ta[3];
+    for (int c = 0; c < 3; ++c) { td[c] = fr->td[c] & 1; ta[c] = 2 + (fr->ta[c] & 1); }
+    int16_t* const out = coef + (int64_t)f * g.blocks * 64;
+
+    auto huff = [&](int t, int vbase, int vmask) -> int {
+        // 16 bits of look-ahead (fill_bits left > 48), the code-length search against this lane's maxcode column
+        const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
+        for (int l = 1; l <= 16; ++l) {
+            const int code = (int)(look >> (16 - l));
+            if (code <= s_max[(t * 16 + l - 1) * EW + lane]) {
+                b.cnt -= l;
+                return s_val[(vbase + ((code + s_off[(t * 16 + l - 1) * EW + lane]) & vmask)) * EW + lane];
+            }
+        }
+        b.cnt -= 16;       // corrupt stream: libjpeg warns and returns 0
+        return 0;
+    };
+
+    int blk = 0;
+    for (int m = 0; m < g.mcux * g.mcuy; ++m) {
+        if (ri) {
+            if (left == 0) {
+                // discard the partial byte, find the RSTn marker, step over it; DC predictions restart
+                b.cnt = 0; b.acc = 0;
+                uint32_t q = b.pos;
+                while (q + 1 < b.end) {
+                    if (byte_at(b, bc, q) == 0xFF) {
+                        const int m2 = byte_at(b, bc, q + 1);
+                        if (m2 >= 0xD0 && m2 <= 0xD7) break;
+                    }
+                    ++q;
+                }
+                if (q + 1 < b.end) b.pos = q + 2;
+                b.marker = 0;
+                pred[0] = pred[1] = pred[2] = 0;
+                left = ri;
+            }
+            --left;
+        }
+        for (int c = 0; c < g.ncomp; ++c) {
+            const int nb = g.hs[c] * g.vs[c];
+            for (int bi = 0; bi < nb; ++bi, ++blk) {
+                int16_t* const o = out + (int64_t)blk * 64;
+                fill_bits(b, bc);
+                int s = huff(td[c], td[c] * 16, 15);
+                if (s) { fill_bits(b, bc); s = extend(get_bits(b, s & 15), s & 15); }
+                pred[c] += s;
+                if (pred[c]) o[0] = (int16_t)pred[c];
+                for (int k = 1; k < 64; ++k) {
+                    fill_bits(b, bc);
+                    const int rs = huff(ta[c], 32 + (ta[c] - 2) * 256, 255);
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz) {
+                        k += r;
+                        const int v = extend(get_bits(b, sz), sz);          // (16 + 15 bits <= the 49 the fill guarantees)
+                        o[kNaturalDev[k]] = (int16_t)v;
+                    } else {
+                        if (r != 15) break;
+                        k += 15;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------
+#define GJ_CONST_BITS 13
+#define GJ_PASS1_BITS 2
+#define GJ_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+__device__ __forceinline__ uint32_t range_limit(int v) {       // post-IDCT range table: index v & 1023, centred on 128
+    const int i = v & 1023;
+    return i < 128 ? (uint32_t)(i + 128) : (i < 512 ? 255u : (i < 896 ? 0u : (uint32_t)(i - 896)));
+}
+
+__device__ __forceinline__ void idct_1d(int32_t in0, int32_t in1, int32_t in2, int32_t in3, int32_t in4, int32_t in5, int32_t in6,
+                                        int32_t in7, int32_t (&t)[8]) {
+    // one column (pass 1) or row (pass 2) of jpeg_idct_islow up to the final butterflies: t[0..3] = tmp10..13 (even part),
+    // t[4..7] = tmp0..3 (odd part)
+    int32_t z2 = in2, z3 = in6;
+    int32_t z1 = (z2 + z3) * 4433;
+    const int32_t e2 = z1 + z3 * (-15137), e3 = z1 + z2 * 6270;
+    const int32_t e0 = (int32_t)((uint32_t)(in0 + in4) << GJ_CONST_BITS), e1 = (int32_t)((uint32_t)(in0 - in4) << GJ_CONST_BITS);
+    t[0] = e0 + e3; t[3] = e0 - e3; t[1] = e1 + e2; t[2] = e1 - e2;
+    int32_t tmp0 = in7, tmp1 = in5, tmp2 = in3, tmp3 = in1;
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int32_t z4 = tmp1 + tmp3;
+    const int32_t z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+    z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z3 += z5; z4 += z5;
+    t[4] = tmp0 + z1 + z3; t[5] = tmp1 + z2 + z4; t[6] = tmp2 + z2 + z3; t[7] = tmp3 + z1 + z4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coef, const GrlJpegFrame* __restrict__ frames,
+                                                        int n, uint8_t* __restrict__ planes, Geo g) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)n * g.blocks) return;
+    const int f = (int)(gid / g.blocks), blk = (int)(gid % g.blocks);
+    const int mcu = blk / g.bpm;
+    int within = blk % g.bpm, c = 0;
+    while (within >= g.hs[c] * g.vs[c]) { within -= g.hs[c] * g.vs[c]; ++c; }
+    const int by = within / g.hs[c], bx = within % g.hs[c];
+    const int mx = mcu % g.mcux, my = mcu / g.mcux;
+    const uint16_t* q = frames[f].q[frames[f].tq[c] & 3];
+    const int16_t* in = coef + gid * 64;
+    int32_t v[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                 // 8 x 16-byte loads, dequantised on the way in
+        const uint4 cw = *reinterpret_cast<const uint4*>(in + 8 * i);
+        const uint4 qw = *reinterpret_cast<const uint4*>(q + 8 * i);
+        const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w}, qq[4] = {qw.x, qw.y, qw.z, qw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[8 * i + 2 * e] = (int32_t)(int16_t)(cc[e] & 0xffffu) * (int32_t)(qq[e] & 0xffffu);
+            v[8 * i + 2 * e + 1] = (int32_t)(int16_t)(cc[e] >> 16) * (int32_t)(qq[e] >> 16);
+        }
+    }
+    int32_t t[8];
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {           // pass 1: columns
+        idct_1d(v[col], v[8 + col], v[16 + col], v[24 + col], v[32 + col], v[40 + col], v[48 + col], v[56 + col], t);
+        const int sh = GJ_CONST_BITS - GJ_PASS1_BITS;
+        v[col] = GJ_DESCALE(t[0] + t[7], sh);      v[56 + col] = GJ_DESCALE(t[0] - t[7], sh);
+        v[8 + col] = GJ_DESCALE(t[1] + t[6], sh);  v[48 + col] = GJ_DESCALE(t[1] - t[6], sh);
+        v[16 + col] = GJ_DESCALE(t[2] + t[5], sh); v[40 + col] = GJ_DESCALE(t[2] - t[5], sh);
+        v[24 + col] = GJ_DESCALE(t[3] + t[4], sh); v[32 + col] = GJ_DESCALE(t[3] - t[4], sh);
+    }
+    uint8_t* dst = planes + (int64_t)f * g.plane_bytes + g.poff[c] + (int64_t)((my * g.vs[c] + by) * 8) * g.pw[c] + (mx * g.hs[c] + bx) * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                 // pass 2: rows, through the range table, one 8-byte store per row
+        idct_1d(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7], t);
+        const int sh = GJ_CONST_BITS + GJ_PASS1_BITS + 3;
+        const uint32_t o0 = range_limit(GJ_DESCALE(t[0] + t[7], sh)), o7 = range_limit(GJ_DESCALE(t[0] - t[7], sh));
+        const uint32_t o1 = range_limit(GJ_DESCALE(t[1] + t[6], sh)), o6 = range_limit(GJ_DESCALE(t[1] - t[6], sh));
+        const uint32_t o2 = range_limit(GJ_DESCALE(t[2] + t[5], sh)), o5 = range_limit(GJ_DESCALE(t[2] - t[5], sh));
+        const uint32_t o3 = range_limit(GJ_DESCALE(t[3] + t[4], sh)), o4 = range_limit(GJ_DESCALE(t[3] - t[4], sh));
+        uint2 w;
+        w.x = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        w.y = o4 | (o5 << 8) | (o6 << 16) | (o7 << 24);
+        *reinterpret_cast<uint2*>(dst + (int64_t)r * g.pw[c]) = w;
+    }
+}
+
+// ---- 3. chroma upsampling (jdsample.c) + colour conversion (jdcolor.c) ------------------------------------------------------
+__device__ __forceinline__ int up_sample(const uint8_t* __restrict__ p, int stride, int cw, int ch, int h2, int v2, int ox, int oy) {
+    const bool fancy = cw > 2;                    // jdsample.c: `do_fancy && compptr->downsampled_width > 2`
+    const int x = h2 ? ox >> 1 : ox;
+    if (!v2) {
+        const uint8_t* in = p + (int64_t)oy * stride;
+        if (!h2 || !fancy) return in[x];
+        if (ox & 1) return x == cw - 1 ? in[x] : (in[x] * 3 + in[x + 1] + 2) >> 2;
+        return x == 0 ? in[0] : (in[x] * 3 + in[x - 1] + 1) >> 2;
+    }
+    const int iy = oy >> 1, v = oy & 1;
+    const uint8_t* in0 = p + (int64_t)iy * stride;
+    if (!fancy || !h2) return in0[x];             // (h1v2 is outside the parser's scope)
+    int ny = v ? iy + 1 : iy - 1;                 // next-nearest row; beyond the image the edge row is replicated (jdmainct.c)
+    ny = ny < 0 ? 0 : (ny > ch - 1 ? ch - 1 : ny);
+    const uint8_t* in1 = p + (int64_t)ny * stride;
+    const int thiscol = in0[x] * 3 + in1[x];
+    if (ox & 1) return x == cw - 1 ? (thiscol * 4 + 7) >> 4 : (thiscol * 3 + (in0[x + 1] * 3 + in1[x + 1]) + 7) >> 4;
+    return x == 0 ? (thiscol * 4 + 8) >> 4 : (thiscol * 3 + (in0[x - 1] * 3 + in1[x - 1]) + 8) >> 4;
+}
+
+__device__ __forceinline__ uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, const GrlJpegFrame* __restrict__ frames,
+                                                         int n, uint8_t* __restrict__ out, Geo g) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t hw = (int64_t)g.width * g.height;
+    if (gid >= n * hw) return;
+    const int f = (int)(gid / hw);
+    const int y = (int)((gid % hw) / g.width), x = (int)(gid % g.width);
+    const uint8_t* pl = planes + (int64_t)f * g.plane_bytes;
+    const int Y = pl[g.poff[0] + (int64_t)y * g.pw[0] + x];
+    uint8_t* o = out + (int64_t)f * 3 * hw + (int64_t)y * g.width + x;
+    if (g.ncomp == 1) { o[0] = o[hw] = o[2 * hw] = (uint8_t)Y; return; }
+    const int h2 = g.hmax == 2, v2 = g.vmax == 2;
+    const int cbv = up_sample(pl + g.poff[1], g.pw[1], g.cw[1], g.ch[1], h2, v2, x, y);
+    const int crv = up_sample(pl + g.poff[2], g.pw[2], g.cw[2], g.ch[2], h2, v2, x, y);
+    if (frames[f].rgb) { o[0] = (uint8_t)Y; o[hw] = (uint8_t)cbv; o[2 * hw] = (uint8_t)crv; return; }
+    const int cb = cbv - 128, cr = crv - 128;
+    // jdcolor.c build_ycc_rgb_table: FIX(x) = (int)(x * 65536 + 0.5), ONE_HALF = 32768, arithmetic right shifts
+    o[0] = clamp8(Y + ((91881 * cr + 32768) >> 16));
+    o[hw] = clamp8(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16));
+    o[2 * hw] = clamp8(Y + ((116130 * cb + 32768) >> 16));
+}
+
+// ---- host: header parser ---------------------------------------------------------------------------------------------------
+void build_huff(const uint8_t* bits /*[17]*/, int32_t* maxcode /*[18]*/, int32_t* valoff /*[18]*/) {
+    int code = 0, k = 0;
+    maxcode[0] = -1; valoff[0] = 0;
+    for (int l = 1; l <= 16; ++l) {
+        valoff[l] = k - code;
+        if (bits[l]) {
+            k += bits[l];
+            code += bits[l];
+            maxcode[l] = code - 1;
+        } else {
+            maxcode[l] = -1;
+        }
+        code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff; valoff[17] = 0;
+}
+
+}  // namespace
+
+#define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
+
+extern "C" int grl_jpeg_parse(const uint8_t* p, int64_t len, int64_t base_off, GrlJpegFrame* out) {
+    GRL_REQUIRE(p && out && len >= 4 && base_off >= 0, "jpeg_parse: null / empty");
+    GRL_REQUIRE(base_off + len < (1ll << 32), "jpeg_parse: the batch buffer must stay below 4 GiB (32-bit stream offsets)");
+    if (p[0] != 0xFF || p[1] != 0xD8) return grl_fail(GRL_EINVAL, "jpeg_parse: no SOI marker");
+    GrlJpegFrame& f = *out;
+    memset(&f, 0, sizeof(f));
+    bool have_sof = false, have_scan = false, qpresent[4] = {false, false, false, false}, hpresent[4] = {false, false, false, false};
+    int adobe = -1;
+    const size_t n = (size_t)len;
+    size_t i = 2;
+    while (i + 4 <= n) {
+        if (p[i] != 0xFF) return grl_fail(GRL_EINVAL, "jpeg_parse: marker expected at byte %zu", i);
+        while (i < n && p[i] == 0xFF) ++i;
+        if (i >= n) break;
+        const int m = p[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) break;
+        if (i + 2 > n) break;
+        const size_t seg = ((size_t)p[i] << 8) | p[i + 1];
+        if (seg < 2 || i + seg > n) return grl_fail(GRL_EINVAL, "jpeg_parse: truncated segment 0x%02X", m);
+        const uint8_t* s = p + i + 2;
+        const size_t sl = seg - 2;
+        if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || s[0] != 8) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: %d-bit samples", sl ? (int)s[0] : 0);
+            f.height = (uint16_t)((s[1] << 8) | s[2]);
+            f.width = (uint16_t)((s[3] << 8) | s[4]);
+            f.ncomp = s[5];
+            if (f.ncomp != 1 && f.ncomp != 3) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: %d components", (int)f.ncomp);
+            if (sl < 6 + 3 * (size_t)f.ncomp || !f.width || !f.height) return grl_fail(GRL_EINVAL, "jpeg_parse: bad SOF");
+            for (int c = 0; c < f.ncomp; ++c) {
+                f.hs[c] = s[7 + 3 * c] >> 4;
+                f.vs[c] = s[7 + 3 * c] & 15;
+                f.tq[c] = s[8 + 3 * c];
+                if (f.tq[c] > 3 || !f.hs[c] || !f.vs[c]) return grl_fail(GRL_EINVAL, "jpeg_parse: bad SOF component");
+            }
+            have_sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: SOF%d (progressive / lossless / arithmetic) is outside the device decoder's scope", m - 0xC0);
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o + 17 <= sl) {
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3) return grl_fail(GRL_EINVAL, "jpeg_parse: bad DHT");
+                if (th > 1) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: Huffman table id %d (baseline allows 0..1)", th);
+                uint8_t bits[17];
+                int cnt = 0;
+                bits[0] = 0;
+                for (int l = 1; l <= 16; ++l) { bits[l] = s[o + l]; cnt += s[o + l]; }
+                if (cnt > 256 || o + 17 + cnt > sl) return grl_fail(GRL_EINVAL, "jpeg_parse: bad DHT counts");
+                const int t = tc * 2 + th;
+                if (tc == 0 && cnt > 16) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: DC table with %d symbols", cnt);
+                memset(f.vals[t], 0, 256);
+                memcpy(f.vals[t], s + o + 17, cnt);
+                build_huff(bits, f.maxcode[t], f.valoff[t]);
+                hpresent[t] = true;
+                o += 17 + cnt;
+            }
+        } else if (m == 0xDB) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                if (tq > 3 || pq > 1) return grl_fail(GRL_EINVAL, "jpeg_parse: bad DQT");
+                const size_t need = pq ? 129 : 65;
+                if (o + need > sl) return grl_fail(GRL_EINVAL, "jpeg_parse: truncated DQT");
+                for (int k = 0; k < 64; ++k)
+                    f.q[tq][kNaturalHost[k]] = pq ? (uint16_t)((s[o + 1 + 2 * k] << 8) | s[o + 2 + 2 * k]) : s[o + 1 + k];
+                qpresent[tq] = true;
+                o += need;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return grl_fail(GRL_EINVAL, "jpeg_parse: bad DRI");
+            f.restart_interval = (uint16_t)((s[0] << 8) | s[1]);
+        } else if (m == 0xEE) {
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) adobe = s[11];
+        } else if (m == 0xDA) {
+            if (!have_sof) return grl_fail(GRL_EINVAL, "jpeg_parse: SOS before SOF");
+            if (sl < 1 || s[0] != f.ncomp || sl < 1 + 2 * (size_t)f.ncomp + 3)
+                return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: non-interleaved scans are outside the device decoder's scope");
+            for (int c = 0; c < f.ncomp; ++c) {
+                f.td[c] = s[2 + 2 * c] >> 4;
+                f.ta[c] = s[2 + 2 * c] & 15;
+                if (f.td[c] > 1 || f.ta[c] > 1) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: Huffman table id > 1");
+            }
+            f.scan_off = (uint32_t)(base_off + (int64_t)(i + seg));
+            f.scan_len = (uint32_t)(n - (i + seg));
+            have_scan = true;
+            break;
+        }
+        i += seg;
+    }
+    if (!have_scan) return grl_fail(GRL_EINVAL, "jpeg_parse: no scan");
+    f.hmax = f.vmax = 1;
+    for (int c = 0; c < f.ncomp; ++c) {
+        if (f.hs[c] > f.hmax) f.hmax = f.hs[c];
+        if (f.vs[c] > f.vmax) f.vmax = f.vs[c];
+        if (!qpresent[f.tq[c]] || !hpresent[f.td[c]] || !hpresent[2 + f.ta[c]]) return grl_fail(GRL_EINVAL, "jpeg_parse: a table the scan uses is missing");
+    }
+    if (f.ncomp == 3) {
+        const bool chroma11 = f.hs[1] == 1 && f.vs[1] == 1 && f.hs[2] == 1 && f.vs[2] == 1;
+        const bool luma_ok = (f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 2);
+        if (!chroma11 || !luma_ok)
+            return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: sampling %dx%d / %dx%d / %dx%d (4:4:4, 4:2:2, 4:2:0 are in scope)", f.hs[0], f.vs[0],
+                            f.hs[1], f.vs[1], f.hs[2], f.vs[2]);
+        if (adobe == 0) f.rgb = 1;
+        else if (adobe == 2) return grl_fail(GRL_EUNSUPPORTED, "jpeg_parse: Adobe YCCK");
+    } else {
+        f.hs[0] = f.vs[0] = f.hmax = f.vmax = 1;      // a single-component scan is never interleaved: the factors are moot
+    }
+    return GRL_OK;
+}
+
+extern "C" int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n) {
+    if (!frame0 || n <= 0 || !frame0->width || !frame0->hmax) return 0;
+    const Geo g = make_geo(*frame0);
+    return (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t) + (int64_t)n * g.plane_bytes + 256;
+}
+
+extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* frames_dev, const GrlJpegFrame* frames_host, int n,
+                                     uint8_t* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    GRL_REQUIRE(bytes && frames_dev && frames_host && out && workspace && n > 0, "jpeg_decode_batch: null / empty");
+    GRL_REQUIRE(((uintptr_t)bytes & 3) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)frames_dev & 15) == 0,
+                "jpeg_decode_batch: bytes must be 4-byte aligned, the workspace and the descriptors 16-byte aligned");
+    static_assert(sizeof(GrlJpegFrame) == 2160 && offsetof(GrlJpegFrame, q) == 48, "GrlJpegFrame layout (include/grl_hip.h)");
+    const GrlJpegFrame& f0 = frames_host[0];
+    GRL_REQUIRE(f0.width && f0.height && (f0.ncomp == 1 || f0.ncomp == 3) && f0.hmax >= 1 && f0.hmax <= 2 && f0.vmax >= 1 && f0.vmax <= 2,
+                "jpeg_decode_batch: frame 0 was not parsed by grl_jpeg_parse");
+    uint32_t nbytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const GrlJpegFrame& f = frames_host[i];
+        bool same = f.width == f0.width && f.height == f0.height && f.ncomp == f0.ncomp && f.hmax == f0.hmax && f.vmax == f0.vmax;
+        for (int c = 0; c < f0.ncomp; ++c) same = same && f.hs[c] == f0.hs[c] && f.vs[c] == f0.vs[c];
+        if (!same) return grl_fail(GRL_EINVAL, "jpeg_decode_batch: frame %d has another geometry than frame 0 (decode per geometry group)", i);
+        const uint32_t e = f.scan_off + f.scan_len;
+        if (e < f.scan_off) return grl_fail(GRL_EINVAL, "jpeg_decode_batch: frame %d: stream range wraps", i);
+        if (e > nbytes) nbytes = e;
+    }
+    GRL_REQUIRE(workspace_bytes >= grl_jpeg_workspace_bytes(&f0, n), "jpeg_decode_batch: workspace too small (grl_jpeg_workspace_bytes)");
+    const Geo g = make_geo(f0);
+    hipStream_t s = (hipStream_t)stream;
+    int16_t* coef = reinterpret_cast<int16_t*>(workspace);
+    const int64_t coef_bytes = (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t);
+    uint8_t* planes = reinterpret_cast<uint8_t*>(workspace) + ((coef_bytes + 255) & ~(int64_t)255);
+    if (hipMemsetAsync(coef, 0, (size_t)coef_bytes, s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E_LDS);
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(grl_ceil_div(n, EW)), dim3(EW), E_LDS, s, bytes, nbytes, frames_dev, n, coef, g);
+    const int64_t nblk = (int64_t)n * g.blocks;
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, coef, frames_dev, n, planes, g);
+    const int64_t npix = (int64_t)n * g.width * g.height;
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, planes, frames_dev, n, out, g);
+    return grl_check_launch("grl_jpeg_decode_batch");
+}

@@ -159,28 +159,15 @@ def gemm(a, w, y, M, N, K, lda=0, ldw=None, ldy=None, scale=None, shift=None, re
     want_stats = stats is True
     if want_stats:
         stats = None
-    d = GrlGemm()
-    d.a, d.w, d.y = ptr(a), ptr(w), ptr(y)
-    d.scale, d.shift, d.res = ptr(scale), ptr(shift), ptr(res)
-    d.gbias, d.rowscale = ptr(gbias), ptr(rowscale)
-    d.rnorm, d.cnorm, d.stats = ptr(rnorm), ptr(cnorm), ptr(stats)
-    d.M, d.N, d.K = M, N, K
-    d.lda = lda or K
-    d.ldw = ldw or K
-    d.ldy = ldy or N
-    d.ldres = ldres or N
-    d.rows_per_group = rows_per_group
-    d.relu = 1 if relu else 0
-    d.epilogue = epilogue
-    d.math = (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if math is None else math
-    d.out_f32 = 1 if out_f32 else 0
-    d.kblock = 1 if kblock else 0
-    d.res_rows, d.res_gstride = res_rows, res_gstride
-    if bn is not None:                    # BatchNorm-backward reduce in the epilogue (GrlGemm.bn_z; with stats=True)
-        d.bn_z, d.bn_mean, d.bn_invstd, d.bn_mscale, d.bn_mbeta, d.bn_bits = (ptr(t) for t in bn)
-    if conv is not None:
-        d.conv = 1
-        (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
+    # one positional constructor call in the struct's field order (include/grl_hip.h GrlGemm / _lib.GrlGemm) instead of ~30
+    # attribute stores: this wrapper runs ~220 times per training step, which is host-bound in bf16 storage (round 6)
+    cv = (1,) + tuple(conv) if conv is not None else (0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    bnp = tuple(ptr(t) for t in bn) if bn is not None else ()        # BatchNorm-backward reduce in the epilogue (GrlGemm.bn_z; with stats=True)
+    d = GrlGemm(ptr(a), ptr(w), ptr(y), ptr(scale), ptr(shift), ptr(res), ptr(gbias), ptr(rowscale), ptr(rnorm), ptr(cnorm),
+                ptr(stats), M, N, K, lda or K, ldw or K, ldy or N, ldres or N, rows_per_group, 1 if relu else 0, epilogue,
+                cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7], cv[8], cv[9],
+                (MATH_F32 if _math[0] == MATH_BF16S else _math[0]) if math is None else math, 1 if out_f32 else 0,
+                res_rows, res_gstride, 1 if kblock else 0, None, 0, *bnp)
     lib = _lib.load()
     if SPLITK and kblock and conv is None and M <= 256 and K > 512:      # skinny K-blocked GEMM: split-K scratch (include/grl_hip.h)
         need = lib.grl_conv_gemm_f32_workspace_floats(C.byref(d))
@@ -1129,6 +1116,16 @@ class DevicePrefetcher(object):
             imgs, pids, cams, *extra = next(self.it)   # extra: e.g. the augmentation parameter block
         except StopIteration:
             self._next = None
+            return
+        from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+        if isinstance(imgs, JpegBatch):
+            # compressed frames (a loader with decode='device'): the bytes cross PCIe, grl_jpeg_decode_batch turns them
+            # into the uint8 clip tensor on the prefetch stream, next to the current batch's compute (video_loader.py:124-141)
+            with torch.cuda.stream(self.stream):
+                d = decode_jpeg_batch(imgs, self.dev)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._next = (d, pids, cams, ev, None, extra)
             return
         if imgs.dtype not in (torch.uint8, torch.float32):
             imgs = imgs.float()

@@ -53,9 +53,14 @@ class RawVideoDataset(Dataset):
     ``augment.draw_clip_params`` that SEQTrainer hands to grl_augment_normalize_u8.  All frames of a
     batch must share one size (MARS crops are 256 x 128; other sizes are RectScale'd on the device)."""
 
-    def __init__(self, tracklets, seq_len=4, sample='rrs_train', augment=False, height=256, width=128):
+    def __init__(self, tracklets, seq_len=4, sample='rrs_train', augment=False, height=256, width=128, decode='host'):
+        """``decode``: 'host' -- the worker decodes with Pillow (items carry uint8 tensors); 'device' -- the worker only
+        reads the files, items carry the JPEG byte strings, the loader uses ``jpeg.jpeg_collate`` and
+        engine.DevicePrefetcher decodes the batch on the GPU (grl_jpeg_decode_batch, bit-identical to Pillow)."""
+        if decode not in ('host', 'device'):
+            raise ValueError("decode must be 'host' or 'device'")
         self.tracklets, self.seq_len, self.sample = list(tracklets), seq_len, sample
-        self.augment, self.height, self.width = augment, height, width
+        self.augment, self.height, self.width, self.decode = augment, height, width, decode
 
     def __len__(self):
         return len(self.tracklets)
@@ -71,6 +76,14 @@ class RawVideoDataset(Dataset):
         from .augment import draw_clip_params, sample_frame_indices
         paths, pid, camid = self.tracklets[index]
         idx = sample_frame_indices(len(paths), self.seq_len, self.sample)
+        if self.decode == 'device':
+            if self.sample == 'dense':
+                raise NotImplementedError("decode='device' serves fixed-length clips (rrs_train / rrs_test); dense mode decodes on the host")
+            from .jpeg import read_file
+            item = ([read_file(paths[int(i)]) for i in idx], pid, camid)
+            if self.augment:
+                item += (torch.tensor(draw_clip_params(self.seq_len, self.height, self.width), dtype=torch.int32),)
+            return item
         if self.sample == 'dense':
             clip = torch.stack([torch.stack([self._decode(paths[int(i)]) for i in row]) for row in idx])
         else:

@@ -304,9 +304,7 @@ class Tape(object):
     def wgrad_join(self):
         """The launch stream waits for the weight-gradient stream (parameter gradients are about to be read)."""
         if self.wheld:
-            ev = torch.cuda.Event()
-            ev.record(_wgrad_stream(self.dev))
-            torch.cuda.current_stream(self.dev).wait_event(ev)
+            check(_lib.load().grl_stream_wait_stream(_lib.stream(), _wgrad_stream(self.dev).cuda_stream), 'grl_stream_wait_stream')
             self.wheld = []
 
     def flush(self, lo=0, label='rest'):
@@ -455,8 +453,10 @@ RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B an
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
 
 
-def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None):
-    """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32 (datapath: the training math mode)."""
+def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None, stream=None):
+    """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32 (datapath: the training math mode).  ``stream``: a raw
+    hipStream_t to launch on instead of torch's current stream (wgrad_async); returns the workspace tensor (the caller of
+    a side-stream launch keeps it alive until the streams join)."""
     d = GrlWgrad()
     d.math = _train_math[0] if math is None else math
     d.dz, d.x, d.dw = ptr(dz), ptr(x), ptr(dw)
@@ -475,9 +475,10 @@ def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate
     lib = _lib.load()
     ws = torch.empty(lib.grl_wgrad_workspace_floats(C.byref(d)), dtype=torch.float32, device=dz.device)
     d.workspace = ptr(ws)
-    check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream()), 'grl_conv_wgrad_f32')
+    check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream() if stream is None else stream), 'grl_conv_wgrad_f32')
     if engine._DEBUG_SYNC:
         engine._debug_sync('wgrad %s bf16-in %d conv %s' % ((M, N, K), d.in_bf16, conv))
+    return ws
 
 
 # A layer's weight gradient depends on nothing downstream of it and nothing waits for it before the optimizer (or the
@@ -499,14 +500,17 @@ def _wgrad_stream(dev):
 def wgrad_async(tp, dz, x, dw, M, N, K, **kw):
     """``wgrad`` on the weight-gradient stream (ordered after everything issued so far on the current one)."""
     if not WGRAD_STREAM:
-        return wgrad(dz, x, dw, M, N, K, **kw)
-    ws = _wgrad_stream(tp.dev)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(tp.dev))
-    ws.wait_event(ev)
-    with torch.cuda.stream(ws):
         wgrad(dz, x, dw, M, N, K, **kw)
-    tp.wheld.extend((dz, x, dw))
+        return
+    # Round 6: the hand-off is ONE C call (grl_stream_wait_stream: pooled event, record + wait) and the launch takes the
+    # side stream's raw handle -- no torch.cuda.Event, no `with torch.cuda.stream(..)` (15-30 us of Python per weight
+    # gradient, ~65 per step, on a step that is host-bound in bf16 storage).  The workspace is allocated under the CURRENT
+    # stream and, like the operands, held until the streams join (Tape.wgrad_join): its block cannot be handed out again
+    # before the launch stream has waited for the weight-gradient stream.
+    wsh = _wgrad_stream(tp.dev).cuda_stream
+    check(_lib.load().grl_stream_wait_stream(wsh, _lib.stream()), 'grl_stream_wait_stream')
+    buf = wgrad(dz, x, dw, M, N, K, stream=wsh, **kw)
+    tp.wheld.extend((dz, x, dw, buf))
 
 
 def colsum_into(g, M, Ccols, out, ld=None):
@@ -518,7 +522,7 @@ def colsum_into(g, M, Ccols, out, ld=None):
 
 
 class _BNState(object):
-    __slots__ = ('mean', 'invstd', 'scale', 'shift', 'beta')
+    __slots__ = ('mean', 'invstd', 'scale', 'shift', 'beta', 'buf')
 
 
 def bn_apply(z, st, res, y, M, Cc, relu, bits=None):
@@ -533,7 +537,11 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     half of a concatenated pair, so that no copy follows."""
     st = _BNState()
     buf = torch.empty((4, Cc), dtype=torch.float32, device=dev) if out is None else out
-    st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
+    # the four vectors as raw row addresses of `buf` (ptr() passes ints through): four tensor slices per BatchNorm were
+    # ~10 us of host time, 89 times per step
+    base, row = buf.data_ptr(), buf.stride(0) * 4
+    st.buf = buf
+    st.mean, st.invstd, st.scale, st.shift = base, base + row, base + 2 * row, base + 3 * row
     gamma = bn.weight if gamma is None else gamma
     beta = bn.bias if beta is None else beta
     rm = bn.running_mean if rm is None else rm

@@ -35,9 +35,14 @@ const char* grl_last_error(void);
 /* Bumped on every incompatible change of a struct layout or an argument list below; grl_amd/_lib.py refuses a
  * library whose version differs from the one it was written against (round 1: 1, round 2: 2 -- GrlGemm / GrlWgrad
  * grew, grl_bn_bwd gained two pointers -- round 3: 3, then 4 with grl_stem_wgrad, relu_bits, 5: GrlGemm.bn_*;
- * round 4: 6 with grl_bottleneck_tail_bf16, 7 grl_gemm_force_tile; round 5: 8 with grl_conv_gemm_f32_group). */
-#define GRL_ABI_VERSION 8
+ * round 4: 6 with grl_bottleneck_tail_bf16, 7 grl_gemm_force_tile; round 5: 8 with grl_conv_gemm_f32_group;
+ * round 6: 9 with the grl_jpeg_* entry points). */
+#define GRL_ABI_VERSION 9
 int grl_abi_version(void);
+/* `waiter` (a hipStream_t) waits for everything enqueued on `signaler` so far: hipEventRecord + hipStreamWaitEvent on a
+ * pooled event, one call instead of the host framework's Event / stream-context objects (round 6: the train step is
+ * host-bound in bf16 storage; this is the side-stream hand-off of the weight-gradient launches).  Not a reference op. */
+int grl_stream_wait_stream(void* waiter, void* signaler);
 
 /* epilogue selector of grl_conv_gemm_f32 */
 #define GRL_EPI_AFFINE  0   /* y = relu?( rs[m]*(acc + gbias[m/rpg][n])*scale[n] + shift[n] + res[m][n] ) */
@@ -642,6 +647,45 @@ typedef struct GrlBneckTailF32 {
 } GrlBneckTailF32;
 int grl_bottleneck_tail_f32(const GrlBneckTailF32* desc, void* stream);
 int grl_bottleneck_tail_f32_supported(int P, int C4, int Pn);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Frame decode on the device (round 6).  Replaces the per-frame
+ * `Image.open(img_path).convert('RGB')` of reid/data/video_loader.py:124-141 (and :91-96, :108-113): baseline JPEG
+ * -> uint8 RGB, BIT-IDENTICAL to Pillow / libjpeg-turbo with libjpeg's defaults (ISLOW integer IDCT, fancy
+ * upsampling): Huffman decoding (one lane per frame: a scan is a serial bit stream), dequantisation + jidctint's
+ * integer IDCT (one lane per 8 x 8 block), triangle-filter chroma upsampling + YCbCr -> RGB (one lane per pixel).
+ * Scope: 8-bit baseline / extended-sequential Huffman, one interleaved scan, 1 or 3 components, luma sampling 1x1,
+ * 2x1 or 2x2 (4:4:4, 4:2:2, 4:2:0 -- MARS' frames are 256 x 128 4:2:0), table ids 0..1, restart intervals.
+ * Anything else is refused by the parser with GRL_EUNSUPPORTED: the caller (grl_amd/reid/data/jpeg.py) says so
+ * loudly -- it does not decode on the host behind the caller's back.
+ */
+#define GRL_EUNSUPPORTED -3  /* a valid JPEG outside the scope above (progressive, arithmetic, CMYK, 12-bit, 4:4:0 ...) */
+
+typedef struct GrlJpegFrame {      /* one parsed frame: filled on the host by grl_jpeg_parse, read by the kernels */
+    uint32_t scan_off;             /* entropy-coded segment: offset into the batch's byte buffer, length */
+    uint32_t scan_len;
+    uint16_t width, height;
+    uint16_t restart_interval;     /* MCUs between RSTn markers, 0 = none */
+    uint8_t  ncomp, hmax, vmax, rgb;   /* rgb: components are R, G, B (Adobe transform 0): no colour conversion */
+    uint8_t  hs[4], vs[4];         /* sampling factors per component */
+    uint8_t  tq[4], td[4], ta[4];  /* quantisation / DC / AC table of each component */
+    uint8_t  pad_[10];             /* (q starts at byte 48; sizeof == 2160 == 16 * 135: 16-byte loads of q rows) */
+    uint16_t q[4][64];             /* quantisation tables, natural (row-major) order */
+    int32_t  maxcode[4][18];       /* Huffman tables [DC0, DC1, AC0, AC1]: largest code of each length (-1: none) */
+    int32_t  valoff[4][18];        /*   symbol index = code + valoff[length] */
+    uint8_t  vals[4][256];         /*   symbols in code order */
+} GrlJpegFrame;
+
+/* HOST function (no GPU call): parse the headers of ONE JPEG stream `data[0..len)` that will sit at byte `base_off` of
+ * the batch buffer.  Returns GRL_OK, GRL_EINVAL (not a JPEG / truncated) or GRL_EUNSUPPORTED. */
+int grl_jpeg_parse(const uint8_t* data, int64_t len, int64_t base_off, GrlJpegFrame* out);
+/* bytes of device scratch grl_jpeg_decode_batch needs for n frames of frame 0's geometry (coefficients + planes) */
+int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n);
+/* n frames of ONE geometry (width, height, components, sampling: as frames[0]; frames_host is checked) ->
+ * out uint8 [n][3][height][width] (planar RGB: the layout the clip tensors [B][T][3][H][W] have).
+ * bytes: the concatenated streams (device); frames_dev: the n parsed descriptors (device copy of frames_host). */
+int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* frames_dev, const GrlJpegFrame* frames_host, int n,
+                          uint8_t* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

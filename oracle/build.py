@@ -9,12 +9,12 @@ OUT = os.path.join(HERE, 'libgrl_oracle.so')
 
 
 def build(force=False):
-    src = os.path.join(HERE, 'ref_c', 'gemm_chain.c')
+    srcs = [os.path.join(HERE, 'ref_c', f) for f in ('gemm_chain.c', 'jpeg_baseline.c')]
     if (not force and os.path.isfile(OUT)
-            and os.path.getmtime(OUT) >= os.path.getmtime(src)):
+            and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs)):
         return OUT
     subprocess.check_call(['gcc', '-O2', '-mfma', '-ffp-contract=off', '-fopenmp', '-shared',
-                           '-fPIC', src, '-o', OUT, '-lm'])
+                           '-fPIC'] + srcs + ['-o', OUT, '-lm'])
     return OUT
 
 

@@ -14,6 +14,10 @@ def _lib():
         _LIB = C.CDLL(build())
         _LIB.grl_oracle_chain_gemm.restype = C.c_int
         _LIB.grl_oracle_chain_gemm.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p] * 2 + [C.c_int]
+        _LIB.grl_oracle_jpeg_info.restype = C.c_int
+        _LIB.grl_oracle_jpeg_info.argtypes = [C.c_char_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
+        _LIB.grl_oracle_jpeg_decode.restype = C.c_int
+        _LIB.grl_oracle_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
     return _LIB
 
 
@@ -34,3 +38,19 @@ def chain_gemm(a, w, mode=0, rn=None, cn=None, kblock=False):
     if rc:
         raise RuntimeError('grl_oracle_chain_gemm failed: %d' % rc)
     return y
+
+
+def jpeg_decode(data):
+    """Baseline-JPEG bytes -> uint8 [H, W, 3] RGB: the C restatement of Pillow's Image.open(..).convert('RGB')
+    (oracle/ref_c/jpeg_baseline.c).  Raises ValueError with the oracle's code for streams outside its scope."""
+    lib = _lib()
+    v = [C.c_int() for _ in range(5)]
+    rc = lib.grl_oracle_jpeg_info(data, len(data), *[C.byref(x) for x in v])
+    if rc:
+        raise ValueError('jpeg oracle: header rejected (%d)' % rc)
+    w, h = v[0].value, v[1].value
+    out = np.empty((h, w, 3), np.uint8)
+    rc = lib.grl_oracle_jpeg_decode(data, len(data), out.ctypes.data)
+    if rc:
+        raise ValueError('jpeg oracle: decode failed (%d)' % rc)
+    return out

@@ -1,0 +1,137 @@
+"""Frame decode on the device (grl_jpeg_decode_batch, grl_amd/csrc/jpeg.hip) through the C ABI: bit-identical to Pillow's
+`Image.open(f).convert('RGB')` (/root/reference/reid/data/video_loader.py:124-141), to the committed fixture and to the C
+oracle; batches across workgroup boundaries; the loader -> prefetcher -> extract_features path on real files."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu_models(synth_models):
+    assert torch.cuda.is_available()
+    cnn, siam, siamv = synth_models
+    dev = torch.device('cuda:0')
+    return cnn.to(dev).eval(), siam.to(dev).eval(), siamv.to(dev).eval()
+
+
+def _frame(h, w, rng, grey=False):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = np.stack([128 + 90 * np.sin(xx / rng.uniform(5, 40) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(6, 60) + rng.uniform(0, 6))
+                     for _ in range(3)], -1)
+    img = np.clip(base + rng.normal(0, 22, (h, w, 3)), 0, 255).astype(np.uint8)
+    return img[..., 0] if grey else img
+
+
+def _encode(img, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format='JPEG', **kw)
+    return buf.getvalue()
+
+
+def _pil_chw(data):
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(data)).convert('RGB')).transpose(2, 0, 1))
+
+
+def test_device_decode_matches_the_committed_pillow_fixture(golden):
+    from grl_amd.reid.data.jpeg import decode_jpeg_batch
+    from oracle.ref_c import jpeg_decode
+    g = golden('jpeg_frames.npz')
+    for nm in [k[5:] for k in g.files if k.startswith('jpeg.')]:
+        data = g['jpeg.' + nm].tobytes()
+        got = decode_jpeg_batch([data], 'cuda')
+        want = g['rgb.' + nm].transpose(2, 0, 1)
+        assert got.shape == (1,) + want.shape and got.dtype == torch.uint8
+        assert np.array_equal(got[0].cpu().numpy(), want), nm
+        assert np.array_equal(got[0].cpu().numpy(), jpeg_decode(data).transpose(2, 0, 1)), nm
+
+
+@pytest.mark.parametrize('h,w', [(256, 128), (17, 33), (250, 130), (1, 1), (31, 2), (64, 48)])
+@pytest.mark.parametrize('sub', [0, 1, 2])
+def test_device_decode_is_bit_identical_to_pillow(h, w, sub):
+    """sizes on and off the MCU grid, 4:4:4 / 4:2:2 / 4:2:0; per batch: qualities 30..100, default and optimised Huffman
+    tables (per-frame tables in LDS), restart intervals -- frames of ONE geometry in one launch."""
+    from grl_amd.reid.data.jpeg import decode_jpeg_batch
+    rng = np.random.default_rng(h * 1000 + w + sub)
+    streams = []
+    for q, kw in ((30, {}), (75, dict(optimize=True)), (90, {}), (100, {}), (60, dict(restart_marker_blocks=2)), (85, dict(restart_marker_rows=1))):
+        try:
+            streams.append(_encode(_frame(h, w, rng), quality=q, subsampling=sub, **kw))
+        except OSError:
+            continue
+    streams.append(_encode(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), quality=95, subsampling=sub))     # white noise
+    got = decode_jpeg_batch(streams, 'cuda').cpu().numpy()
+    for i, s in enumerate(streams):
+        assert np.array_equal(got[i], _pil_chw(s)), (h, w, sub, i)
+
+
+def test_device_decode_batches_across_workgroups_and_grey():
+    """130 frames of MARS geometry = three 64-frame entropy workgroups (the last with 2 live lanes), every frame with its
+    own content and quality; grey frames; the [B, T] batch shape of a clip tensor."""
+    from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+    rng = np.random.default_rng(7)
+    streams = [_encode(_frame(256, 128, rng), quality=int(rng.integers(40, 98))) for _ in range(130)]
+    got = decode_jpeg_batch(JpegBatch(streams, (65, 2)), 'cuda')
+    assert got.shape == (65, 2, 3, 256, 128)
+    flat = got.view(130, 3, 256, 128).cpu().numpy()
+    for i in (0, 1, 63, 64, 65, 127, 128, 129):
+        assert np.array_equal(flat[i], _pil_chw(streams[i])), i
+    again = decode_jpeg_batch(JpegBatch(streams, (65, 2)), 'cuda')
+    assert torch.equal(got, again)
+    grey = [_encode(_frame(48, 40, rng, grey=True), quality=q) for q in (50, 90)]
+    gg = decode_jpeg_batch(grey, 'cuda').cpu().numpy()
+    for i, s in enumerate(grey):
+        assert np.array_equal(gg[i], _pil_chw(s))
+
+
+def test_device_decode_rejects_mixed_geometry_and_has_no_host_fallback():
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import JpegUnsupported, decode_jpeg_batch
+    rng = np.random.default_rng(3)
+    a, b = _encode(_frame(32, 32, rng), quality=80), _encode(_frame(48, 32, rng), quality=80)
+    with pytest.raises(_lib.GrlHipError, match='another geometry'):
+        decode_jpeg_batch([a, b], 'cuda')
+    with pytest.raises(JpegUnsupported):
+        decode_jpeg_batch([_encode(_frame(32, 32, rng), progressive=True)], 'cuda')
+    with pytest.raises(_lib.GrlHipError, match='MI355X only'):
+        decode_jpeg_batch([a], 'cpu')
+
+
+def test_loader_to_features_with_device_decode(tmp_path, gpu_models):
+    """The reference's loader path on real files: tracklets of JPEG frames -> RawVideoDataset(decode='device') (workers
+    only read the files) -> jpeg_collate -> engine.DevicePrefetcher (decode on the prefetch stream) ->
+    engine.extract_features; the features equal the ones of the host-decoded (Pillow) uint8 clips bit for bit."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from grl_amd import engine
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.jpeg import jpeg_collate
+    cnn, siam, _ = gpu_models
+    rng = np.random.default_rng(11)
+    tracklets = []
+    for tr in range(4):
+        paths = []
+        for fi in range(6):
+            p = os.path.join(tmp_path, 't%d_f%d.jpg' % (tr, fi))
+            Image.fromarray(_frame(256, 128, rng)).save(p, format='JPEG', quality=92)
+            paths.append(p)
+        tracklets.append((paths, tr, tr % 2))
+    dev_ds = RawVideoDataset(tracklets, seq_len=4, sample='rrs_test', decode='device')
+    host_ds = RawVideoDataset(tracklets, seq_len=4, sample='rrs_test', decode='host')
+    dev_loader = DataLoader(dev_ds, batch_size=2, collate_fn=jpeg_collate, num_workers=0)
+    host_loader = DataLoader(host_ds, batch_size=2, num_workers=0)
+    feats = {}
+    for name, loader in (('device', dev_loader), ('host', host_loader)):
+        rows = []
+        for clips, pids, cams in engine.DevicePrefetcher(loader, 'cuda'):
+            assert clips.dtype == torch.uint8 and clips.shape == (2, 4, 3, 256, 128)
+            rows.append(engine.extract_features(cnn, siam, clips))
+        feats[name] = torch.cat(rows)
+    assert feats['device'].shape == (4, 6144)
+    assert torch.equal(feats['device'], feats['host'])

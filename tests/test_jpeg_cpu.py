@@ -1,0 +1,130 @@
+"""Frame decode, CPU half: the C oracle (oracle/ref_c/jpeg_baseline.c) against Pillow itself --
+`Image.open(f).convert('RGB')`, the call of /root/reference/reid/data/video_loader.py:124-141 -- and against the
+committed fixture; the product library's HOST header parser (grl_jpeg_parse: no GPU call) against the same streams."""
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+
+from oracle.ref_c import jpeg_decode
+
+
+def _frame(h, w, rng, grey=False):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = np.stack([128 + 90 * np.sin(xx / rng.uniform(5, 40) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(6, 60) + rng.uniform(0, 6))
+                     for _ in range(3)], -1)
+    img = np.clip(base + rng.normal(0, 25, (h, w, 3)), 0, 255).astype(np.uint8)
+    return img[..., 0] if grey else img
+
+
+def _encode(img, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format='JPEG', **kw)
+    return buf.getvalue()
+
+
+def _pil(data):
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+
+
+def test_jpeg_oracle_matches_the_committed_pillow_fixture(golden):
+    g = golden('jpeg_frames.npz')
+    names = [k[5:] for k in g.files if k.startswith('jpeg.')]
+    assert len(names) >= 6
+    for nm in names:
+        got = jpeg_decode(g['jpeg.' + nm].tobytes())
+        assert np.array_equal(got, g['rgb.' + nm]), nm
+
+
+def test_jpeg_oracle_is_bit_identical_to_pillow_on_a_sweep():
+    """Sizes on and off the MCU grid (down to 1 x 1), 4:4:4 / 4:2:2 / 4:2:0, qualities 5..100 (quality 100 = quantiser 1:
+    saturating blocks), optimised Huffman tables, restart intervals, grey, saturated colours, white noise."""
+    pytest.importorskip('PIL')
+    rng = np.random.default_rng(0)
+    n = 0
+    for (h, w) in [(256, 128), (16, 16), (8, 8), (17, 33), (250, 130), (1, 1), (3, 5), (100, 37), (31, 2), (5, 3), (64, 48)]:
+        for sub in (0, 1, 2):
+            for q, opt in ((30, False), (75, True), (90, False), (100, True)):
+                try:
+                    data = _encode(_frame(h, w, rng), quality=q, subsampling=sub, optimize=opt)
+                except OSError:                  # Pillow's encoder buffer is too small for some tiny optimised frames
+                    continue
+                assert np.array_equal(jpeg_decode(data), _pil(data)), (h, w, sub, q, opt)
+                n += 1
+    for sub in (0, 1, 2):
+        for q in (5, 50, 100):
+            noise = rng.integers(0, 256, (96, 80, 3), dtype=np.uint8)
+            sat = np.zeros((64, 96, 3), np.uint8)
+            sat[:, :48] = (255, 0, 0); sat[:32, 48:] = (0, 0, 255); sat[32:, 48:] = (255, 255, 255)
+            for img, kw in ((noise, {}), (sat, {}), (noise, dict(restart_marker_blocks=1)), (noise, dict(restart_marker_rows=1)),
+                            (noise[:40, :24], dict(restart_marker_blocks=5))):
+                data = _encode(np.ascontiguousarray(img), quality=q, subsampling=sub, **kw)
+                assert np.array_equal(jpeg_decode(data), _pil(data)), (sub, q, kw)
+                n += 1
+    for (h, w) in [(256, 128), (17, 33)]:
+        data = _encode(_frame(h, w, rng, grey=True), quality=85)
+        assert np.array_equal(jpeg_decode(data), _pil(data))
+        n += 1
+    data = _encode(rng.integers(0, 256, (48, 40, 3), dtype=np.uint8), qtables=[[1] * 64, [3] * 64])
+    assert np.array_equal(jpeg_decode(data), _pil(data))
+    assert n > 150
+
+
+def test_jpeg_oracle_and_parser_refuse_what_is_out_of_scope(golden):
+    pytest.importorskip('PIL')
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import JpegBatch, JpegUnsupported
+    rng = np.random.default_rng(1)
+    prog = _encode(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8), progressive=True)
+    with pytest.raises(ValueError, match=r'\(-2\)'):
+        jpeg_decode(prog)
+    with pytest.raises(ValueError, match=r'\(-1\)'):
+        jpeg_decode(b'\x00\x01 not a jpeg')
+    with pytest.raises(JpegUnsupported, match='progressive'):
+        JpegBatch([prog], (1,)).pack()
+    with pytest.raises(_lib.GrlHipError, match='SOI'):
+        JpegBatch([b'\x00\x01 not a jpeg at all'], (1,)).pack()
+    with pytest.raises(_lib.GrlHipError):                                   # truncated inside the headers
+        JpegBatch([g_bytes(golden)[:200]], (1,)).pack()
+
+
+def g_bytes(golden):
+    return golden('jpeg_frames.npz')['jpeg.mars_420_q90'].tobytes()
+
+
+def test_host_header_parser_fills_the_frame_descriptor(golden):
+    """grl_jpeg_parse (host code of libgrl_hip.so, no GPU call): geometry, sampling, table selectors, restart interval,
+    quantisation tables in natural order and canonical Huffman tables for every fixture stream; offsets are relative to
+    the batch buffer."""
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import JpegBatch
+    g = golden('jpeg_frames.npz')
+    names = [k[5:] for k in g.files if k.startswith('jpeg.')]
+    streams = [g['jpeg.' + nm].tobytes() for nm in names]
+    frames = []
+    for s in streams:                       # one geometry per pack() is a decode-time rule; parsing is per stream
+        frames.append(JpegBatch([s], (1,)).pack()[1][0])
+    for nm, s, f in zip(names, streams, frames):
+        h, w = g['rgb.' + nm].shape[:2]
+        assert (f.height, f.width) == (h, w), nm
+        assert s[f.scan_off - 2 - (6 + 2 * f.ncomp):f.scan_off][:2] == b'\xff\xda'          # the scan starts right behind SOS
+        assert f.scan_off + f.scan_len == len(s)
+        assert f.ncomp == (1 if nm.startswith('grey') else 3)
+        want = {'mars': (2, 2), 'small_444': (1, 1), 'odd_422': (2, 1), 'odd_420': (2, 2), 'grey': (1, 1)}
+        assert (f.hmax, f.vmax) == next(v for k, v in want.items() if nm.startswith(k)), nm
+        assert f.restart_interval == (3 if nm.endswith('rst') else 0)
+        assert all(1 <= f.q[f.tq[c]][k] <= 255 for c in range(f.ncomp) for k in range(64))
+        for t in ([0, 2] if f.ncomp == 1 else [0, 1, 2, 3]):
+            mc = list(f.maxcode[t])
+            assert mc[17] == 0x7fffffff and any(m >= 0 for m in mc[1:17])
+    # offsets inside a batch buffer
+    two = JpegBatch([streams[0], streams[1]], (2,))
+    host, fr = two.pack()
+    assert fr[1].scan_off == len(streams[0]) + frames[1].scan_off and host.numel() % 8 == 0
+    assert bytes(host[:len(streams[0])].numpy().tobytes()) == streams[0]
+    lib = _lib.load()
+    assert lib.grl_jpeg_workspace_bytes(C.byref(fr[0]), 2) >= 2 * (768 * 128 + 256 * 128 * 3 // 2)
+    assert lib.grl_jpeg_decode_batch(None, None, fr, 2, None, None, 0, None) == -1             # argument checks need no GPU

@@ -67,12 +67,33 @@ def main():
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     print('unprofiled: issue %.2f ms / step, wall %.2f ms / step' % (t_issue / a.steps * 1e3, t_all / a.steps * 1e3))
+    # the backward closures run on the autograd engine's device thread, which a profiler enabled here does not see:
+    # Tape.backward is wrapped so that it profiles itself on whatever thread calls it
+    bw = cProfile.Profile()
+    orig_bw = train_engine.Tape.backward
+
+    def profiled_backward(self):
+        bw.enable()
+        try:
+            return orig_bw(self)
+        finally:
+            bw.disable()
+    train_engine.Tape.backward = profiled_backward
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(a.steps):
         step()
     pr.disable()
     torch.cuda.synchronize()
+    train_engine.Tape.backward = orig_bw
+    s = io.StringIO()
+    pstats.Stats(bw, stream=s).strip_dirs().sort_stats('tottime').print_stats(a.top)
+    print('==== Tape.backward (autograd thread), %d steps ====' % a.steps)
+    print(s.getvalue())
+    s = io.StringIO()
+    pstats.Stats(bw, stream=s).strip_dirs().sort_stats('cumulative').print_stats(40)
+    print(s.getvalue())
+    print('==== main thread ====')
     s = io.StringIO()
     st = pstats.Stats(pr, stream=s).strip_dirs().sort_stats(a.sort)
     st.print_stats(a.top)

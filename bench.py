@@ -515,6 +515,28 @@ def release_cached_blocks():
     torch.cuda.empty_cache()
 
 
+def decode_block():
+    """Frame decode next to the model: grl_jpeg_decode_batch (device, bit-identical to Pillow) on synthetic MARS-size
+    JPEG frames (256 x 128, 4:2:0, quality 90) against Pillow on ONE host core (the reference's eval loaders run with 0
+    workers, dataloader.py:77-79), and the frame rates the eval series consume.  Informational; bounded to ~3 s."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import decode_rate
+        frames = decode_rate.make_frames(64)
+        decode_rate._init(frames)
+        decode_rate._decode_range((0, 32))
+        t0 = time.perf_counter()
+        decode_rate._decode_range((0, 512))
+        host = 512 / (time.perf_counter() - t0)
+        dev_r = decode_rate.device_rates(frames, batches=(128, 512))
+        return {"host_pillow_frames_per_sec_one_core": round(host), "device": dev_r,
+                "mean_jpeg_kb": round(sum(len(f) for f in frames) / len(frames) / 1024.0, 1),
+                "consumers_frames_per_sec": "fp32 eval headline ~8.9 k, bf16-storage configs[2] ~53 k, bf16s train ~7.3 k",
+                "profiles": "profiles/r06_decode_rate.json: Pillow with 1..128 worker processes on the node (5.8 k / worker, 88 k at 16)"}
+    except Exception as e:                                  # noqa: BLE001 (informational block: never fails the line)
+        return {"error": repr(e)[:300]}
+
+
 def secondary_block(dev, cnn, siam, steps):
     """Informational series measured by the SAME default run (so the driver's record holds them too):
     BASELINE configs[2] (64 clips x 8 frames, bf16 storage), the train step (fp32 and the bf16x3
@@ -549,6 +571,7 @@ def secondary_block(dev, cnn, siam, steps):
     release_cached_blocks()
     v["frames_per_sec"] = round(512 / v["ms_per_step"] * 1e3)
     out["configs[2] as a training batch: P x K = 16 x 4, T = 8, bf16 storage (fwd + loss + bwd + SGD)"] = v
+    out["input pipeline: frame decode (SURVEY 8(f) rank 4; video_loader.py:124-141)"] = decode_block()
     qf, gf = synth_eval_features(1980, 11310, seed=1, noise=6.0)[:2]
     qd, gd = qf.to(dev), gf.to(dev)
     # 15 warm-ups / 20 timed launches (round 6): generating the 13290 feature rows on the host above leaves the GPU idle for

@@ -487,6 +487,7 @@ def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate
 # launch stream waits for that stream where parameter gradients are consumed (Tape.flush, end of Tape.backward); the
 # operands stay referenced until then.  GRL_WGRAD_STREAM=0 / WGRAD_STREAM = False: everything on the launch stream.
 WGRAD_STREAM = __import__('os').environ.get('GRL_WGRAD_STREAM', '1') != '0'
+WGRAD_HANDOFF_TORCH = __import__('os').environ.get('GRL_WGRAD_HANDOFF', 'c') == 'torch'       # A/B only
 _wgrad_streams = {}
 
 
@@ -507,6 +508,15 @@ def wgrad_async(tp, dz, x, dw, M, N, K, **kw):
     # gradient, ~65 per step, on a step that is host-bound in bf16 storage).  The workspace is allocated under the CURRENT
     # stream and, like the operands, held until the streams join (Tape.wgrad_join): its block cannot be handed out again
     # before the launch stream has waited for the weight-gradient stream.
+    if WGRAD_HANDOFF_TORCH:               # (A/B switch: the rounds 3-5 hand-off through torch objects)
+        ws = _wgrad_stream(tp.dev)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(tp.dev))
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            wgrad(dz, x, dw, M, N, K, **kw)
+        tp.wheld.extend((dz, x, dw))
+        return
     wsh = _wgrad_stream(tp.dev).cuda_stream
     check(_lib.load().grl_stream_wait_stream(wsh, _lib.stream()), 'grl_stream_wait_stream')
     buf = wgrad(dz, x, dw, M, N, K, stream=wsh, **kw)

@@ -52,11 +52,56 @@ def _decode_range(args):
     return s
 
 
+def device_rates(frames, batches=(128, 512, 2048)):
+    """grl_jpeg_decode_batch (grl_amd/csrc/jpeg.hip) on the same frames: frames/s of the three kernels alone (HIP events,
+    bytes and descriptors resident) and end to end from host byte strings (header parse + pinned H2D + decode)."""
+    import sys
+    import ctypes as C
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+    lib = _lib.load()
+    out = {}
+    for n in batches:
+        streams = [frames[i % len(frames)] for i in range(n)]
+        ref = decode_jpeg_batch(streams, 'cuda')                         # warm-up (+ allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            y = decode_jpeg_batch(streams, 'cuda')
+        torch.cuda.synchronize()
+        e2e = (time.perf_counter() - t0) / reps
+        assert torch.equal(y, ref)
+        host, fr = JpegBatch(streams, (n,)).pack()
+        dbytes = host.cuda()
+        dfr = torch.frombuffer(bytearray(bytes(fr)), dtype=torch.uint8).cuda()
+        need = int(lib.grl_jpeg_workspace_bytes(C.byref(fr[0]), n))
+        ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+        o = torch.empty((n, 3, int(fr[0].height), int(fr[0].width)), dtype=torch.uint8, device='cuda')
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(3):
+            e0.record()
+            for _ in range(reps):
+                _lib.check(lib.grl_jpeg_decode_batch(dbytes.data_ptr(), dfr.data_ptr(), fr, n, o.data_ptr(), ws.data_ptr(), need,
+                                                     _lib.stream()), 'decode')
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        assert torch.equal(o, ref)
+        out[n] = {"kernels_ms_per_batch": round(ms, 3), "kernels_frames_per_sec": round(n / ms * 1e3),
+                  "end_to_end_ms_per_batch": round(e2e * 1e3, 3), "end_to_end_frames_per_sec": round(n / e2e),
+                  "compressed_MB": round(host.numel() / 1e6, 2), "decoded_MB": round(o.numel() / 1e6, 2)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=4096)
     ap.add_argument('--unique', type=int, default=256)
     ap.add_argument('--workers', default='1,2,4,8,16,32,64,128')
+    ap.add_argument('--device', action='store_true', help='also time grl_jpeg_decode_batch on the GPU')
     a = ap.parse_args()
     frames = make_frames(a.unique)
     kb = sum(len(f) for f in frames) / len(frames) / 1024.0
@@ -79,7 +124,9 @@ def main():
                 pool.map(_decode_range, chunks)
                 dt = time.perf_counter() - t0
         res[w] = round(n / dt, 1)
+    dev = device_rates(frames) if a.device else None
     print(json.dumps({"what": "PIL Image.open(jpeg).convert('RGB') -> uint8 array, 256x128 4:2:0 q90 frames",
+                      "device_decode (grl_jpeg_decode_batch, bit-identical to the host decode) by frames per batch": dev,
                       "mean_jpeg_kb": round(kb, 2), "host_cores": os.cpu_count(), "frames_per_sec_by_workers": res,
                       "consumers_frames_per_sec": {"fp32 eval headline (2218 clips/s x 4)": 8870,
                                                    "bf16-storage eval configs[2] (6500 clips/s x 8)": 52000,

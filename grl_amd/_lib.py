@@ -62,7 +62,7 @@ class GrlJpegFrame(C.Structure):
     _fields_ = [('scan_off', C.c_uint32), ('scan_len', C.c_uint32), ('width', C.c_uint16), ('height', C.c_uint16),
                 ('restart_interval', C.c_uint16), ('ncomp', C.c_uint8), ('hmax', C.c_uint8), ('vmax', C.c_uint8),
                 ('rgb', C.c_uint8), ('hs', C.c_uint8 * 4), ('vs', C.c_uint8 * 4), ('tq', C.c_uint8 * 4),
-                ('td', C.c_uint8 * 4), ('ta', C.c_uint8 * 4), ('pad_', C.c_uint8 * 10), ('q', (C.c_uint16 * 64) * 4),
+                ('td', C.c_uint8 * 4), ('ta', C.c_uint8 * 4), ('tabset', C.c_uint16), ('pad_', C.c_uint8 * 8), ('q', (C.c_uint16 * 64) * 4),
                 ('maxcode', (C.c_int32 * 18) * 4), ('valoff', (C.c_int32 * 18) * 4), ('vals', (C.c_uint8 * 256) * 4)]
 
 
@@ -190,6 +190,7 @@ _SIGNATURES = {
     'grl_bottleneck_tail_f32_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     # frame decode on the device (jpeg.hip)
     'grl_jpeg_parse': ([_fp, _i64, _i64, C.POINTER(GrlJpegFrame)], C.c_int),
+    'grl_jpeg_assign_tables': ([C.POINTER(GrlJpegFrame), C.c_int], C.c_int),
     'grl_jpeg_workspace_bytes': ([C.POINTER(GrlJpegFrame), C.c_int], _i64),
     'grl_jpeg_decode_batch': ([_fp, _fp, C.POINTER(GrlJpegFrame), C.c_int, _fp, _fp, _i64, _fp], C.c_int),
 }

@@ -20,6 +20,8 @@
 
 #include "../../include/grl_hip.h"
 #include "common.h"
+#define GRL_HD __host__ __device__
+#include "jpeg_core.h"
 
 namespace {
 
@@ -64,170 +66,41 @@ Geo make_geo(const GrlJpegFrame& f) {
     return g;
 }
 
-// ---- 1. entropy decoding ----------------------------------------------------------------------------------------------
+// ---- 1. entropy decoding (the per-lane logic lives in jpeg_core.h: it also compiles as host C++ for the CPU tests) -------
 constexpr int EW = 64;                                   // frames per workgroup (one wave)
-// LDS, lane-minor: [4 tables][16 lengths][EW] maxcode, the same for valoff, then the symbols [DC0 16][DC1 16][AC0 256][AC1 256][EW]
-constexpr int E_MAX_INTS = 4 * 16 * EW;
-constexpr int E_VALS = (16 + 16 + 256 + 256) * EW;
-constexpr size_t E_LDS = (size_t)2 * E_MAX_INTS * sizeof(int32_t) + E_VALS;
+constexpr int MAX_LDS_SETS = 8;                          // Huffman table sets whose look-ahead tables fit LDS (8 x 4 KiB)
+constexpr int LUT_PER_SET = 4 * GJ_LUT_SIZE;             // uint16 entries: [DC0, DC1, AC0, AC1] x 512
 
-struct BitReader {
-    const uint8_t* base;      // the batch's byte buffer
-    uint32_t pos, end;        // next stream byte, one past the scan
-    uint32_t limit;           // bytes that may be read as whole dwords (buffer length rounded down to 4)
-    uint64_t acc;             // bits, MSB first, in the low `cnt` bits
-    int cnt;
-    int marker;               // a marker was met: zero bits from here on (libjpeg's "insufficient data" behaviour)
-};
+struct Reps { int frame[MAX_LDS_SETS]; };               // the frame whose tables define table set u
 
-__device__ __forceinline__ uint32_t load_dword(const BitReader& b, uint32_t a) {
-    if (a + 4 <= b.limit) return *reinterpret_cast<const uint32_t*>(b.base + a);
-    uint32_t v = 0;                                                       // the buffer's last, partial dword
-    for (int i = 0; i < 4; ++i)
-        if (a + i < b.end) v |= (uint32_t)b.base[a + i] << (8 * i);
-    return v;
+// look-ahead tables of the batch's table sets: grid (sets * 4), 512 threads
+__global__ __launch_bounds__(GJ_LUT_SIZE) void jpeg_lut_kernel(const GrlJpegFrame* __restrict__ frames, Reps reps, int identity,
+                                                               uint16_t* __restrict__ lut) {
+    const int u = blockIdx.x >> 2, t = blockIdx.x & 3;
+    const GrlJpegFrame* fr = frames + (identity ? u : reps.frame[u]);
+    lut[(int64_t)blockIdx.x * GJ_LUT_SIZE + threadIdx.x] = gj_lut_entry(fr, t, threadIdx.x);
 }
-
-// stream byte at p, through the one-dword cache (cur_addr = the aligned address `cur` was loaded from)
-struct ByteCache { uint32_t addr; uint32_t word; };
-__device__ __forceinline__ int byte_at(const BitReader& b, ByteCache& c, uint32_t p) {
-    const uint32_t a = p & ~3u;
-    if (a != c.addr) { c.word = load_dword(b, a); c.addr = a; }
-    return (int)((c.word >> (8 * (p & 3u))) & 255u);
-}
-
-__device__ __forceinline__ void fill_bits(BitReader& b, ByteCache& c) {
-    while (b.cnt <= 48) {
-        int byte = 0;
-        if (!b.marker && b.pos < b.end) {
-            byte = byte_at(b, c, b.pos);
-            if (byte == 0xFF) {
-                uint32_t q = b.pos + 1;
-                while (q < b.end && byte_at(b, c, q) == 0xFF) ++q;          // fill bytes
-                if (q < b.end && byte_at(b, c, q) == 0x00) {
-                    b.pos = q + 1;                                           // stuffed zero: a data byte 0xFF
-                } else {
-                    b.marker = 1;                                            // RSTn / EOI / anything else: stays unread
-                    byte = 0;
-                }
-            } else {
-                b.pos++;
-            }
-        } else if (b.pos >= b.end) {
-            b.marker = 1;
-        }
-        b.acc = (b.acc << 8) | (uint64_t)byte;
-        b.cnt += 8;
-    }
-}
-
-__device__ __forceinline__ int get_bits(BitReader& b, int s) {              // s <= 16, cnt >= s guaranteed by the caller's fill
-    b.cnt -= s;
-    return (int)((b.acc >> b.cnt) & ((1u << s) - 1u));
-}
-
-__device__ __forceinline__ int extend(int x, int s) { return x < (1 << (s - 1)) ? x + (int)((~0u) << s) + 1 : x; }
 
 __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restrict__ bytes, uint32_t nbytes,
                                                           const GrlJpegFrame* __restrict__ frames, int n,
-                                                          int16_t* __restrict__ coef, Geo g) {
+                                                          int16_t* __restrict__ coef, GjScanGeo sg, int blocks,
+                                                          const uint16_t* __restrict__ lut, int lds_sets) {
     extern __shared__ __align__(16) uint8_t lds[];
-    int32_t* const s_max = reinterpret_cast<int32_t*>(lds);
-    int32_t* const s_off = s_max + E_MAX_INTS;
-    uint8_t* const s_val = reinterpret_cast<uint8_t*>(s_off + E_MAX_INTS);
+    uint8_t* const s_nat = lds;                                           // 80 bytes (+ pad to 128)
+    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128);       // lds_sets x 4 KiB
     const int lane = threadIdx.x;
-    const int f = blockIdx.x * EW + lane;
-    const bool live = f < n;
-    const GrlJpegFrame* fr = frames + (live ? f : n - 1);
-    // this lane's tables -> LDS [entry][lane]
-    for (int t = 0; t < 4; ++t) {
-        for (int l = 1; l <= 16; ++l) {
-            s_max[(t * 16 + l - 1) * EW + lane] = fr->maxcode[t][l];
-            s_off[(t * 16 + l - 1) * EW + lane] = fr->valoff[t][l];
-        }
-        const int nv = t < 2 ? 16 : 256, vbase = t < 2 ? t * 16 : 32 + (t - 2) * 256;
-        for (int i = 0; i < nv; i += 4) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(&fr->vals[t][i]);
-            for (int e = 0; e < 4; ++e) s_val[(vbase + i + e) * EW + lane] = (uint8_t)(w >> (8 * e));
-        }
+    for (int i = lane; i < 80; i += EW) s_nat[i] = kNaturalDev[i];
+    {   // the batch's look-ahead tables -> LDS (when they fit: a batch of camera frames shares ONE table set)
+        const uint4* src = reinterpret_cast<const uint4*>(lut);
+        uint4* dst = reinterpret_cast<uint4*>(s_lut);
+        for (int i = lane; i < lds_sets * LUT_PER_SET / 8; i += EW) dst[i] = src[i];
     }
     __syncthreads();
-    if (!live) return;
-
-    BitReader b;
-    b.base = bytes;
-    b.pos = fr->scan_off;
-    b.end = fr->scan_off + fr->scan_len;
-    b.limit = nbytes & ~3u;
-    b.acc = 0; b.cnt = 0; b.marker = 0;
-    ByteCache bc = {0xffffffffu, 0u};
-    int pred[3] = {0, 0, 0};
-    const int ri = fr->restart_interval;
-    int left = ri;
-    int td[3], ta[3];
-    for (int c = 0; c < 3; ++c) { td[c] = fr->td[c] & 1; ta[c] = 2 + (fr->ta[c] & 1); }
-    int16_t* const out = coef + (int64_t)f * g.blocks * 64;
-
-    auto huff = [&](int t, int vbase, int vmask) -> int {
-        // 16 bits of look-ahead (fill_bits left > 48), the code-length search against this lane's maxcode column
-        const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
-        for (int l = 1; l <= 16; ++l) {
-            const int code = (int)(look >> (16 - l));
-            if (code <= s_max[(t * 16 + l - 1) * EW + lane]) {
-                b.cnt -= l;
-                return s_val[(vbase + ((code + s_off[(t * 16 + l - 1) * EW + lane]) & vmask)) * EW + lane];
-            }
-        }
-        b.cnt -= 16;       // corrupt stream: libjpeg warns and returns 0
-        return 0;
-    };
-
-    int blk = 0;
-    for (int m = 0; m < g.mcux * g.mcuy; ++m) {
-        if (ri) {
-            if (left == 0) {
-                // discard the partial byte, find the RSTn marker, step over it; DC predictions restart
-                b.cnt = 0; b.acc = 0;
-                uint32_t q = b.pos;
-                while (q + 1 < b.end) {
-                    if (byte_at(b, bc, q) == 0xFF) {
-                        const int m2 = byte_at(b, bc, q + 1);
-                        if (m2 >= 0xD0 && m2 <= 0xD7) break;
-                    }
-                    ++q;
-                }
-                if (q + 1 < b.end) b.pos = q + 2;
-                b.marker = 0;
-                pred[0] = pred[1] = pred[2] = 0;
-                left = ri;
-            }
-            --left;
-        }
-        for (int c = 0; c < g.ncomp; ++c) {
-            const int nb = g.hs[c] * g.vs[c];
-            for (int bi = 0; bi < nb; ++bi, ++blk) {
-                int16_t* const o = out + (int64_t)blk * 64;
-                fill_bits(b, bc);
-                int s = huff(td[c], td[c] * 16, 15);
-                if (s) { fill_bits(b, bc); s = extend(get_bits(b, s & 15), s & 15); }
-                pred[c] += s;
-                if (pred[c]) o[0] = (int16_t)pred[c];
-                for (int k = 1; k < 64; ++k) {
-                    fill_bits(b, bc);
-                    const int rs = huff(ta[c], 32 + (ta[c] - 2) * 256, 255);
-                    const int r = rs >> 4, sz = rs & 15;
-                    if (sz) {
-                        k += r;
-                        const int v = extend(get_bits(b, sz), sz);          // (16 + 15 bits <= the 49 the fill guarantees)
-                        o[kNaturalDev[k]] = (int16_t)v;
-                    } else {
-                        if (r != 15) break;
-                        k += 15;
-                    }
-                }
-            }
-        }
-    }
+    const int f = blockIdx.x * EW + lane;
+    if (f >= n) return;
+    const GrlJpegFrame* fr = frames + f;
+    const uint16_t* my_lut = (lds_sets ? s_lut : lut) + (int64_t)fr->tabset * LUT_PER_SET;
+    gj_decode_scan(bytes, nbytes & ~3u, fr, my_lut, s_nat, coef + (int64_t)f * blocks * 64, sg);
 }
 
 // ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------
@@ -490,7 +363,34 @@ extern "C" int grl_jpeg_parse(const uint8_t* p, int64_t len, int64_t base_off, G
 extern "C" int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n) {
     if (!frame0 || n <= 0 || !frame0->width || !frame0->hmax) return 0;
     const Geo g = make_geo(*frame0);
-    return (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t) + (int64_t)n * g.plane_bytes + 256;
+    return (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t) + (int64_t)n * g.plane_bytes + (int64_t)n * LUT_PER_SET * 2 + 512;
+}
+
+// HOST: give every frame the index of its Huffman table set (frames[i].tabset).  Up to 8 distinct sets share look-ahead
+// tables that the entropy kernel keeps in LDS (a batch of frames from one camera / encoder has ONE); with more, every
+// frame gets its own (tabset = i) and the tables are read through the L2.  Returns the number of sets.
+extern "C" int grl_jpeg_assign_tables(GrlJpegFrame* frames, int n) {
+    if (!frames || n <= 0) return grl_fail(GRL_EINVAL, "jpeg_assign_tables: null / empty");
+    constexpr size_t TB = sizeof(frames[0].maxcode) + sizeof(frames[0].valoff) + sizeof(frames[0].vals);
+    static_assert(offsetof(GrlJpegFrame, vals) + sizeof(frames[0].vals) - offsetof(GrlJpegFrame, maxcode) == TB, "tables are contiguous");
+    int rep[MAX_LDS_SETS], sets = 0;
+    bool many = false;
+    for (int i = 0; i < n && !many; ++i) {
+        int u = 0;
+        for (; u < sets; ++u)
+            if (!memcmp(frames[i].maxcode, frames[rep[u]].maxcode, TB)) break;
+        if (u == sets) {
+            if (sets == MAX_LDS_SETS) { many = true; break; }
+            rep[sets++] = i;
+        }
+        frames[i].tabset = (uint16_t)u;
+    }
+    if (many) {
+        if (n > 65535) return grl_fail(GRL_EINVAL, "jpeg_assign_tables: more than 65535 frames with distinct tables in one batch");
+        for (int i = 0; i < n; ++i) frames[i].tabset = (uint16_t)i;
+        return n;
+    }
+    return sets;
 }
 
 extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* frames_dev, const GrlJpegFrame* frames_host, int n,
@@ -513,18 +413,41 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
         if (e > nbytes) nbytes = e;
     }
     GRL_REQUIRE(workspace_bytes >= grl_jpeg_workspace_bytes(&f0, n), "jpeg_decode_batch: workspace too small (grl_jpeg_workspace_bytes)");
+    // table sets (grl_jpeg_assign_tables): a frame's tables must be the ones of its set's first frame
+    constexpr size_t TB = sizeof(f0.maxcode) + sizeof(f0.valoff) + sizeof(f0.vals);
+    int sets = 0;
+    for (int i = 0; i < n; ++i) sets = frames_host[i].tabset + 1 > sets ? frames_host[i].tabset + 1 : sets;
+    Reps reps;
+    const bool identity = sets > MAX_LDS_SETS;
+    if (identity) {
+        for (int i = 0; i < n; ++i)
+            if (frames_host[i].tabset != i) return grl_fail(GRL_EINVAL, "jpeg_decode_batch: frame %d: table sets not assigned (grl_jpeg_assign_tables)", i);
+        GRL_REQUIRE(sets == n, "jpeg_decode_batch: table sets not assigned (grl_jpeg_assign_tables)");
+    } else {
+        for (int u = 0; u < MAX_LDS_SETS; ++u) reps.frame[u] = -1;
+        for (int i = 0; i < n; ++i) {
+            const int u = frames_host[i].tabset;
+            if (reps.frame[u] < 0) reps.frame[u] = i;
+            else if (memcmp(frames_host[i].maxcode, frames_host[reps.frame[u]].maxcode, TB))
+                return grl_fail(GRL_EINVAL, "jpeg_decode_batch: frame %d does not carry the tables of its table set (grl_jpeg_assign_tables)", i);
+        }
+        for (int u = 0; u < sets; ++u) GRL_REQUIRE(reps.frame[u] >= 0, "jpeg_decode_batch: a table set without a frame");
+    }
     const Geo g = make_geo(f0);
+    GjScanGeo sg;
+    sg.mcus = g.mcux * g.mcuy; sg.ncomp = g.ncomp;
+    for (int c = 0; c < 3; ++c) sg.nb[c] = g.hs[c] * g.vs[c];
     hipStream_t s = (hipStream_t)stream;
     int16_t* coef = reinterpret_cast<int16_t*>(workspace);
     const int64_t coef_bytes = (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t);
     uint8_t* planes = reinterpret_cast<uint8_t*>(workspace) + ((coef_bytes + 255) & ~(int64_t)255);
+    uint16_t* lut = reinterpret_cast<uint16_t*>(planes + (((int64_t)n * g.plane_bytes + 255) & ~(int64_t)255));
     if (hipMemsetAsync(coef, 0, (size_t)coef_bytes, s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E_LDS);
-        return true;
-    }();
-    (void)attr;
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(grl_ceil_div(n, EW)), dim3(EW), E_LDS, s, bytes, nbytes, frames_dev, n, coef, g);
+    hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4), dim3(GJ_LUT_SIZE), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
+    const int lds_sets = identity ? 0 : sets;
+    const size_t e_lds = 128 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
+    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
+                       g.blocks, lut, lds_sets);
     const int64_t nblk = (int64_t)n * g.blocks;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, coef, frames_dev, n, planes, g);
     const int64_t npix = (int64_t)n * g.width * g.height;

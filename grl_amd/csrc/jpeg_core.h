@@ -1,0 +1,187 @@
+// Entropy-decoding core of the device JPEG decoder (jpeg.hip), written so that the SAME source also compiles as plain
+// host C++ (GRL_HD expands to nothing): a frame is decoded by one lane with no cross-lane operation, so a CPU build of
+// this header run on one frame at a time exercises exactly the logic a lane runs (tests/test_jpeg_cpu.py builds it with
+// g++ and compares the coefficients with the oracle's -- sanitizers and debuggers work there; the GPU pool has neither).
+//
+// ITU-T T.81 F.2.2 (jdhuff.c decode_mcu): per block a DC difference and run/size coded AC coefficients.
+//   * bit reader: 64-bit accumulator, refilled 32 bits at a time from an ALIGNED dword when that dword holds no 0xFF byte
+//     (no stuffing, no marker: ~98 % of the dwords of a photographic scan), byte by byte otherwise (0xFF00 stuffing, fill
+//     bytes, RSTn / EOI, the unaligned head and the tail of a scan);
+//   * Huffman symbols through a 9-bit look-ahead table (one read: length << 8 | symbol; 0 = longer than 9 bits), the
+//     rare long codes by the canonical maxcode / valoff search;
+//   * only NON-ZERO coefficients are stored (the caller zero-fills the coefficient array).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/grl_hip.h"
+
+#ifndef GRL_HD
+#define GRL_HD
+#endif
+
+#define GJ_LUT_BITS 9
+#define GJ_LUT_SIZE (1 << GJ_LUT_BITS)
+
+struct GjBits {
+    const uint8_t* base;      // the batch's byte buffer
+    uint32_t pos, end;        // next stream byte, one past the scan
+    uint32_t limit;           // bytes of the BUFFER that may be read as whole dwords (its length rounded down to 4)
+    uint64_t acc;             // bits, MSB first, in the low `cnt` bits
+    int cnt;
+    int marker;               // a marker was met: zero bits from here on (libjpeg's "insufficient data" behaviour)
+    uint32_t caddr, cword;    // one-dword cache of the byte path
+};
+
+GRL_HD static inline uint32_t gj_load_dword(const GjBits& b, uint32_t a) {
+    if (a + 4 <= b.limit) return *reinterpret_cast<const uint32_t*>(b.base + a);
+    uint32_t v = 0;                                                       // the buffer's last, partial dword
+    for (int i = 0; i < 4; ++i)
+        if (a + i < b.end) v |= (uint32_t)b.base[a + i] << (8 * i);
+    return v;
+}
+
+GRL_HD static inline int gj_byte_at(GjBits& b, uint32_t p) {
+    const uint32_t a = p & ~3u;
+    if (a != b.caddr) { b.cword = gj_load_dword(b, a); b.caddr = a; }
+    return (int)((b.cword >> (8 * (p & 3u))) & 255u);
+}
+
+GRL_HD static inline uint32_t gj_bswap(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xff00u) | ((w << 8) & 0xff0000u) | (w << 24); }
+
+// after the call cnt >= 33 (the most a symbol consumes is 16 code bits + 15 extra bits)
+GRL_HD static inline void gj_fill(GjBits& b) {
+    while (b.cnt <= 32) {
+        if (!b.marker && (b.pos & 3u) == 0 && b.pos + 4 <= b.end && b.pos + 4 <= b.limit) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(b.base + b.pos);
+            const uint32_t inv = ~w;
+            if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {       // no 0xFF byte in this dword
+                b.acc = (b.acc << 32) | (uint64_t)gj_bswap(w);
+                b.cnt += 32;
+                b.pos += 4;
+                continue;
+            }
+        }
+        int byte = 0;
+        if (!b.marker && b.pos < b.end) {
+            byte = gj_byte_at(b, b.pos);
+            if (byte == 0xFF) {
+                uint32_t q = b.pos + 1;
+                while (q < b.end && gj_byte_at(b, q) == 0xFF) ++q;        // fill bytes
+                if (q < b.end && gj_byte_at(b, q) == 0x00) {
+                    b.pos = q + 1;                                         // stuffed zero: a data byte 0xFF
+                } else {
+                    b.marker = 1;                                          // RSTn / EOI / anything else: stays unread
+                    byte = 0;
+                }
+            } else {
+                b.pos++;
+            }
+        } else if (b.pos >= b.end) {
+            b.marker = 1;
+        }
+        b.acc = (b.acc << 8) | (uint64_t)byte;
+        b.cnt += 8;
+    }
+}
+
+GRL_HD static inline int gj_get_bits(GjBits& b, int s) {                  // s in 1..16, cnt >= s
+    b.cnt -= s;
+    return (int)((b.acc >> b.cnt) & ((1u << s) - 1u));
+}
+
+GRL_HD static inline int gj_extend(int x, int s) { return x < (1 << (s - 1)) ? x + (int)((~0u) << s) + 1 : x; }
+
+// one Huffman symbol of table t (0, 1: DC; 2, 3: AC): look-ahead table first, canonical search for codes > 9 bits
+GRL_HD static inline int gj_symbol(GjBits& b, const uint16_t* lut /* this table's GJ_LUT_SIZE entries */, const GrlJpegFrame* fr, int t) {
+    const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
+    const uint32_t e = lut[look >> (16 - GJ_LUT_BITS)];
+    if (e) { b.cnt -= (int)(e >> 8); return (int)(e & 255u); }
+    for (int l = GJ_LUT_BITS + 1; l <= 16; ++l) {
+        const int code = (int)(look >> (16 - l));
+        if (code <= fr->maxcode[t][l]) {
+            b.cnt -= l;
+            return fr->vals[t][(code + fr->valoff[t][l]) & 255];
+        }
+    }
+    b.cnt -= 16;       // corrupt stream: libjpeg warns and returns 0
+    return 0;
+}
+
+// the look-ahead entry for the 9 bits `p` of table t (jpeg_lut_kernel / the host test build the tables with this)
+GRL_HD static inline uint16_t gj_lut_entry(const GrlJpegFrame* fr, int t, int p) {
+    for (int l = 1; l <= GJ_LUT_BITS; ++l) {
+        const int code = p >> (GJ_LUT_BITS - l);
+        if (code <= fr->maxcode[t][l]) return (uint16_t)((l << 8) | fr->vals[t][(code + fr->valoff[t][l]) & 255]);
+    }
+    return 0;
+}
+
+struct GjScanGeo {
+    int mcus;                 // MCUs per frame
+    int ncomp;
+    int nb[3];                // blocks of each component per MCU (hs * vs)
+};
+
+// Decode one frame's scan: `lut` = 4 tables x GJ_LUT_SIZE entries [DC0, DC1, AC0, AC1] of this frame's table set,
+// `nat` = the 64 (+16 guard) entry zigzag -> natural order table, `out` = this frame's zero-filled coefficients
+// [blocks][64].
+GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, const GrlJpegFrame* fr, const uint16_t* lut,
+                                         const uint8_t* nat, int16_t* out, const GjScanGeo& g) {
+    GjBits b;
+    b.base = bytes;
+    b.pos = fr->scan_off;
+    b.end = fr->scan_off + fr->scan_len;
+    b.limit = limit;
+    b.acc = 0; b.cnt = 0; b.marker = 0;
+    b.caddr = 0xffffffffu; b.cword = 0;
+    int pred[3] = {0, 0, 0};
+    const int ri = fr->restart_interval;
+    int left = ri;
+    int blk = 0;
+    for (int m = 0; m < g.mcus; ++m) {
+        if (ri) {
+            if (left == 0) {
+                // discard the partial byte, find the RSTn marker, step over it; DC predictions restart
+                b.cnt = 0; b.acc = 0;
+                uint32_t q = b.pos;
+                while (q + 1 < b.end) {
+                    if (gj_byte_at(b, q) == 0xFF) {
+                        const int m2 = gj_byte_at(b, q + 1);
+                        if (m2 >= 0xD0 && m2 <= 0xD7) break;
+                    }
+                    ++q;
+                }
+                if (q + 1 < b.end) b.pos = q + 2;
+                b.marker = 0;
+                pred[0] = pred[1] = pred[2] = 0;
+                left = ri;
+            }
+            --left;
+        }
+        for (int c = 0; c < g.ncomp; ++c) {
+            const int td = fr->td[c] & 1, ta = 2 + (fr->ta[c] & 1);
+            const uint16_t* const lut_dc = lut + td * GJ_LUT_SIZE;
+            const uint16_t* const lut_ac = lut + ta * GJ_LUT_SIZE;
+            for (int bi = 0; bi < g.nb[c]; ++bi, ++blk) {
+                int16_t* const o = out + (int64_t)blk * 64;
+                gj_fill(b);
+                int s = gj_symbol(b, lut_dc, fr, td) & 15;
+                if (s) s = gj_extend(gj_get_bits(b, s), s);
+                pred[c] += s;
+                if (pred[c]) o[0] = (int16_t)pred[c];
+                for (int k = 1; k < 64; ++k) {
+                    gj_fill(b);
+                    const int rs = gj_symbol(b, lut_ac, fr, ta);
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz) {
+                        k += r;
+                        o[nat[k]] = (int16_t)gj_extend(gj_get_bits(b, sz), sz);
+                    } else {
+                        if (r != 15) break;
+                        k += 15;
+                    }
+                }
+            }
+        }
+    }
+}

@@ -54,6 +54,8 @@ class JpegBatch(object):
                 msg = lib.grl_last_error().decode('utf-8', 'replace')
                 raise (JpegUnsupported if rc == _lib.GRL_EUNSUPPORTED else GrlHipError)('frame %d: %s' % (i, msg))
             off += n
+        if lib.grl_jpeg_assign_tables(frames, len(self.streams)) <= 0:
+            raise GrlHipError('grl_jpeg_assign_tables: %s' % lib.grl_last_error().decode('utf-8', 'replace'))
         return torch.from_numpy(buf), frames
 
 

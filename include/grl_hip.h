@@ -669,7 +669,8 @@ typedef struct GrlJpegFrame {      /* one parsed frame: filled on the host by gr
     uint8_t  ncomp, hmax, vmax, rgb;   /* rgb: components are R, G, B (Adobe transform 0): no colour conversion */
     uint8_t  hs[4], vs[4];         /* sampling factors per component */
     uint8_t  tq[4], td[4], ta[4];  /* quantisation / DC / AC table of each component */
-    uint8_t  pad_[10];             /* (q starts at byte 48; sizeof == 2160 == 16 * 135: 16-byte loads of q rows) */
+    uint16_t tabset;               /* index of this frame's Huffman table set inside its batch (grl_jpeg_assign_tables) */
+    uint8_t  pad_[8];              /* (q starts at byte 48; sizeof == 2160 == 16 * 135: 16-byte loads of q rows) */
     uint16_t q[4][64];             /* quantisation tables, natural (row-major) order */
     int32_t  maxcode[4][18];       /* Huffman tables [DC0, DC1, AC0, AC1]: largest code of each length (-1: none) */
     int32_t  valoff[4][18];        /*   symbol index = code + valoff[length] */
@@ -679,6 +680,10 @@ typedef struct GrlJpegFrame {      /* one parsed frame: filled on the host by gr
 /* HOST function (no GPU call): parse the headers of ONE JPEG stream `data[0..len)` that will sit at byte `base_off` of
  * the batch buffer.  Returns GRL_OK, GRL_EINVAL (not a JPEG / truncated) or GRL_EUNSUPPORTED. */
 int grl_jpeg_parse(const uint8_t* data, int64_t len, int64_t base_off, GrlJpegFrame* out);
+/* HOST function: number the Huffman table sets of a batch (frames[i].tabset).  Up to 8 distinct sets get shared
+ * look-ahead tables in LDS (frames of one encoder share ONE set); beyond that every frame keeps its own.  Returns
+ * the number of sets (> 0) or a negative GRL_E* code.  Call after grl_jpeg_parse, before the descriptors are copied. */
+int grl_jpeg_assign_tables(GrlJpegFrame* frames, int n);
 /* bytes of device scratch grl_jpeg_decode_batch needs for n frames of frame 0's geometry (coefficients + planes) */
 int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n);
 /* n frames of ONE geometry (width, height, components, sampling: as frames[0]; frames_host is checked) ->

@@ -18,6 +18,10 @@ def _lib():
         _LIB.grl_oracle_jpeg_info.argtypes = [C.c_char_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
         _LIB.grl_oracle_jpeg_decode.restype = C.c_int
         _LIB.grl_oracle_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        _LIB.grl_oracle_jpeg_coefficients.restype = C.c_int
+        _LIB.grl_oracle_jpeg_coefficients.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        _LIB.grl_oracle_jpeg_blocks.restype = C.c_int
+        _LIB.grl_oracle_jpeg_blocks.argtypes = [C.c_char_p, C.c_size_t]
     return _LIB
 
 
@@ -51,6 +55,19 @@ def jpeg_decode(data):
     w, h = v[0].value, v[1].value
     out = np.empty((h, w, 3), np.uint8)
     rc = lib.grl_oracle_jpeg_decode(data, len(data), out.ctypes.data)
+    if rc:
+        raise ValueError('jpeg oracle: decode failed (%d)' % rc)
+    return out
+
+
+def jpeg_coefficients(data):
+    """The quantised DCT coefficients of a baseline JPEG, int16 [blocks in scan order][64 natural order]."""
+    lib = _lib()
+    nb = lib.grl_oracle_jpeg_blocks(data, len(data))
+    if nb <= 0:
+        raise ValueError('jpeg oracle: header rejected')
+    out = np.zeros((nb, 64), np.int16)
+    rc = lib.grl_oracle_jpeg_coefficients(data, len(data), out.ctypes.data)
     if rc:
         raise ValueError('jpeg oracle: decode failed (%d)' % rc)
     return out

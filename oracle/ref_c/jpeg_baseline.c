@@ -13,7 +13,7 @@
  * 4:2:0 / 4:4:0 / grey, qualities 30..100, restart intervals) and by tests/golden/jpeg_frames.npz.
  *
  * Scope: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), one scan, 1 or 3 components (YCbCr by JFIF
- * convention, RGB when an Adobe marker says transform 0), luma sampling 1x1, 2x1, 1x2 or 2x2 with 1x1 chroma.
+ * convention, RGB when an Adobe marker says transform 0), luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma.
  * Anything else (progressive, arithmetic, CMYK, 12-bit) returns an error code -- the caller decides.
  */
 #include <stdint.h>
@@ -160,6 +160,7 @@ static int parse(const uint8_t* p, size_t n, Jpeg* j) {
     }
     if (j->ncomp == 3) {
         if (j->hs[1] != 1 || j->vs[1] != 1 || j->hs[2] != 1 || j->vs[2] != 1 || j->hs[0] > 2 || j->vs[0] > 2) return GJ_EUNSUPPORTED;
+        if (j->hs[0] == 1 && j->vs[0] == 2) return GJ_EUNSUPPORTED;   /* 4:4:0: Pillow cannot write it, so it cannot be pinned here */
         if (adobe == 0) j->rgb = 1;
         else if (adobe == 2) return GJ_EUNSUPPORTED;
     } else if (j->hs[0] != 1 || j->vs[0] != 1) {
@@ -355,8 +356,24 @@ int grl_oracle_jpeg_info(const uint8_t* data, size_t len, int* width, int* heigh
     return GJ_OK;
 }
 
+static int decode_impl(const uint8_t* data, size_t len, uint8_t* out, int16_t* coef_out);
+
 /* out: RGB, interleaved [height][width][3] (what np.asarray(Image.open(..).convert('RGB')) holds) */
-int grl_oracle_jpeg_decode(const uint8_t* data, size_t len, uint8_t* out) {
+int grl_oracle_jpeg_decode(const uint8_t* data, size_t len, uint8_t* out) { return decode_impl(data, len, out, 0); }
+
+/* the quantised coefficients as the entropy decoder leaves them: int16 [blocks in scan order][64 natural order]
+ * (blocks = MCUs x blocks per MCU).  Pins the entropy stage of the device decoder on its own. */
+int grl_oracle_jpeg_coefficients(const uint8_t* data, size_t len, int16_t* coef_out) { return decode_impl(data, len, 0, coef_out); }
+
+int grl_oracle_jpeg_blocks(const uint8_t* data, size_t len) {
+    Jpeg j;
+    if (parse(data, len, &j)) return -1;
+    int bpm = 0;
+    for (int c = 0; c < j.ncomp; ++c) bpm += j.hs[c] * j.vs[c];
+    return ((j.width + 8 * j.hmax - 1) / (8 * j.hmax)) * ((j.height + 8 * j.vmax - 1) / (8 * j.vmax)) * bpm;
+}
+
+static int decode_impl(const uint8_t* data, size_t len, uint8_t* out, int16_t* coef_out) {
     Jpeg j;
     int rc = parse(data, len, &j);
     if (rc) return rc;
@@ -406,11 +423,13 @@ int grl_oracle_jpeg_decode(const uint8_t* data, size_t len, uint8_t* out) {
                                     k += 15;
                                 }
                             }
+                            if (coef_out) { memcpy(coef_out, coef, sizeof(coef)); coef_out += 64; }
                             idct_islow(coef, j.q[j.tq[c]],
                                        plane[c] + (size_t)((my * j.vs[c] + by) * 8) * pw[c] + (mx * j.hs[c] + bx) * 8, pw[c]);
                         }
             }
     }
+    if (!out) goto done;
     if (j.ncomp == 1) {
         for (int y = 0; y < j.height; ++y)
             for (int x = 0; x < j.width; ++x) {

@@ -1,0 +1,25 @@
+// CPU build of the device decoder's entropy core (grl_amd/csrc/jpeg_core.h compiles as plain C++): one frame at a time,
+// exactly the per-lane logic of jpeg_entropy_kernel.  Built by tests/test_jpeg_cpu.py with g++ (no GPU, no HIP).
+#include <stdint.h>
+#include <string.h>
+#define GRL_HD
+#include "../grl_amd/csrc/jpeg_core.h"
+
+static const uint8_t kNat[80] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+    63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+
+// buf: the batch byte buffer (nbytes long), fr: the parsed frame, out: zero-filled int16 [blocks][64]
+extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
+    static uint16_t lut[4 * GJ_LUT_SIZE];
+    for (int t = 0; t < 4; ++t)
+        for (int p = 0; p < GJ_LUT_SIZE; ++p) lut[t * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
+    GjScanGeo g;
+    const int mcux = (fr->width + 8 * fr->hmax - 1) / (8 * fr->hmax), mcuy = (fr->height + 8 * fr->vmax - 1) / (8 * fr->vmax);
+    g.mcus = mcux * mcuy;
+    g.ncomp = fr->ncomp;
+    for (int c = 0; c < 3; ++c) g.nb[c] = fr->hs[c] * fr->vs[c];
+    gj_decode_scan(buf, nbytes & ~3u, fr, lut, kNat, out, g);
+    return 0;
+}

@@ -135,3 +135,22 @@ def test_loader_to_features_with_device_decode(tmp_path, gpu_models):
         feats[name] = torch.cat(rows)
     assert feats['device'].shape == (4, 6144)
     assert torch.equal(feats['device'], feats['host'])
+
+
+def test_device_decode_with_per_frame_huffman_tables():
+    """More than eight distinct Huffman table sets in one batch (every frame encoded with optimised tables): the
+    look-ahead tables are per frame and read through the L2 instead of LDS; mixed batches (default + optimised) use the
+    shared sets.  Same pixels as Pillow either way."""
+    from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+    rng = np.random.default_rng(21)
+    many = [_encode(_frame(64, 48, rng), quality=int(rng.integers(30, 99)), optimize=True) for _ in range(70)]
+    _, fr = JpegBatch(many, (70,)).pack()
+    assert [f.tabset for f in fr] == list(range(70))
+    got = decode_jpeg_batch(many, 'cuda').cpu().numpy()
+    for i, s in enumerate(many):
+        assert np.array_equal(got[i], _pil_chw(s)), i
+    mixed = [_encode(_frame(64, 48, rng), quality=80), _encode(_frame(64, 48, rng), quality=80, optimize=True),
+             _encode(_frame(64, 48, rng), quality=50), _encode(_frame(64, 48, rng), quality=95, optimize=True)]
+    got = decode_jpeg_batch(mixed, 'cuda').cpu().numpy()
+    for i, s in enumerate(mixed):
+        assert np.array_equal(got[i], _pil_chw(s)), i

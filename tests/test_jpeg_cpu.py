@@ -128,3 +128,59 @@ def test_host_header_parser_fills_the_frame_descriptor(golden):
     lib = _lib.load()
     assert lib.grl_jpeg_workspace_bytes(C.byref(fr[0]), 2) >= 2 * (768 * 128 + 256 * 128 * 3 // 2)
     assert lib.grl_jpeg_decode_batch(None, None, fr, 2, None, None, 0, None) == -1             # argument checks need no GPU
+
+
+def test_device_entropy_core_on_the_cpu_matches_the_oracle_coefficients(tmp_path):
+    """grl_amd/csrc/jpeg_core.h is the per-lane logic of jpeg_entropy_kernel and compiles as plain C++
+    (tests/jpeg_core_host.cpp, g++): the quantised coefficients it leaves equal the oracle's for every stream of a sweep
+    (look-ahead tables + long-code fallback, the 32-bit refill fast path at all four alignments of the scan inside the
+    batch buffer, 0xFF00 stuffing, restart markers, optimised tables)."""
+    import os
+    import subprocess
+    pytest.importorskip('PIL')
+    from grl_amd.reid.data.jpeg import JpegBatch
+    from oracle.ref_c import jpeg_coefficients
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tmp_path, 'libgjhost.so')
+    subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', os.path.join(root, 'tests', 'jpeg_core_host.cpp'), '-o', so])
+    lib = C.CDLL(so)
+    lib.gj_host_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0)
+    streams = []
+    for (h, w) in [(256, 128), (17, 33), (1, 1), (31, 2), (64, 48), (100, 77)]:
+        for sub in (0, 1, 2):
+            for q, kw in ((30, {}), (75, dict(optimize=True)), (100, {}), (60, dict(restart_marker_blocks=2)),
+                          (85, dict(restart_marker_rows=1))):
+                try:
+                    streams.append(_encode(_frame(h, w, rng), quality=q, subsampling=sub, **kw))
+                except OSError:
+                    pass
+            streams.append(_encode(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), quality=100, subsampling=sub))
+    assert len(streams) > 90
+    for s in streams:
+        ref = jpeg_coefficients(s)
+        for lead in (0, 1, 2, 3):
+            host, fr = JpegBatch([s], (1,)).pack()
+            buf = np.ascontiguousarray(np.concatenate([np.full(lead, 0xFF, np.uint8), host.numpy(), np.zeros(8, np.uint8)]))
+            f = fr[0]
+            f.scan_off += lead
+            out = np.zeros_like(ref)
+            lib.gj_host_decode(buf.ctypes.data, len(buf) - 8, C.addressof(f), out.ctypes.data)
+            assert np.array_equal(out, ref), (len(s), lead)
+
+
+def test_table_sets_are_shared_or_per_frame():
+    """grl_jpeg_assign_tables: frames with Pillow's default tables share ONE set; every optimised frame has its own; more
+    than eight distinct sets switch the batch to per-frame tables."""
+    pytest.importorskip('PIL')
+    from grl_amd.reid.data.jpeg import JpegBatch
+    rng = np.random.default_rng(2)
+    same = [_encode(_frame(32, 32, rng), quality=q) for q in (40, 60, 80, 95)]
+    _, fr = JpegBatch(same, (4,)).pack()
+    assert [f.tabset for f in fr] == [0, 0, 0, 0]
+    mixed = same[:2] + [_encode(_frame(32, 32, rng), quality=70, optimize=True) for _ in range(3)]
+    _, fr = JpegBatch(mixed, (5,)).pack()
+    assert [f.tabset for f in fr][:2] == [0, 0] and len({f.tabset for f in fr}) == 4
+    many = [_encode(_frame(32, 32, rng), quality=70, optimize=True) for _ in range(12)]
+    _, fr = JpegBatch(many, (12,)).pack()
+    assert [f.tabset for f in fr] == list(range(12))

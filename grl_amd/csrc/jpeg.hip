@@ -68,17 +68,18 @@ Geo make_geo(const GrlJpegFrame& f) {
 
 // ---- 1. entropy decoding (the per-lane logic lives in jpeg_core.h: it also compiles as host C++ for the CPU tests) -------
 constexpr int EW = 64;                                   // frames per workgroup (one wave)
-constexpr int MAX_LDS_SETS = 8;                          // Huffman table sets whose look-ahead tables fit LDS (8 x 4 KiB)
-constexpr int LUT_PER_SET = 4 * GJ_LUT_SIZE;             // uint16 entries: [DC0, DC1, AC0, AC1] x 512
+constexpr int MAX_LDS_SETS = 4;                          // Huffman table sets whose look-ahead tables fit LDS (4 x 32 KiB)
+constexpr int LUT_PER_SET = 4 * GJ_LUT_SIZE;             // uint16 entries: [DC0, DC1, AC0, AC1] x 4096
 
 struct Reps { int frame[MAX_LDS_SETS]; };               // the frame whose tables define table set u
 
-// look-ahead tables of the batch's table sets: grid (sets * 4), 512 threads
-__global__ __launch_bounds__(GJ_LUT_SIZE) void jpeg_lut_kernel(const GrlJpegFrame* __restrict__ frames, Reps reps, int identity,
+// look-ahead tables of the batch's table sets: grid (sets * 4, GJ_LUT_SIZE / 256), 256 threads
+__global__ __launch_bounds__(256) void jpeg_lut_kernel(const GrlJpegFrame* __restrict__ frames, Reps reps, int identity,
                                                                uint16_t* __restrict__ lut) {
     const int u = blockIdx.x >> 2, t = blockIdx.x & 3;
     const GrlJpegFrame* fr = frames + (identity ? u : reps.frame[u]);
-    lut[(int64_t)blockIdx.x * GJ_LUT_SIZE + threadIdx.x] = gj_lut_entry(fr, t, threadIdx.x);
+    const int p = blockIdx.y * 256 + threadIdx.x;
+    lut[(int64_t)blockIdx.x * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
 }
 
 __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restrict__ bytes, uint32_t nbytes,
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
                                                           const uint16_t* __restrict__ lut, int lds_sets) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t* const s_nat = lds;                                           // 80 bytes (+ pad to 128)
-    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128);       // lds_sets x 4 KiB
+    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128);       // lds_sets x 32 KiB
     const int lane = threadIdx.x;
     for (int i = lane; i < 80; i += EW) s_nat[i] = kNaturalDev[i];
     {   // the batch's look-ahead tables -> LDS (when they fit: a batch of camera frames shares ONE table set)
@@ -366,7 +367,7 @@ extern "C" int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n) {
     return (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t) + (int64_t)n * g.plane_bytes + (int64_t)n * LUT_PER_SET * 2 + 512;
 }
 
-// HOST: give every frame the index of its Huffman table set (frames[i].tabset).  Up to 8 distinct sets share look-ahead
+// HOST: give every frame the index of its Huffman table set (frames[i].tabset).  Up to 4 distinct sets share look-ahead
 // tables that the entropy kernel keeps in LDS (a batch of frames from one camera / encoder has ONE); with more, every
 // frame gets its own (tabset = i) and the tables are read through the L2.  Returns the number of sets.
 extern "C" int grl_jpeg_assign_tables(GrlJpegFrame* frames, int n) {
@@ -443,9 +444,15 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     uint8_t* planes = reinterpret_cast<uint8_t*>(workspace) + ((coef_bytes + 255) & ~(int64_t)255);
     uint16_t* lut = reinterpret_cast<uint16_t*>(planes + (((int64_t)n * g.plane_bytes + 255) & ~(int64_t)255));
     if (hipMemsetAsync(coef, 0, (size_t)coef_bytes, s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
-    hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4), dim3(GJ_LUT_SIZE), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
+    hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4, GJ_LUT_SIZE / 256), dim3(256), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
     const int lds_sets = identity ? 0 : sets;
     const size_t e_lds = 128 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 + MAX_LDS_SETS * LUT_PER_SET * (int)sizeof(uint16_t));
+        return true;
+    }();
+    (void)attr;
     hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
                        g.blocks, lut, lds_sets);
     const int64_t nblk = (int64_t)n * g.blocks;

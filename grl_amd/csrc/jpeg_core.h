@@ -7,7 +7,7 @@
 //   * bit reader: 64-bit accumulator, refilled 32 bits at a time from an ALIGNED dword when that dword holds no 0xFF byte
 //     (no stuffing, no marker: ~98 % of the dwords of a photographic scan), byte by byte otherwise (0xFF00 stuffing, fill
 //     bytes, RSTn / EOI, the unaligned head and the tail of a scan);
-//   * Huffman symbols through a 9-bit look-ahead table (one read: length << 8 | symbol; 0 = longer than 9 bits), the
+//   * Huffman symbols through a 12-bit look-ahead table (one read: length << 8 | symbol; 0 = longer than 12 bits), the
 //     rare long codes by the canonical maxcode / valoff search;
 //   * only NON-ZERO coefficients are stored (the caller zero-fills the coefficient array).
 #pragma once
@@ -19,7 +19,7 @@
 #define GRL_HD
 #endif
 
-#define GJ_LUT_BITS 9
+#define GJ_LUT_BITS 12
 #define GJ_LUT_SIZE (1 << GJ_LUT_BITS)
 
 struct GjBits {
@@ -29,7 +29,8 @@ struct GjBits {
     uint64_t acc;             // bits, MSB first, in the low `cnt` bits
     int cnt;
     int marker;               // a marker was met: zero bits from here on (libjpeg's "insufficient data" behaviour)
-    uint32_t caddr, cword;    // one-dword cache of the byte path
+    int ffp;                  // the last byte seen was 0xFF (stuffing / marker decision pending)
+    uint32_t caddr, cword;    // one-dword cache of the byte path (restart search)
 };
 
 GRL_HD static inline uint32_t gj_load_dword(const GjBits& b, uint32_t a) {
@@ -48,39 +49,45 @@ GRL_HD static inline int gj_byte_at(GjBits& b, uint32_t p) {
 
 GRL_HD static inline uint32_t gj_bswap(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xff00u) | ((w << 8) & 0xff0000u) | (w << 24); }
 
-// after the call cnt >= 33 (the most a symbol consumes is 16 code bits + 15 extra bits)
+// after the call cnt >= 33 (the most a symbol consumes is 16 code bits + 15 extra bits).  One aligned dword load per
+// iteration; its bytes go through the stuffing state machine as STRAIGHT-LINE code (no inner loop, no second load): a wave
+// decodes 64 frames in lockstep, and whatever one lane has to do every lane waits for.
 GRL_HD static inline void gj_fill(GjBits& b) {
     while (b.cnt <= 32) {
-        if (!b.marker && (b.pos & 3u) == 0 && b.pos + 4 <= b.end && b.pos + 4 <= b.limit) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(b.base + b.pos);
-            const uint32_t inv = ~w;
-            if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {       // no 0xFF byte in this dword
-                b.acc = (b.acc << 32) | (uint64_t)gj_bswap(w);
-                b.cnt += 32;
-                b.pos += 4;
-                continue;
-            }
-        }
-        int byte = 0;
-        if (!b.marker && b.pos < b.end) {
-            byte = gj_byte_at(b, b.pos);
-            if (byte == 0xFF) {
-                uint32_t q = b.pos + 1;
-                while (q < b.end && gj_byte_at(b, q) == 0xFF) ++q;        // fill bytes
-                if (q < b.end && gj_byte_at(b, q) == 0x00) {
-                    b.pos = q + 1;                                         // stuffed zero: a data byte 0xFF
-                } else {
-                    b.marker = 1;                                          // RSTn / EOI / anything else: stays unread
-                    byte = 0;
-                }
-            } else {
-                b.pos++;
-            }
-        } else if (b.pos >= b.end) {
+        if (b.marker || b.pos >= b.end) {                                 // past the data: zero bits (libjpeg does the same)
             b.marker = 1;
+            b.acc <<= 32;
+            b.cnt += 32;
+            continue;
         }
-        b.acc = (b.acc << 8) | (uint64_t)byte;
-        b.cnt += 8;
+        const uint32_t a = b.pos & ~3u, i0 = b.pos & 3u;
+        const uint32_t w = gj_load_dword(b, a);
+        const uint32_t nvalid = b.end - a < 4u ? b.end - a : 4u;          // bytes of this dword that belong to the scan
+        const uint32_t inv = ~w;
+        if (i0 == 0 && nvalid == 4 && !b.ffp && ((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {
+            b.acc = (b.acc << 32) | (uint64_t)gj_bswap(w);                // no 0xFF byte: 32 bits at once
+            b.cnt += 32;
+            b.pos += 4;
+            continue;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t byte = (w >> (8 * i)) & 255u;
+            if (i >= i0 && i < nvalid && !b.marker) {
+                if (b.ffp) {
+                    if (byte == 0) { b.acc = (b.acc << 8) | 0xFFu; b.cnt += 8; b.ffp = 0; }   // stuffed zero: a data byte 0xFF
+                    else if (byte != 0xFF) { b.marker = 1; b.pos = a + i - 1; }               // RSTn / EOI / ...: stays unread
+                } else if (byte == 0xFF) {
+                    b.ffp = 1;
+                } else {
+                    b.acc = (b.acc << 8) | (uint64_t)byte;
+                    b.cnt += 8;
+                }
+            }
+        }
+        if (!b.marker) b.pos = a + nvalid;
     }
 }
 
@@ -91,7 +98,7 @@ GRL_HD static inline int gj_get_bits(GjBits& b, int s) {                  // s i
 
 GRL_HD static inline int gj_extend(int x, int s) { return x < (1 << (s - 1)) ? x + (int)((~0u) << s) + 1 : x; }
 
-// one Huffman symbol of table t (0, 1: DC; 2, 3: AC): look-ahead table first, canonical search for codes > 9 bits
+// one Huffman symbol of table t (0, 1: DC; 2, 3: AC): look-ahead table first, canonical search for the codes it does not cover
 GRL_HD static inline int gj_symbol(GjBits& b, const uint16_t* lut /* this table's GJ_LUT_SIZE entries */, const GrlJpegFrame* fr, int t) {
     const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
     const uint32_t e = lut[look >> (16 - GJ_LUT_BITS)];
@@ -107,7 +114,7 @@ GRL_HD static inline int gj_symbol(GjBits& b, const uint16_t* lut /* this table'
     return 0;
 }
 
-// the look-ahead entry for the 9 bits `p` of table t (jpeg_lut_kernel / the host test build the tables with this)
+// the look-ahead entry for the GJ_LUT_BITS bits `p` of table t (jpeg_lut_kernel / the host test build the tables with this)
 GRL_HD static inline uint16_t gj_lut_entry(const GrlJpegFrame* fr, int t, int p) {
     for (int l = 1; l <= GJ_LUT_BITS; ++l) {
         const int code = p >> (GJ_LUT_BITS - l);
@@ -132,7 +139,7 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
     b.pos = fr->scan_off;
     b.end = fr->scan_off + fr->scan_len;
     b.limit = limit;
-    b.acc = 0; b.cnt = 0; b.marker = 0;
+    b.acc = 0; b.cnt = 0; b.marker = 0; b.ffp = 0;
     b.caddr = 0xffffffffu; b.cword = 0;
     int pred[3] = {0, 0, 0};
     const int ri = fr->restart_interval;
@@ -142,7 +149,7 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
         if (ri) {
             if (left == 0) {
                 // discard the partial byte, find the RSTn marker, step over it; DC predictions restart
-                b.cnt = 0; b.acc = 0;
+                b.cnt = 0; b.acc = 0; b.ffp = 0;
                 uint32_t q = b.pos;
                 while (q + 1 < b.end) {
                     if (gj_byte_at(b, q) == 0xFF) {

@@ -5,8 +5,8 @@
 //                            across frames: a lane owns a frame, a 64-lane workgroup owns 64 frames whose Huffman tables sit
 //                            in LDS lane-minor ([entry][lane]: 4-byte entries are bank-conflict-free whatever each lane
 //                            indexes).  The byte stream is read as aligned dwords (one global load per 4 stream bytes),
-//                            0xFF00 stuffing / fill bytes / RSTn handled in registers.  Only NON-ZERO coefficients are
-//                            written (the coefficient array is zero-filled by a memset node in front of the kernel).
+//                            0xFF00 stuffing / fill bytes / RSTn handled in registers.  A block is assembled in LDS
+//                            (dword-interleaved over the lanes) and leaves as eight 16-byte stores.
 //   2. jpeg_idct_kernel      dequantisation + jidctint.c's jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2), one lane per 8 x 8
 //                            block, both passes in registers, eight 8-byte row stores into the component plane.
 //   3. jpeg_color_kernel     jdsample.c's triangle-filter ("fancy") chroma upsampling + jdcolor.c's fixed-point YCbCr -> RGB,
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
                                                           const uint16_t* __restrict__ lut, int lds_sets) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t* const s_nat = lds;                                           // 80 bytes (+ pad to 128)
-    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128);       // lds_sets x 32 KiB
+    int16_t* const s_stage = reinterpret_cast<int16_t*>(lds + 128);       // 8 KiB: one 8 x 8 block per lane, [dword][lane]
+    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128 + 8192);    // lds_sets x 32 KiB
     const int lane = threadIdx.x;
     for (int i = lane; i < 80; i += EW) s_nat[i] = kNaturalDev[i];
     {   // the batch's look-ahead tables -> LDS (when they fit: a batch of camera frames shares ONE table set)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
     if (f >= n) return;
     const GrlJpegFrame* fr = frames + f;
     const uint16_t* my_lut = (lds_sets ? s_lut : lut) + (int64_t)fr->tabset * LUT_PER_SET;
-    gj_decode_scan(bytes, nbytes & ~3u, fr, my_lut, s_nat, coef + (int64_t)f * blocks * 64, sg);
+    gj_decode_scan(bytes, nbytes & ~3u, fr, my_lut, s_nat, coef + (int64_t)f * blocks * 64, sg, s_stage + 2 * lane, 2 * EW);
 }
 
 // ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------
@@ -443,13 +444,12 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     const int64_t coef_bytes = (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t);
     uint8_t* planes = reinterpret_cast<uint8_t*>(workspace) + ((coef_bytes + 255) & ~(int64_t)255);
     uint16_t* lut = reinterpret_cast<uint16_t*>(planes + (((int64_t)n * g.plane_bytes + 255) & ~(int64_t)255));
-    if (hipMemsetAsync(coef, 0, (size_t)coef_bytes, s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
     hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4, GJ_LUT_SIZE / 256), dim3(256), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
     const int lds_sets = identity ? 0 : sets;
-    const size_t e_lds = 128 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
+    const size_t e_lds = 128 + 8192 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 + MAX_LDS_SETS * LUT_PER_SET * (int)sizeof(uint16_t));
+                                  128 + 8192 + MAX_LDS_SETS * LUT_PER_SET * (int)sizeof(uint16_t));
         return true;
     }();
     (void)attr;

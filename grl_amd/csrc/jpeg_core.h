@@ -9,7 +9,7 @@
 //     bytes, RSTn / EOI, the unaligned head and the tail of a scan);
 //   * Huffman symbols through a 12-bit look-ahead table (one read: length << 8 | symbol; 0 = longer than 12 bits), the
 //     rare long codes by the canonical maxcode / valoff search;
-//   * only NON-ZERO coefficients are stored (the caller zero-fills the coefficient array).
+//   * a block's coefficients are assembled in a small staging area (LDS on the device) and leave as whole 128-byte blocks.
 #pragma once
 #include <stdint.h>
 
@@ -123,6 +123,8 @@ GRL_HD static inline uint16_t gj_lut_entry(const GrlJpegFrame* fr, int t, int p)
     return 0;
 }
 
+struct __attribute__((aligned(16))) GjU4 { uint32_t x, y, z, w; };
+
 struct GjScanGeo {
     int mcus;                 // MCUs per frame
     int ncomp;
@@ -130,10 +132,14 @@ struct GjScanGeo {
 };
 
 // Decode one frame's scan: `lut` = 4 tables x GJ_LUT_SIZE entries [DC0, DC1, AC0, AC1] of this frame's table set,
-// `nat` = the 64 (+16 guard) entry zigzag -> natural order table, `out` = this frame's zero-filled coefficients
-// [blocks][64].
+// `nat` = the 64 (+16 guard) entry zigzag -> natural order table, `out` = this frame's coefficients [blocks][64] (every
+// block is written whole).  A block is assembled in `stage` -- coefficient i lives at stage[(i >> 1) * sstride + (i & 1)]:
+// on the device that is LDS, dword-interleaved over the wave's lanes (sstride = 128 int16: lane l's dword w sits in bank l
+// whatever w is), on the host a plain 64-entry array (sstride = 2) -- and leaves as eight 16-byte stores.  (The first
+// device version scattered 2-byte stores straight to HBM: gfx9's vmcnt counts stores too, so every later load of the byte
+// stream waited for 64 partial-line writes to be acknowledged -- 1700 cycles per symbol.)
 GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, const GrlJpegFrame* fr, const uint16_t* lut,
-                                         const uint8_t* nat, int16_t* out, const GjScanGeo& g) {
+                                         const uint8_t* nat, int16_t* out, const GjScanGeo& g, int16_t* stage, int sstride) {
     GjBits b;
     b.base = bytes;
     b.pos = fr->scan_off;
@@ -143,8 +149,11 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
     b.caddr = 0xffffffffu; b.cword = 0;
     int pred[3] = {0, 0, 0};
     const int ri = fr->restart_interval;
+    int tdc[3], tac[3];
+    for (int c = 0; c < 3; ++c) { tdc[c] = fr->td[c] & 1; tac[c] = 2 + (fr->ta[c] & 1); }
     int left = ri;
     int blk = 0;
+    for (int w = 0; w < 32; ++w) *reinterpret_cast<uint32_t*>(stage + w * sstride) = 0u;
     for (int m = 0; m < g.mcus; ++m) {
         if (ri) {
             if (left == 0) {
@@ -166,27 +175,39 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
             --left;
         }
         for (int c = 0; c < g.ncomp; ++c) {
-            const int td = fr->td[c] & 1, ta = 2 + (fr->ta[c] & 1);
+            const int td = tdc[c], ta = tac[c];
             const uint16_t* const lut_dc = lut + td * GJ_LUT_SIZE;
             const uint16_t* const lut_ac = lut + ta * GJ_LUT_SIZE;
             for (int bi = 0; bi < g.nb[c]; ++bi, ++blk) {
-                int16_t* const o = out + (int64_t)blk * 64;
                 gj_fill(b);
                 int s = gj_symbol(b, lut_dc, fr, td) & 15;
                 if (s) s = gj_extend(gj_get_bits(b, s), s);
                 pred[c] += s;
-                if (pred[c]) o[0] = (int16_t)pred[c];
+                stage[0] = (int16_t)pred[c];
                 for (int k = 1; k < 64; ++k) {
                     gj_fill(b);
                     const int rs = gj_symbol(b, lut_ac, fr, ta);
                     const int r = rs >> 4, sz = rs & 15;
                     if (sz) {
                         k += r;
-                        o[nat[k]] = (int16_t)gj_extend(gj_get_bits(b, sz), sz);
+                        const int i = nat[k];
+                        stage[(i >> 1) * sstride + (i & 1)] = (int16_t)gj_extend(gj_get_bits(b, sz), sz);
                     } else {
                         if (r != 15) break;
                         k += 15;
                     }
+                }
+                // the block leaves as eight 16-byte rows; the stage is cleared for the next one on the way
+                uint32_t* const o = reinterpret_cast<uint32_t*>(out + (int64_t)blk * 64);
+                for (int w4 = 0; w4 < 8; ++w4) {
+                    uint32_t v[4];
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t* const sp = reinterpret_cast<uint32_t*>(stage + (w4 * 4 + e) * sstride);
+                        v[e] = *sp;
+                        *sp = 0u;
+                    }
+                    GjU4 q4 = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<GjU4*>(o + w4 * 4) = q4;
                 }
             }
         }

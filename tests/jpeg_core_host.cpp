@@ -20,6 +20,7 @@ extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpeg
     g.mcus = mcux * mcuy;
     g.ncomp = fr->ncomp;
     for (int c = 0; c < 3; ++c) g.nb[c] = fr->hs[c] * fr->vs[c];
-    gj_decode_scan(buf, nbytes & ~3u, fr, lut, kNat, out, g);
+    alignas(16) int16_t stage[64];
+    gj_decode_scan(buf, nbytes & ~3u, fr, lut, kNat, out, g, stage, 2);
     return 0;
 }

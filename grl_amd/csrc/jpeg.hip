@@ -101,8 +101,14 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
     const int f = blockIdx.x * EW + lane;
     if (f >= n) return;
     const GrlJpegFrame* fr = frames + f;
-    const uint16_t* my_lut = (lds_sets ? s_lut : lut) + (int64_t)fr->tabset * LUT_PER_SET;
-    gj_decode_scan(bytes, nbytes & ~3u, fr, my_lut, s_nat, coef + (int64_t)f * blocks * 64, sg, s_stage + 2 * lane, 2 * EW);
+    // two calls, not one pointer chosen at run time: a pointer that may be LDS or global compiles to FLAT loads (each symbol's
+    // table read then waits vmcnt(0) & lgkmcnt(0)); with the provenance known per call they are ds_read / global_load
+    if (lds_sets)
+        gj_decode_scan(bytes, nbytes & ~3u, fr, s_lut + (int)fr->tabset * LUT_PER_SET, s_nat, coef + (int64_t)f * blocks * 64, sg,
+                       s_stage + 2 * lane, 2 * EW);
+    else
+        gj_decode_scan(bytes, nbytes & ~3u, fr, lut + (int64_t)fr->tabset * LUT_PER_SET, s_nat, coef + (int64_t)f * blocks * 64, sg,
+                       s_stage + 2 * lane, 2 * EW);
 }
 
 // ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------

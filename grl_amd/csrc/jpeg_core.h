@@ -123,7 +123,11 @@ GRL_HD static inline uint16_t gj_lut_entry(const GrlJpegFrame* fr, int t, int p)
     return 0;
 }
 
-struct __attribute__((aligned(16))) GjU4 { uint32_t x, y, z, w; };
+// (the staging area is written as int16 and read back as dwords, the output as 16-byte rows: may_alias types, or the
+//  compiler is free to forward the stage's zero-fill to the read-back -- it did)
+typedef uint32_t __attribute__((may_alias)) gj_u32a;
+typedef int16_t __attribute__((may_alias)) gj_i16a;
+struct __attribute__((aligned(16), may_alias)) GjU4 { uint32_t x, y, z, w; };
 
 struct GjScanGeo {
     int mcus;                 // MCUs per frame
@@ -153,7 +157,7 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
     for (int c = 0; c < 3; ++c) { tdc[c] = fr->td[c] & 1; tac[c] = 2 + (fr->ta[c] & 1); }
     int left = ri;
     int blk = 0;
-    for (int w = 0; w < 32; ++w) *reinterpret_cast<uint32_t*>(stage + w * sstride) = 0u;
+    for (int w = 0; w < 32; ++w) *reinterpret_cast<gj_u32a*>(stage + w * sstride) = 0u;
     for (int m = 0; m < g.mcus; ++m) {
         if (ri) {
             if (left == 0) {
@@ -183,7 +187,7 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
                 int s = gj_symbol(b, lut_dc, fr, td) & 15;
                 if (s) s = gj_extend(gj_get_bits(b, s), s);
                 pred[c] += s;
-                stage[0] = (int16_t)pred[c];
+                *reinterpret_cast<gj_i16a*>(stage) = (int16_t)pred[c];
                 for (int k = 1; k < 64; ++k) {
                     gj_fill(b);
                     const int rs = gj_symbol(b, lut_ac, fr, ta);
@@ -191,18 +195,18 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
                     if (sz) {
                         k += r;
                         const int i = nat[k];
-                        stage[(i >> 1) * sstride + (i & 1)] = (int16_t)gj_extend(gj_get_bits(b, sz), sz);
+                        *reinterpret_cast<gj_i16a*>(stage + (i >> 1) * sstride + (i & 1)) = (int16_t)gj_extend(gj_get_bits(b, sz), sz);
                     } else {
                         if (r != 15) break;
                         k += 15;
                     }
                 }
                 // the block leaves as eight 16-byte rows; the stage is cleared for the next one on the way
-                uint32_t* const o = reinterpret_cast<uint32_t*>(out + (int64_t)blk * 64);
+                gj_u32a* const o = reinterpret_cast<gj_u32a*>(out + (int64_t)blk * 64);
                 for (int w4 = 0; w4 < 8; ++w4) {
                     uint32_t v[4];
                     for (int e = 0; e < 4; ++e) {
-                        uint32_t* const sp = reinterpret_cast<uint32_t*>(stage + (w4 * 4 + e) * sstride);
+                        gj_u32a* const sp = reinterpret_cast<gj_u32a*>(stage + (w4 * 4 + e) * sstride);
                         v[e] = *sp;
                         *sp = 0u;
                     }

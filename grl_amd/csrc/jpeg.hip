@@ -82,10 +82,68 @@ __global__ __launch_bounds__(256) void jpeg_lut_kernel(const GrlJpegFrame* __res
     lut[(int64_t)blockIdx.x * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
 }
 
+// Unstuffing pre-pass: one workgroup per frame walks the scan in 1 KiB chunks; a lane owns four bytes, applies the
+// per-byte rule of jpeg_core.h (drop the 0x00 behind an 0xFF, drop fill bytes, stop at the first marker), an exclusive
+// scan of the kept-byte counts over the workgroup gives every lane its output offset.  The clean stream of a frame lives at
+// the dword-rounded offset of its scan (scans never touch: there are headers in between) and is zero-padded by 16 bytes.
+constexpr int UT = 256;                                  // lanes of the pre-pass workgroup (4 bytes each per chunk)
+__global__ __launch_bounds__(UT) void jpeg_unstuff_kernel(const uint8_t* __restrict__ bytes, const GrlJpegFrame* __restrict__ frames,
+                                                          uint8_t* __restrict__ clean, uint32_t* __restrict__ clean_len) {
+    __shared__ uint32_t s_wave[UT / 64];
+    __shared__ uint32_t s_marker;
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint8_t* src = bytes + frames[f].scan_off;
+    const uint32_t len = frames[f].scan_len;
+    uint8_t* dst = clean + ((frames[f].scan_off + 3u) & ~3u);
+    uint32_t base = 0;
+    for (uint32_t chunk = 0; chunk < len; chunk += UT * 4) {
+        if (t == 0) s_marker = 0xffffffffu;
+        __syncthreads();
+        const uint32_t i0 = chunk + 4u * t;
+        int by[6];                                                         // bytes i0 - 1 .. i0 + 4 (-1 beyond the scan)
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t i = i0 + k - 1;
+            by[k] = (i0 + k >= 1 && i < len) ? (int)src[i] : (i0 + k == 0 ? 0 : -1);
+        }
+        uint32_t first_marker = 0xffffffffu;
+        for (int k = 3; k >= 0; --k)
+            if (i0 + k < len && gj_marker_starts(by[k + 1], by[k + 2])) first_marker = i0 + k;
+        if (first_marker != 0xffffffffu) atomicMin(&s_marker, first_marker);
+        __syncthreads();
+        const uint32_t marker = s_marker;
+        uint32_t keep = 0, cnt = 0;
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < len && i0 + k < marker && gj_is_data(by[k], by[k + 1], by[k + 2])) { keep |= 1u << k; ++cnt; }
+        // exclusive scan of cnt over the workgroup: wave-level shuffles, then the wave totals
+        uint32_t incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t off = base + incl - cnt, total = 0;
+        for (int w = 0; w < UT / 64; ++w) {
+            if (w < wave) off += s_wave[w];
+            total += s_wave[w];
+        }
+        for (int k = 0; k < 4; ++k)
+            if (keep & (1u << k)) dst[off++] = (uint8_t)by[k + 1];
+        base += total;
+        __syncthreads();
+        if (marker != 0xffffffffu) break;                                  // (uniform: every lane read the same s_marker)
+    }
+    if (t < 16) dst[base + t] = 0;                                         // zero padding: the reader's last dword and one more
+    if (t == 0) clean_len[f] = base;
+}
+
+// READER 0: the clean stream of the pre-pass (no restart intervals in the batch); READER 1: the general reader on the raw bytes
+template <int READER>
 __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restrict__ bytes, uint32_t nbytes,
                                                           const GrlJpegFrame* __restrict__ frames, int n,
                                                           int16_t* __restrict__ coef, GjScanGeo sg, int blocks,
-                                                          const uint16_t* __restrict__ lut, int lds_sets) {
+                                                          const uint16_t* __restrict__ lut, int lds_sets,
+                                                          const uint8_t* __restrict__ clean, const uint32_t* __restrict__ clean_len) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t* const s_nat = lds;                                           // 80 bytes (+ pad to 128)
     int16_t* const s_stage = reinterpret_cast<int16_t*>(lds + 128);       // 8 KiB: one 8 x 8 block per lane, [dword][lane]
@@ -101,14 +159,20 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
     const int f = blockIdx.x * EW + lane;
     if (f >= n) return;
     const GrlJpegFrame* fr = frames + f;
-    // two calls, not one pointer chosen at run time: a pointer that may be LDS or global compiles to FLAT loads (each symbol's
-    // table read then waits vmcnt(0) & lgkmcnt(0)); with the provenance known per call they are ds_read / global_load
-    if (lds_sets)
-        gj_decode_scan(bytes, nbytes & ~3u, fr, s_lut + (int)fr->tabset * LUT_PER_SET, s_nat, coef + (int64_t)f * blocks * 64, sg,
-                       s_stage + 2 * lane, 2 * EW);
-    else
-        gj_decode_scan(bytes, nbytes & ~3u, fr, lut + (int64_t)fr->tabset * LUT_PER_SET, s_nat, coef + (int64_t)f * blocks * 64, sg,
-                       s_stage + 2 * lane, 2 * EW);
+    int16_t* const out = coef + (int64_t)f * blocks * 64;
+    // (two calls per reader, not one table pointer chosen at run time: a pointer that may be LDS or global compiles to FLAT
+    //  loads, each followed by s_waitcnt vmcnt(0) & lgkmcnt(0); with the provenance known per call they are ds_read / global_load)
+    if constexpr (READER == 0) {
+        GjClean b;
+        gj_clean_init(b, clean + ((fr->scan_off + 3u) & ~3u), clean_len[f]);
+        if (lds_sets) gj_decode_scan(b, fr, s_lut + (int)fr->tabset * LUT_PER_SET, s_nat, out, sg, s_stage + 2 * lane, 2 * EW);
+        else gj_decode_scan(b, fr, lut + (int64_t)fr->tabset * LUT_PER_SET, s_nat, out, sg, s_stage + 2 * lane, 2 * EW);
+    } else {
+        GjBits b;
+        gj_bits_init(b, bytes, nbytes & ~3u, fr);
+        if (lds_sets) gj_decode_scan(b, fr, s_lut + (int)fr->tabset * LUT_PER_SET, s_nat, out, sg, s_stage + 2 * lane, 2 * EW);
+        else gj_decode_scan(b, fr, lut + (int64_t)fr->tabset * LUT_PER_SET, s_nat, out, sg, s_stage + 2 * lane, 2 * EW);
+    }
 }
 
 // ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------
@@ -368,10 +432,32 @@ extern "C" int grl_jpeg_parse(const uint8_t* p, int64_t len, int64_t base_off, G
     return GRL_OK;
 }
 
-extern "C" int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n) {
-    if (!frame0 || n <= 0 || !frame0->width || !frame0->hmax) return 0;
-    const Geo g = make_geo(*frame0);
-    return (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t) + (int64_t)n * g.plane_bytes + (int64_t)n * LUT_PER_SET * 2 + 512;
+static uint32_t scan_extent(const GrlJpegFrame* frames, int n) {
+    uint32_t nbytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t e = frames[i].scan_off + frames[i].scan_len;
+        if (e > nbytes) nbytes = e;
+    }
+    return nbytes;
+}
+
+// workspace layout: coefficients | planes | look-ahead tables | clean (unstuffed) streams | their lengths
+struct Layout { int64_t coef, planes, lut, clean, clean_len, total; };
+static Layout make_layout(const Geo& g, int n, uint32_t nbytes) {
+    auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    Layout l;
+    l.coef = 0;
+    l.planes = up((int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t));
+    l.lut = l.planes + up((int64_t)n * g.plane_bytes);
+    l.clean = l.lut + up((int64_t)n * LUT_PER_SET * 2);
+    l.clean_len = l.clean + up((int64_t)nbytes + 32);
+    l.total = l.clean_len + up((int64_t)n * 4);
+    return l;
+}
+
+extern "C" int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frames_host, int n) {
+    if (!frames_host || n <= 0 || !frames_host[0].width || !frames_host[0].hmax) return 0;
+    return make_layout(make_geo(frames_host[0]), n, scan_extent(frames_host, n)).total;
 }
 
 // HOST: give every frame the index of its Huffman table set (frames[i].tabset).  Up to 4 distinct sets share look-ahead
@@ -420,7 +506,7 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
         if (e < f.scan_off) return grl_fail(GRL_EINVAL, "jpeg_decode_batch: frame %d: stream range wraps", i);
         if (e > nbytes) nbytes = e;
     }
-    GRL_REQUIRE(workspace_bytes >= grl_jpeg_workspace_bytes(&f0, n), "jpeg_decode_batch: workspace too small (grl_jpeg_workspace_bytes)");
+    GRL_REQUIRE(workspace_bytes >= grl_jpeg_workspace_bytes(frames_host, n), "jpeg_decode_batch: workspace too small (grl_jpeg_workspace_bytes)");
     // table sets (grl_jpeg_assign_tables): a frame's tables must be the ones of its set's first frame
     constexpr size_t TB = sizeof(f0.maxcode) + sizeof(f0.valoff) + sizeof(f0.vals);
     int sets = 0;
@@ -446,21 +532,34 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     sg.mcus = g.mcux * g.mcuy; sg.ncomp = g.ncomp;
     for (int c = 0; c < 3; ++c) sg.nb[c] = g.hs[c] * g.vs[c];
     hipStream_t s = (hipStream_t)stream;
-    int16_t* coef = reinterpret_cast<int16_t*>(workspace);
-    const int64_t coef_bytes = (int64_t)n * g.blocks * 64 * (int64_t)sizeof(int16_t);
-    uint8_t* planes = reinterpret_cast<uint8_t*>(workspace) + ((coef_bytes + 255) & ~(int64_t)255);
-    uint16_t* lut = reinterpret_cast<uint16_t*>(planes + (((int64_t)n * g.plane_bytes + 255) & ~(int64_t)255));
+    const Layout lay = make_layout(g, n, nbytes);
+    uint8_t* const wsb = reinterpret_cast<uint8_t*>(workspace);
+    int16_t* coef = reinterpret_cast<int16_t*>(wsb + lay.coef);
+    uint8_t* planes = wsb + lay.planes;
+    uint16_t* lut = reinterpret_cast<uint16_t*>(wsb + lay.lut);
+    uint8_t* clean = wsb + lay.clean;
+    uint32_t* clean_len = reinterpret_cast<uint32_t*>(wsb + lay.clean_len);
     hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4, GJ_LUT_SIZE / 256), dim3(256), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
     const int lds_sets = identity ? 0 : sets;
     const size_t e_lds = 128 + 8192 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
     static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 + 8192 + MAX_LDS_SETS * LUT_PER_SET * (int)sizeof(uint16_t));
+        const int most = 128 + 8192 + MAX_LDS_SETS * LUT_PER_SET * (int)sizeof(uint16_t);
+        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        (void)hipFuncSetAttribute((const void*)jpeg_entropy_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
         return true;
     }();
     (void)attr;
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
-                       g.blocks, lut, lds_sets);
+    bool any_restart = false;
+    for (int i = 0; i < n; ++i) any_restart = any_restart || frames_host[i].restart_interval != 0;
+    if (!any_restart) {
+        // the common case: stuffing and the trailing marker removed by a pre-pass, the decoder reads clean dwords
+        hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(UT), 0, s, bytes, frames_dev, clean, clean_len);
+        hipLaunchKernelGGL(jpeg_entropy_kernel<0>, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
+                           g.blocks, lut, lds_sets, clean, clean_len);
+    } else {
+        hipLaunchKernelGGL(jpeg_entropy_kernel<1>, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
+                           g.blocks, lut, lds_sets, clean, clean_len);
+    }
     const int64_t nblk = (int64_t)n * g.blocks;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, coef, frames_dev, n, planes, g);
     const int64_t npix = (int64_t)n * g.width * g.height;

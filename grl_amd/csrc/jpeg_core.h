@@ -91,7 +91,68 @@ GRL_HD static inline void gj_fill(GjBits& b) {
     }
 }
 
-GRL_HD static inline int gj_get_bits(GjBits& b, int s) {                  // s in 1..16, cnt >= s
+GRL_HD static inline void gj_bits_init(GjBits& b, const uint8_t* bytes, uint32_t limit, const GrlJpegFrame* fr) {
+    b.base = bytes;
+    b.pos = fr->scan_off;
+    b.end = fr->scan_off + fr->scan_len;
+    b.limit = limit;
+    b.acc = 0; b.cnt = 0; b.marker = 0; b.ffp = 0;
+    b.caddr = 0xffffffffu; b.cword = 0;
+}
+
+// discard the partial byte, find the RSTn marker, step over it (restart intervals: the general reader only)
+GRL_HD static inline void gj_restart(GjBits& b) {
+    b.cnt = 0; b.acc = 0; b.ffp = 0;
+    uint32_t q = b.pos;
+    while (q + 1 < b.end) {
+        if (gj_byte_at(b, q) == 0xFF) {
+            const int m2 = gj_byte_at(b, q + 1);
+            if (m2 >= 0xD0 && m2 <= 0xD7) break;
+        }
+        ++q;
+    }
+    if (q + 1 < b.end) b.pos = q + 2;
+    b.marker = 0;
+}
+
+// ---- the CLEAN reader: a scan whose stuffing and trailing marker were removed by a pre-pass (jpeg_unstuff_kernel /
+// gj_unstuff_host) into dword-aligned, zero-padded storage.  Refill is one already-loaded dword, byte-swapped, and the
+// request for the next one -- no branch, no 0xFF handling, no exposed load latency.  With 64 frames decoded in lockstep the
+// general reader's "rare" paths (an 0xFF byte in 1.6 % of the dwords, a refill every ~4.5 symbols at a different moment in
+// every lane) run at almost every step and every lane waits for them; this reader has none.
+struct GjClean {
+    const uint32_t* p;        // next dword to LOAD
+    int left;                 // dwords not loaded yet
+    uint32_t nw;              // the dword loaded ahead
+    uint64_t acc;
+    int cnt;
+};
+GRL_HD static inline void gj_clean_init(GjClean& b, const uint8_t* clean, uint32_t nbytes) {
+    b.p = reinterpret_cast<const uint32_t*>(clean);
+    b.left = (int)((nbytes + 3u) >> 2);
+    b.acc = 0; b.cnt = 0;
+    b.nw = b.left > 0 ? *b.p : 0u;
+    ++b.p; --b.left;
+}
+GRL_HD static inline void gj_fill(GjClean& b) {
+    while (b.cnt <= 32) {
+        const uint32_t w = b.nw;
+        b.nw = b.left > 0 ? *b.p : 0u;      // past the data: zero bits (libjpeg does the same)
+        ++b.p; --b.left;
+        b.acc = (b.acc << 32) | (uint64_t)gj_bswap(w);
+        b.cnt += 32;
+    }
+}
+GRL_HD static inline void gj_restart(GjClean&) {}     // (scans with restart intervals take the general reader)
+
+// the unstuffing rule, per byte of a scan (prev / next: the neighbours, -1 beyond the scan):
+//   a marker starts at an 0xFF that is followed by neither 0x00 (stuffing) nor 0xFF (fill) -- or by nothing;
+//   a byte is data unless it is the 0x00 behind an 0xFF, or an 0xFF that is not followed by 0x00.
+GRL_HD static inline bool gj_marker_starts(int cur, int next) { return cur == 0xFF && next != 0x00 && next != 0xFF; }
+GRL_HD static inline bool gj_is_data(int prev, int cur, int next) { return !(cur == 0x00 && prev == 0xFF) && !(cur == 0xFF && next != 0x00); }
+
+template <class R>
+GRL_HD static inline int gj_get_bits(R& b, int s) {                  // s in 1..16, cnt >= s
     b.cnt -= s;
     return (int)((b.acc >> b.cnt) & ((1u << s) - 1u));
 }
@@ -99,7 +160,8 @@ GRL_HD static inline int gj_get_bits(GjBits& b, int s) {                  // s i
 GRL_HD static inline int gj_extend(int x, int s) { return x < (1 << (s - 1)) ? x + (int)((~0u) << s) + 1 : x; }
 
 // one Huffman symbol of table t (0, 1: DC; 2, 3: AC): look-ahead table first, canonical search for the codes it does not cover
-GRL_HD static inline int gj_symbol(GjBits& b, const uint16_t* lut /* this table's GJ_LUT_SIZE entries */, const GrlJpegFrame* fr, int t) {
+template <class R>
+GRL_HD static inline int gj_symbol(R& b, const uint16_t* lut /* this table's GJ_LUT_SIZE entries */, const GrlJpegFrame* fr, int t) {
     const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
     const uint32_t e = lut[look >> (16 - GJ_LUT_BITS)];
     if (e) { b.cnt -= (int)(e >> 8); return (int)(e & 255u); }
@@ -142,15 +204,9 @@ struct GjScanGeo {
 // whatever w is), on the host a plain 64-entry array (sstride = 2) -- and leaves as eight 16-byte stores.  (The first
 // device version scattered 2-byte stores straight to HBM: gfx9's vmcnt counts stores too, so every later load of the byte
 // stream waited for 64 partial-line writes to be acknowledged -- 1700 cycles per symbol.)
-GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, const GrlJpegFrame* fr, const uint16_t* lut,
+template <class R>
+GRL_HD static inline void gj_decode_scan(R& b, const GrlJpegFrame* fr, const uint16_t* lut,
                                          const uint8_t* nat, int16_t* out, const GjScanGeo& g, int16_t* stage, int sstride) {
-    GjBits b;
-    b.base = bytes;
-    b.pos = fr->scan_off;
-    b.end = fr->scan_off + fr->scan_len;
-    b.limit = limit;
-    b.acc = 0; b.cnt = 0; b.marker = 0; b.ffp = 0;
-    b.caddr = 0xffffffffu; b.cword = 0;
     int pred[3] = {0, 0, 0};
     const int ri = fr->restart_interval;
     int tdc[3], tac[3];
@@ -161,18 +217,7 @@ GRL_HD static inline void gj_decode_scan(const uint8_t* bytes, uint32_t limit, c
     for (int m = 0; m < g.mcus; ++m) {
         if (ri) {
             if (left == 0) {
-                // discard the partial byte, find the RSTn marker, step over it; DC predictions restart
-                b.cnt = 0; b.acc = 0; b.ffp = 0;
-                uint32_t q = b.pos;
-                while (q + 1 < b.end) {
-                    if (gj_byte_at(b, q) == 0xFF) {
-                        const int m2 = gj_byte_at(b, q + 1);
-                        if (m2 >= 0xD0 && m2 <= 0xD7) break;
-                    }
-                    ++q;
-                }
-                if (q + 1 < b.end) b.pos = q + 2;
-                b.marker = 0;
+                gj_restart(b);                       // DC predictions restart
                 pred[0] = pred[1] = pred[2] = 0;
                 left = ri;
             }

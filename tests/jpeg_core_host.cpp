@@ -2,6 +2,7 @@
 // exactly the per-lane logic of jpeg_entropy_kernel.  Built by tests/test_jpeg_cpu.py with g++ (no GPU, no HIP).
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #define GRL_HD
 #include "../grl_amd/csrc/jpeg_core.h"
 
@@ -10,17 +11,47 @@ static const uint8_t kNat[80] = {
     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
     63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
 
-// buf: the batch byte buffer (nbytes long), fr: the parsed frame, out: zero-filled int16 [blocks][64]
-extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
-    static uint16_t lut[4 * GJ_LUT_SIZE];
+static void setup(const GrlJpegFrame* fr, uint16_t* lut, GjScanGeo& g) {
     for (int t = 0; t < 4; ++t)
         for (int p = 0; p < GJ_LUT_SIZE; ++p) lut[t * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
-    GjScanGeo g;
     const int mcux = (fr->width + 8 * fr->hmax - 1) / (8 * fr->hmax), mcuy = (fr->height + 8 * fr->vmax - 1) / (8 * fr->vmax);
     g.mcus = mcux * mcuy;
     g.ncomp = fr->ncomp;
     for (int c = 0; c < 3; ++c) g.nb[c] = fr->hs[c] * fr->vs[c];
+}
+
+// the GENERAL reader (stuffing / markers / restart intervals handled while decoding).
+// buf: the batch byte buffer (nbytes long), fr: the parsed frame, out: int16 [blocks][64]
+extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
+    static uint16_t lut[4 * GJ_LUT_SIZE];
+    GjScanGeo g;
+    setup(fr, lut, g);
     alignas(16) int16_t stage[64];
-    gj_decode_scan(buf, nbytes & ~3u, fr, lut, kNat, out, g, stage, 2);
+    GjBits b;
+    gj_bits_init(b, buf, nbytes & ~3u, fr);
+    gj_decode_scan(b, fr, lut, kNat, out, g, stage, 2);
     return 0;
+}
+
+// the CLEAN reader behind the unstuffing pre-pass (here a serial loop over the same per-byte rule the kernel applies).
+// Returns the number of data bytes the pre-pass kept.
+extern "C" int gj_host_decode_clean(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
+    static uint16_t lut[4 * GJ_LUT_SIZE];
+    GjScanGeo g;
+    setup(fr, lut, g);
+    const uint8_t* src = buf + fr->scan_off;
+    const int len = (int)fr->scan_len;
+    std::vector<uint32_t> clean((size_t)len / 4 + 4, 0u);
+    uint8_t* dst = reinterpret_cast<uint8_t*>(clean.data());
+    int kept = 0;
+    for (int i = 0; i < len; ++i) {
+        const int prev = i > 0 ? src[i - 1] : 0, cur = src[i], next = i + 1 < len ? src[i + 1] : -1;
+        if (gj_marker_starts(cur, next)) break;
+        if (gj_is_data(prev, cur, next)) dst[kept++] = (uint8_t)cur;
+    }
+    alignas(16) int16_t stage[64];
+    GjClean b;
+    gj_clean_init(b, dst, (uint32_t)kept);
+    gj_decode_scan(b, fr, lut, kNat, out, g, stage, 2);
+    return kept;
 }

@@ -133,8 +133,9 @@ def test_host_header_parser_fills_the_frame_descriptor(golden):
 def test_device_entropy_core_on_the_cpu_matches_the_oracle_coefficients(tmp_path):
     """grl_amd/csrc/jpeg_core.h is the per-lane logic of jpeg_entropy_kernel and compiles as plain C++
     (tests/jpeg_core_host.cpp, g++): the quantised coefficients it leaves equal the oracle's for every stream of a sweep
-    (look-ahead tables + long-code fallback, the 32-bit refill fast path at all four alignments of the scan inside the
-    batch buffer, 0xFF00 stuffing, restart markers, optimised tables)."""
+    (look-ahead tables + long-code fallback, the refill paths at all four alignments of the scan inside the batch buffer,
+    0xFF00 stuffing, restart markers, optimised tables) -- through the general reader and through the clean reader fed by
+    the unstuffing rule the pre-pass kernel applies."""
     import os
     import subprocess
     pytest.importorskip('PIL')
@@ -144,7 +145,8 @@ def test_device_entropy_core_on_the_cpu_matches_the_oracle_coefficients(tmp_path
     so = os.path.join(tmp_path, 'libgjhost.so')
     subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', os.path.join(root, 'tests', 'jpeg_core_host.cpp'), '-o', so])
     lib = C.CDLL(so)
-    lib.gj_host_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    for fn in (lib.gj_host_decode, lib.gj_host_decode_clean):       # the general reader / the clean reader behind the unstuffing rule
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(0)
     streams = []
     for (h, w) in [(256, 128), (17, 33), (1, 1), (31, 2), (64, 48), (100, 77)]:
@@ -164,9 +166,10 @@ def test_device_entropy_core_on_the_cpu_matches_the_oracle_coefficients(tmp_path
             buf = np.ascontiguousarray(np.concatenate([np.full(lead, 0xFF, np.uint8), host.numpy(), np.zeros(8, np.uint8)]))
             f = fr[0]
             f.scan_off += lead
-            out = np.zeros_like(ref)
-            lib.gj_host_decode(buf.ctypes.data, len(buf) - 8, C.addressof(f), out.ctypes.data)
-            assert np.array_equal(out, ref), (len(s), lead)
+            for fn in ((lib.gj_host_decode,) if f.restart_interval else (lib.gj_host_decode, lib.gj_host_decode_clean)):
+                out = np.full_like(ref, 7)              # (every block is written whole: no zero-fill needed)
+                fn(buf.ctypes.data, len(buf) - 8, C.addressof(f), out.ctypes.data)
+                assert np.array_equal(out, ref), (len(s), lead, fn)
 
 
 def test_table_sets_are_shared_or_per_frame():

@@ -1018,8 +1018,31 @@ def main():
                     engine.extract_features(cnn, siam, d_)
                 torch.cuda.synchronize()
                 host[name] = round(B * args.steps / (time.perf_counter() - t1), 2)
+            try:
+                # ... and from COMPRESSED frames: B x T JPEG byte strings per step (256 x 128, 4:2:0, quality 90), header parse on
+                # the host, bytes over PCIe, grl_jpeg_decode_batch on the prefetch streams next to the previous step's compute
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import decode_rate
+                from grl_amd.reid.data.jpeg import JpegBatch
+                jf = decode_rate.make_frames(B * T)
+                jb = JpegBatch(jf, (B, T))
+
+                def jloader(k):
+                    for _ in range(k):
+                        yield jb, None, None
+                for d_, _, _ in engine.DevicePrefetcher(jloader(3), dev):
+                    engine.extract_features(cnn, siam, d_)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for d_, _, _ in engine.DevicePrefetcher(jloader(args.steps), dev):
+                    engine.extract_features(cnn, siam, d_)
+                torch.cuda.synchronize()
+                host["jpeg (device decode)"] = round(B * args.steps / (time.perf_counter() - t1), 2)
+            except Exception as e:                              # noqa: BLE001 (informational)
+                host["jpeg (device decode)"] = 'error: %r' % (e,)
             out["host_resident_inputs"] = {"clip_features_per_sec": host,
-                                           "note": "pinned host batches, H2D overlapped; uint8 is normalised in the stem"}
+                                           "note": "pinned host batches, H2D overlapped; uint8 is normalised in the stem; jpeg: compressed "
+                                                   "frames decoded on the device (bit-identical to Pillow), two batches in flight"}
         if n == 1 and not args.no_alt and (B, T, args.math) == (32, 4, 'f32'):
             out["secondary"] = secondary_block(dev, cnn, siam, args.steps)
         if n == 1 and not args.no_cpu_baseline:

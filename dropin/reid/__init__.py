@@ -12,3 +12,11 @@ for _name in ('models', 'evaluator', 'train', 'loss', 'data'):
         continue
     sys.modules['reid.' + _name] = _m
     globals()[_name] = _m
+
+# sub-modules callers import by path: ONE module object under both names, so that classes
+# (e.g. reid.data.jpeg.JpegBatch) are the ones grl_amd itself checks with isinstance
+for _sub in ('data.augment', 'data.jpeg'):
+    try:
+        sys.modules['reid.' + _sub] = importlib.import_module('grl_amd.reid.' + _sub)
+    except ImportError:
+        pass

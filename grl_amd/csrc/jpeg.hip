@@ -68,18 +68,19 @@ Geo make_geo(const GrlJpegFrame& f) {
 
 // ---- 1. entropy decoding (the per-lane logic lives in jpeg_core.h: it also compiles as host C++ for the CPU tests) -------
 constexpr int EW = 64;                                   // frames per workgroup (one wave)
-constexpr int MAX_LDS_SETS = 4;                          // Huffman table sets whose look-ahead tables fit LDS (4 x 32 KiB)
-constexpr int LUT_PER_SET = 4 * GJ_LUT_SIZE;             // uint16 entries: [DC0, DC1, AC0, AC1] x 4096
+constexpr int MAX_LDS_SETS = 4;                          // Huffman table sets whose look-ahead tables fit LDS (4 x 18 KiB; ONE set: 26 KiB with the stage)
+constexpr int LUT_PER_SET = GJ_LUT_PER_SET;              // uint16 entries: [DC0 512][DC1 512][AC0 4096][AC1 4096] = 18 KiB
 
 struct Reps { int frame[MAX_LDS_SETS]; };               // the frame whose tables define table set u
 
-// look-ahead tables of the batch's table sets: grid (sets * 4, GJ_LUT_SIZE / 256), 256 threads
+// look-ahead tables of the batch's table sets: grid (sets, LUT_PER_SET / 256), 256 threads
 __global__ __launch_bounds__(256) void jpeg_lut_kernel(const GrlJpegFrame* __restrict__ frames, Reps reps, int identity,
                                                                uint16_t* __restrict__ lut) {
-    const int u = blockIdx.x >> 2, t = blockIdx.x & 3;
+    const int u = blockIdx.x;
     const GrlJpegFrame* fr = frames + (identity ? u : reps.frame[u]);
-    const int p = blockIdx.y * 256 + threadIdx.x;
-    lut[(int64_t)blockIdx.x * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
+    const int e = blockIdx.y * 256 + threadIdx.x;                       // entry inside the set
+    const int t = e < (2 << GJ_DC_BITS) ? e >> GJ_DC_BITS : 2 + ((e - (2 << GJ_DC_BITS)) >> GJ_AC_BITS);
+    lut[(int64_t)u * LUT_PER_SET + e] = gj_lut_entry(fr, t, e - gj_lut_offset(t));
 }
 
 // Unstuffing pre-pass: one workgroup per frame walks the scan in 1 KiB chunks; a lane owns four bytes, applies the
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t* const s_nat = lds;                                           // 80 bytes (+ pad to 128)
     int16_t* const s_stage = reinterpret_cast<int16_t*>(lds + 128);       // 8 KiB: one 8 x 8 block per lane, [dword][lane]
-    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128 + 8192);    // lds_sets x 32 KiB
+    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + 128 + 8192);    // lds_sets x 18 KiB
     const int lane = threadIdx.x;
     for (int i = lane; i < 80; i += EW) s_nat[i] = kNaturalDev[i];
     {   // the batch's look-ahead tables -> LDS (when they fit: a batch of camera frames shares ONE table set)
@@ -432,6 +433,22 @@ extern "C" int grl_jpeg_parse(const uint8_t* p, int64_t len, int64_t base_off, G
     return GRL_OK;
 }
 
+// HOST: grl_jpeg_parse for the n streams of a batch buffer (stream i = buf[offsets[i] .. offsets[i + 1])) followed by
+// grl_jpeg_assign_tables -- one call per batch instead of one per frame (a Python loop over 512 frames costs ~10 ms).
+// On failure *bad_index names the frame and the return value is that frame's code.
+extern "C" int grl_jpeg_parse_batch(const uint8_t* buf, const int64_t* offsets, int n, GrlJpegFrame* frames, int* bad_index) {
+    if (!buf || !offsets || !frames || n <= 0) return grl_fail(GRL_EINVAL, "jpeg_parse_batch: null / empty");
+    for (int i = 0; i < n; ++i) {
+        const int rc = grl_jpeg_parse(buf + offsets[i], offsets[i + 1] - offsets[i], offsets[i], &frames[i]);
+        if (rc) {
+            if (bad_index) *bad_index = i;
+            return rc;
+        }
+    }
+    const int sets = grl_jpeg_assign_tables(frames, n);
+    return sets > 0 ? GRL_OK : sets;
+}
+
 static uint32_t scan_extent(const GrlJpegFrame* frames, int n) {
     uint32_t nbytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -539,7 +556,7 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     uint16_t* lut = reinterpret_cast<uint16_t*>(wsb + lay.lut);
     uint8_t* clean = wsb + lay.clean;
     uint32_t* clean_len = reinterpret_cast<uint32_t*>(wsb + lay.clean_len);
-    hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets * 4, GJ_LUT_SIZE / 256), dim3(256), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
+    hipLaunchKernelGGL(jpeg_lut_kernel, dim3(sets, LUT_PER_SET / 256), dim3(256), 0, s, frames_dev, reps, identity ? 1 : 0, lut);
     const int lds_sets = identity ? 0 : sets;
     const size_t e_lds = 128 + 8192 + (size_t)lds_sets * LUT_PER_SET * sizeof(uint16_t);
     static const bool attr = [] {

@@ -7,7 +7,7 @@
 //   * bit reader: 64-bit accumulator, refilled 32 bits at a time from an ALIGNED dword when that dword holds no 0xFF byte
 //     (no stuffing, no marker: ~98 % of the dwords of a photographic scan), byte by byte otherwise (0xFF00 stuffing, fill
 //     bytes, RSTn / EOI, the unaligned head and the tail of a scan);
-//   * Huffman symbols through a 12-bit look-ahead table (one read: length << 8 | symbol; 0 = longer than 12 bits), the
+//   * Huffman symbols through a look-ahead table (12 bits for AC, 9 for DC; one read: length << 8 | symbol; 0 = longer), the
 //     rare long codes by the canonical maxcode / valoff search;
 //   * a block's coefficients are assembled in a small staging area (LDS on the device) and leave as whole 128-byte blocks.
 #pragma once
@@ -19,8 +19,16 @@
 #define GRL_HD
 #endif
 
-#define GJ_LUT_BITS 12
-#define GJ_LUT_SIZE (1 << GJ_LUT_BITS)
+// look-ahead bits: AC tables 12 (codes up to 16 bits, the long ones rare), DC tables 9 (baseline DC codes are <= 9 / 11 bits).
+// One table SET = [DC0 512][DC1 512][AC0 4096][AC1 4096] uint16 = 18 KiB: with the 8 KiB block stage the entropy workgroup
+// needs 26.3 KiB of LDS -- what is LEFT on a CU next to two 64 KiB GEMM workgroups (or one 128 KiB bf16 tile).  With 12-bit
+// DC tables (41 KiB) the decoder could not co-reside: a persistent GEMM launch then ran with workgroups missing and the
+// eval step fed from JPEG bytes took 20 ms instead of 14.5.
+#define GJ_AC_BITS 12
+#define GJ_DC_BITS 9
+#define GJ_LUT_PER_SET (2 * (1 << GJ_DC_BITS) + 2 * (1 << GJ_AC_BITS))
+GRL_HD static inline int gj_lut_bits(int t) { return t < 2 ? GJ_DC_BITS : GJ_AC_BITS; }
+GRL_HD static inline int gj_lut_offset(int t) { return t < 2 ? t << GJ_DC_BITS : (2 << GJ_DC_BITS) + ((t - 2) << GJ_AC_BITS); }
 
 struct GjBits {
     const uint8_t* base;      // the batch's byte buffer
@@ -161,11 +169,11 @@ GRL_HD static inline int gj_extend(int x, int s) { return x < (1 << (s - 1)) ? x
 
 // one Huffman symbol of table t (0, 1: DC; 2, 3: AC): look-ahead table first, canonical search for the codes it does not cover
 template <class R>
-GRL_HD static inline int gj_symbol(R& b, const uint16_t* lut /* this table's GJ_LUT_SIZE entries */, const GrlJpegFrame* fr, int t) {
+GRL_HD static inline int gj_symbol(R& b, const uint16_t* lut /* this table's look-ahead entries */, const GrlJpegFrame* fr, int t, const int bits) {
     const uint32_t look = (uint32_t)(b.acc >> (b.cnt - 16)) & 0xffffu;
-    const uint32_t e = lut[look >> (16 - GJ_LUT_BITS)];
+    const uint32_t e = lut[look >> (16 - bits)];
     if (e) { b.cnt -= (int)(e >> 8); return (int)(e & 255u); }
-    for (int l = GJ_LUT_BITS + 1; l <= 16; ++l) {
+    for (int l = bits + 1; l <= 16; ++l) {
         const int code = (int)(look >> (16 - l));
         if (code <= fr->maxcode[t][l]) {
             b.cnt -= l;
@@ -176,10 +184,11 @@ GRL_HD static inline int gj_symbol(R& b, const uint16_t* lut /* this table's GJ_
     return 0;
 }
 
-// the look-ahead entry for the GJ_LUT_BITS bits `p` of table t (jpeg_lut_kernel / the host test build the tables with this)
+// the look-ahead entry for the `bits` bits `p` of table t (jpeg_lut_kernel / the host test build the tables with this)
 GRL_HD static inline uint16_t gj_lut_entry(const GrlJpegFrame* fr, int t, int p) {
-    for (int l = 1; l <= GJ_LUT_BITS; ++l) {
-        const int code = p >> (GJ_LUT_BITS - l);
+    const int bits = gj_lut_bits(t);
+    for (int l = 1; l <= bits; ++l) {
+        const int code = p >> (bits - l);
         if (code <= fr->maxcode[t][l]) return (uint16_t)((l << 8) | fr->vals[t][(code + fr->valoff[t][l]) & 255]);
     }
     return 0;
@@ -197,7 +206,7 @@ struct GjScanGeo {
     int nb[3];                // blocks of each component per MCU (hs * vs)
 };
 
-// Decode one frame's scan: `lut` = 4 tables x GJ_LUT_SIZE entries [DC0, DC1, AC0, AC1] of this frame's table set,
+// Decode one frame's scan: `lut` = the GJ_LUT_PER_SET entries [DC0, DC1, AC0, AC1] of this frame's table set,
 // `nat` = the 64 (+16 guard) entry zigzag -> natural order table, `out` = this frame's coefficients [blocks][64] (every
 // block is written whole).  A block is assembled in `stage` -- coefficient i lives at stage[(i >> 1) * sstride + (i & 1)]:
 // on the device that is LDS, dword-interleaved over the wave's lanes (sstride = 128 int16: lane l's dword w sits in bank l
@@ -225,17 +234,17 @@ GRL_HD static inline void gj_decode_scan(R& b, const GrlJpegFrame* fr, const uin
         }
         for (int c = 0; c < g.ncomp; ++c) {
             const int td = tdc[c], ta = tac[c];
-            const uint16_t* const lut_dc = lut + td * GJ_LUT_SIZE;
-            const uint16_t* const lut_ac = lut + ta * GJ_LUT_SIZE;
+            const uint16_t* const lut_dc = lut + gj_lut_offset(td);
+            const uint16_t* const lut_ac = lut + gj_lut_offset(ta);
             for (int bi = 0; bi < g.nb[c]; ++bi, ++blk) {
                 gj_fill(b);
-                int s = gj_symbol(b, lut_dc, fr, td) & 15;
+                int s = gj_symbol(b, lut_dc, fr, td, GJ_DC_BITS) & 15;
                 if (s) s = gj_extend(gj_get_bits(b, s), s);
                 pred[c] += s;
                 *reinterpret_cast<gj_i16a*>(stage) = (int16_t)pred[c];
                 for (int k = 1; k < 64; ++k) {
                     gj_fill(b);
-                    const int rs = gj_symbol(b, lut_ac, fr, ta);
+                    const int rs = gj_symbol(b, lut_ac, fr, ta, GJ_AC_BITS);
                     const int r = rs >> 4, sz = rs & 15;
                     if (sz) {
                         k += r;

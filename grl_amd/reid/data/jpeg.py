@@ -41,21 +41,18 @@ class JpegBatch(object):
     def pack(self):
         """-> (uint8 host tensor of the concatenated streams padded to a multiple of 8 bytes, (GrlJpegFrame * n) parsed)"""
         lib = _lib.load()
-        total = sum(len(s) for s in self.streams)
-        buf = np.zeros((total + 15) // 8 * 8, np.uint8)
-        frames = (GrlJpegFrame * len(self.streams))()
-        off = 0
-        base = buf.ctypes.data
-        for i, s in enumerate(self.streams):
-            n = len(s)
-            buf[off:off + n] = np.frombuffer(s, np.uint8)
-            rc = lib.grl_jpeg_parse(base + off, n, off, C.byref(frames[i]))
-            if rc:
-                msg = lib.grl_last_error().decode('utf-8', 'replace')
-                raise (JpegUnsupported if rc == _lib.GRL_EUNSUPPORTED else GrlHipError)('frame %d: %s' % (i, msg))
-            off += n
-        if lib.grl_jpeg_assign_tables(frames, len(self.streams)) <= 0:
-            raise GrlHipError('grl_jpeg_assign_tables: %s' % lib.grl_last_error().decode('utf-8', 'replace'))
+        n = len(self.streams)
+        raw = b''.join(self.streams)
+        buf = np.zeros((len(raw) + 15) // 8 * 8, np.uint8)
+        buf[:len(raw)] = np.frombuffer(raw, np.uint8)
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum([len(s) for s in self.streams], out=offs[1:])
+        frames = (GrlJpegFrame * n)()
+        bad = C.c_int(-1)
+        rc = lib.grl_jpeg_parse_batch(buf.ctypes.data, offs.ctypes.data, n, frames, C.addressof(bad))   # headers + table sets: one call
+        if rc:
+            msg = lib.grl_last_error().decode('utf-8', 'replace')
+            raise (JpegUnsupported if rc == _lib.GRL_EUNSUPPORTED else GrlHipError)('frame %d: %s' % (bad.value, msg))
         return torch.from_numpy(buf), frames
 
 

@@ -684,8 +684,12 @@ int grl_jpeg_parse(const uint8_t* data, int64_t len, int64_t base_off, GrlJpegFr
  * look-ahead tables in LDS (frames of one encoder share ONE set); beyond that every frame keeps its own.  Returns
  * the number of sets (> 0) or a negative GRL_E* code.  Call after grl_jpeg_parse, before the descriptors are copied. */
 int grl_jpeg_assign_tables(GrlJpegFrame* frames, int n);
-/* bytes of device scratch grl_jpeg_decode_batch needs for n frames of frame 0's geometry (coefficients + planes) */
-int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frame0, int n);
+/* HOST function: grl_jpeg_parse for the n streams of one batch buffer (stream i = buf[offsets[i] .. offsets[i+1])), then
+ * grl_jpeg_assign_tables.  On failure *bad_index is the offending frame and the return value its code. */
+int grl_jpeg_parse_batch(const uint8_t* buf, const int64_t* offsets, int n, GrlJpegFrame* frames, int* bad_index);
+/* bytes of device scratch grl_jpeg_decode_batch needs for the n parsed frames of a batch (coefficients, planes,
+ * look-ahead tables, unstuffed streams) */
+int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frames_host, int n);
 /* n frames of ONE geometry (width, height, components, sampling: as frames[0]; frames_host is checked) ->
  * out uint8 [n][3][height][width] (planar RGB: the layout the clip tensors [B][T][3][H][W] have).
  * bytes: the concatenated streams (device); frames_dev: the n parsed descriptors (device copy of frames_host). */

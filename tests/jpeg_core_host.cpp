@@ -13,7 +13,7 @@ static const uint8_t kNat[80] = {
 
 static void setup(const GrlJpegFrame* fr, uint16_t* lut, GjScanGeo& g) {
     for (int t = 0; t < 4; ++t)
-        for (int p = 0; p < GJ_LUT_SIZE; ++p) lut[t * GJ_LUT_SIZE + p] = gj_lut_entry(fr, t, p);
+        for (int p = 0; p < (1 << gj_lut_bits(t)); ++p) lut[gj_lut_offset(t) + p] = gj_lut_entry(fr, t, p);
     const int mcux = (fr->width + 8 * fr->hmax - 1) / (8 * fr->hmax), mcuy = (fr->height + 8 * fr->vmax - 1) / (8 * fr->vmax);
     g.mcus = mcux * mcuy;
     g.ncomp = fr->ncomp;
@@ -23,7 +23,7 @@ static void setup(const GrlJpegFrame* fr, uint16_t* lut, GjScanGeo& g) {
 // the GENERAL reader (stuffing / markers / restart intervals handled while decoding).
 // buf: the batch byte buffer (nbytes long), fr: the parsed frame, out: int16 [blocks][64]
 extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
-    static uint16_t lut[4 * GJ_LUT_SIZE];
+    static uint16_t lut[GJ_LUT_PER_SET];
     GjScanGeo g;
     setup(fr, lut, g);
     alignas(16) int16_t stage[64];
@@ -36,7 +36,7 @@ extern "C" int gj_host_decode(const uint8_t* buf, uint32_t nbytes, const GrlJpeg
 // the CLEAN reader behind the unstuffing pre-pass (here a serial loop over the same per-byte rule the kernel applies).
 // Returns the number of data bytes the pre-pass kept.
 extern "C" int gj_host_decode_clean(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out) {
-    static uint16_t lut[4 * GJ_LUT_SIZE];
+    static uint16_t lut[GJ_LUT_PER_SET];
     GjScanGeo g;
     setup(fr, lut, g);
     const uint8_t* src = buf + fr->scan_off;

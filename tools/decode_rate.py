@@ -77,7 +77,7 @@ def device_rates(frames, batches=(128, 512, 2048)):
         host, fr = JpegBatch(streams, (n,)).pack()
         dbytes = host.cuda()
         dfr = torch.frombuffer(bytearray(bytes(fr)), dtype=torch.uint8).cuda()
-        need = int(lib.grl_jpeg_workspace_bytes(C.byref(fr[0]), n))
+        need = int(lib.grl_jpeg_workspace_bytes(fr, n))
         ws = torch.empty(need, dtype=torch.uint8, device='cuda')
         o = torch.empty((n, 3, int(fr[0].height), int(fr[0].width)), dtype=torch.uint8, device='cuda')
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

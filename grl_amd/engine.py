@@ -1119,7 +1119,13 @@ class DevicePrefetcher(object):
     def _stream(self):
         want = self.depth or 1
         while len(self.streams) < want:
-            self.streams.append(torch.cuda.Stream(self.dev))
+            # HIGH priority: not to jump the queue, but because the runtime gives priority levels their own hardware queues.
+            # Streams of one level share GPU_MAX_HW_QUEUES (4) in-order hardware queues; the eval step already uses the
+            # default stream + the TRL side streams, so a 10 ms decode kernel on a normal-priority prefetch stream landed in
+            # front of compute kernels in the SAME hardware queue: decode and compute ran back to back (24.8 ms per step =
+            # 14.5 + 10.3; 18.3 with GPU_MAX_HW_QUEUES=8; tools/jpegfeed_ab.sh).
+            pr = int(os.environ.get('GRL_PREFETCH_PRIORITY', '-1'))
+            self.streams.append(torch.cuda.Stream(self.dev, priority=pr))
         self._k += 1
         return self.streams[self._k % want]
 

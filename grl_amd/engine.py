@@ -1112,6 +1112,7 @@ class DevicePrefetcher(object):
         self.dev = torch.device(device)
         self.depth = depth
         self.streams = []
+        self._compressed = False
         self.queue = collections.deque()
         self._k = 0
         self._fill()
@@ -1124,7 +1125,8 @@ class DevicePrefetcher(object):
             # default stream + the TRL side streams, so a 10 ms decode kernel on a normal-priority prefetch stream landed in
             # front of compute kernels in the SAME hardware queue: decode and compute ran back to back (24.8 ms per step =
             # 14.5 + 10.3; 18.3 with GPU_MAX_HW_QUEUES=8; tools/jpegfeed_ab.sh).
-            pr = int(os.environ.get('GRL_PREFETCH_PRIORITY', '-1'))
+            # (plain host -> device copies stay at normal priority: at high priority they cost the step 3 %)
+            pr = int(os.environ.get('GRL_PREFETCH_PRIORITY', '-1')) if self._compressed else 0
             self.streams.append(torch.cuda.Stream(self.dev, priority=pr))
         self._k += 1
         return self.streams[self._k % want]
@@ -1145,6 +1147,8 @@ class DevicePrefetcher(object):
             # into the uint8 clip tensor on a prefetch stream, next to the current batch's compute (video_loader.py:124-141)
             if self.depth is None:
                 self.depth = 2
+            if not self._compressed:
+                self._compressed, self.streams = True, []
             with torch.cuda.stream(self._stream()) as _:
                 d = decode_jpeg_batch(imgs, self.dev)
                 ev = torch.cuda.Event()

@@ -6,15 +6,6 @@
 int grl_fail(int code, const char* fmt, ...);          // sets the thread-local message
 int grl_check_launch(const char* what);                 // hipGetLastError -> GRL_ELAUNCH
 
-// The persistent GEMM kernels raise their waves' issue priority (s_setprio 2).  Round 6: a wave of the JPEG entropy decoder
-// co-resident on a CU (prefetch stream, ~120 plain VALU instructions per 1000 cycles for 10 ms) slows the GEMM wave it
-// shares a SIMD with -- next to v_mfma_f32_32x32x2_f32 every VALU instruction costs ~4 matrix-pipe cycles -- and a
-// persistent launch waits for its slowest workgroup: the eval step fed from JPEG bytes took 18.4 ms instead of 14.5.
-// With the priority the decoder only gets the issue slots the GEMM wave leaves.  -DGRL_GEMM_SETPRIO=0: A/B.
-#ifndef GRL_GEMM_SETPRIO
-#define GRL_GEMM_SETPRIO 1
-#endif
-
 static inline int grl_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // wave64 sum (all lanes receive the total)

@@ -37,9 +37,6 @@ namespace {
 // CH: channels of y per LDS weight chunk, NW: waves per workgroup (32 pixels each), PD: 32-channel blocks of residual in flight
 template <int P, int C4, int PN, int CH, int NW, int PD, int KO = 0>     // KO: timing knock-outs (1: no MFMA, 2: no residual / store traffic)
 __global__ __launch_bounds__(NW * 64) void bneck_tail_f32_kernel(const GrlBneckTailF32 p, const int num_tiles) {
-#if GRL_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(2);      // wave priority over co-resident low-rate kernels (round 6: the JPEG entropy decoder) -- see common.h
-#endif
     constexpr int NT = NW * 64;
     constexpr int TILE_PX = NW * 32;
     constexpr bool CHAIN = PN > 0;

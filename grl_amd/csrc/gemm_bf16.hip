@@ -67,9 +67,6 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 template <bool CONV, bool STATS = false, bool SQD = false, bool RES = false, bool GBIAS = false, int BNZ = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const GrlGemm p, const int tiles_n,
                                                                const int num_tiles) {
-#if GRL_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(2);      // wave priority over co-resident low-rate kernels (round 6: the JPEG entropy decoder) -- see common.h
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -100,9 +100,6 @@ struct RowInfo {          // per staged A row: where it comes from
 template <int BM, int BN, bool CONV, int MATH, bool SEG, bool DMA = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GrlGemm p_in, const int tiles_n,
                                                            const int num_tiles, const int vec_epi) {
-#if GRL_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(2);      // wave priority over co-resident low-rate kernels (round 6: the JPEG entropy decoder) -- see common.h
-#endif
     GrlGemm p_seg;
     if constexpr (SPLITK) {
         p_seg = p_in;

@@ -154,3 +154,26 @@ def test_device_decode_with_per_frame_huffman_tables():
     got = decode_jpeg_batch(mixed, 'cuda').cpu().numpy()
     for i, s in enumerate(mixed):
         assert np.array_equal(got[i], _pil_chw(s)), i
+
+
+def test_device_decode_of_damaged_streams_equals_the_oracle():
+    """Truncated / corrupted / marker-riddled scans (tests/test_jpeg_cpu.py:_damaged_streams): no hang, no crash, and the
+    pixels the oracle produces for the same bytes (zero bits past the data, as libjpeg feeds them)."""
+    from test_jpeg_cpu import _damaged_streams
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import decode_jpeg_batch
+    from oracle.ref_c import jpeg_decode
+    n = 0
+    for s in _damaged_streams(np.random.default_rng(9), 60):
+        try:
+            want = jpeg_decode(s)
+        except ValueError:
+            continue
+        try:
+            got = decode_jpeg_batch([s], 'cuda')[0].cpu().numpy()
+        except _lib.GrlHipError:
+            continue                                  # (a header the product parser refuses: fine, loudly)
+        assert np.array_equal(got, want.transpose(2, 0, 1)), len(s)
+        n += 1
+    torch.cuda.synchronize()
+    assert n > 40

@@ -187,3 +187,57 @@ def test_table_sets_are_shared_or_per_frame():
     many = [_encode(_frame(32, 32, rng), quality=70, optimize=True) for _ in range(12)]
     _, fr = JpegBatch(many, (12,)).pack()
     assert [f.tabset for f in fr] == list(range(12))
+
+
+def _damaged_streams(rng, count):
+    """truncated inside the scan / bytes overwritten / a stray 0xFF xx inserted: what a decoder must survive"""
+    from grl_amd.reid.data.jpeg import JpegBatch
+    out = []
+    for it in range(count):
+        h, w = int(rng.integers(8, 80)), int(rng.integers(8, 80))
+        s = bytearray(_encode(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), quality=int(rng.integers(20, 100)),
+                              subsampling=int(rng.integers(0, 3))))
+        so = JpegBatch([bytes(s)], (1,)).pack()[1][0].scan_off
+        kind = it % 3
+        if kind == 0:
+            s = s[:so + int(rng.integers(0, len(s) - so))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                s[so + int(rng.integers(0, len(s) - so - 2))] = int(rng.integers(0, 256))
+        else:
+            p = so + int(rng.integers(0, len(s) - so - 2))
+            s[p:p] = bytes([0xFF, int(rng.choice([0x00, 0xFF, 0xD0, 0xD9, 0x55]))])
+        out.append(bytes(s))
+    return out
+
+
+def test_damaged_streams_decode_the_same_way_everywhere(tmp_path):
+    """Truncated, corrupted and marker-riddled scans: the device core (both readers, CPU build) leaves the coefficients
+    the oracle leaves -- zero bits past the data, symbol 0 for an impossible code, decoding stops feeding at a marker
+    (libjpeg's documented behaviour for damaged data).  No crash, no read outside the scan (the build in /tmp is also run
+    under ASan / UBSan by hand; here it is the plain build)."""
+    import os
+    import subprocess
+    pytest.importorskip('PIL')
+    from grl_amd.reid.data.jpeg import JpegBatch
+    from oracle.ref_c import jpeg_coefficients
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tmp_path, 'libgjhost.so')
+    subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', os.path.join(root, 'tests', 'jpeg_core_host.cpp'), '-o', so])
+    lib = C.CDLL(so)
+    for fn in (lib.gj_host_decode, lib.gj_host_decode_clean):
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    n = 0
+    for s in _damaged_streams(np.random.default_rng(5), 150):
+        try:
+            ref = jpeg_coefficients(s)
+        except ValueError:
+            continue
+        host, fr = JpegBatch([s], (1,)).pack()
+        buf = np.ascontiguousarray(np.concatenate([host.numpy(), np.zeros(8, np.uint8)]))
+        for fn in (lib.gj_host_decode, lib.gj_host_decode_clean):
+            out = np.full_like(ref, 7)
+            fn(buf.ctypes.data, len(buf) - 8, C.addressof(fr[0]), out.ctypes.data)
+            assert np.array_equal(out, ref), len(s)
+            n += 1
+    assert n > 200

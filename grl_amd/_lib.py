@@ -99,6 +99,12 @@ _SIGNATURES = {
     'grl_slab_sum': ([_fp, C.c_int, _i64, C.c_int, _fp, C.c_int, _fp], C.c_int),
     'grl_bn_stats_finalize': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
                                _fp, _fp, _fp, _fp, _fp, _fp], C.c_int),
+    'grl_bn_finalize_apply_takes': ([C.c_int, C.c_int], C.c_int),
+    'grl_bn_finalize_apply_mode': ([C.c_int], C.c_int),
+    'grl_bn_finalize_apply': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp,
+                               _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp], C.c_int),
+    'grl_bn_finalize_apply_bf16': ([_fp, C.c_int, C.c_int, _i64, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp,
+                                    _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_bn_apply': ([_fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp], C.c_int),
     'grl_bn_apply_centered': ([_fp, _fp, _fp, _fp, _fp, _fp, _i64, C.c_int, C.c_int, _fp, _fp], C.c_int),
     'grl_bn_bwd': ([_fp] * 11 + [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp], C.c_int),

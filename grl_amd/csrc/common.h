@@ -39,3 +39,11 @@ int grl_gemm_validate(const GrlGemm& d);               // gemm_f32.hip: the argu
 // train.hip: BatchNorm-backward finalize over an fp32 partial slab (shared with the bf16-storage kernels of train_bf16.hip)
 int grl_launch_bn_bwd_finalize(const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, float* coef,
                                hipStream_t s);
+
+// train_bnfuse.hip: BatchNorm finalize inside the apply pass (rows <= 64 slab rows, C % 64 == 0): the backward entry points of
+// train.hip / train_bf16.hip launch it instead of bn_bwd_finalize + bn_bwd_apply
+bool grl_bn_finapply_takes(int rows, int C);
+int grl_launch_bn_bwd_finapply(int b16, const float* slab, int rows, int C, double count, float* dgamma, float* dbeta, const void* dy,
+                               const void* z, const void* act, const float* mean, const float* invstd, const float* gamma, void* dz,
+                               int M, void* gres, int gres_accumulate, const float* mscale, const float* mbeta, const uint8_t* bits,
+                               hipStream_t s);

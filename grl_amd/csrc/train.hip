@@ -1766,6 +1766,13 @@ extern "C" int grl_bn_bwd(const float* dy, const float* z, const float* act, con
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, dy, z, act, mean,
                            invstd, slab_ws, M, C, mask_scale, mask_beta, gout, relu_bits);
+    if (grl_bn_finapply_takes(rows, C)) {        // round 6: finalize inside the apply pass (train_bnfuse.hip), bit-identical
+        if (inplace)
+            return grl_launch_bn_bwd_finapply(0, slab_ws, rows, C, (double)M, dgamma, dbeta, dy, z, nullptr, mean, invstd, gamma, dz, M,
+                                              nullptr, 0, nullptr, nullptr, nullptr, s);
+        return grl_launch_bn_bwd_finapply(0, slab_ws, rows, C, (double)M, dgamma, dbeta, dy, z, act, mean, invstd, gamma, dz, M, gres,
+                                          gres_accumulate, mask_scale, mask_beta, relu_bits, s);
+    }
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total4 = (int64_t)M * C / 4;
     if (inplace)
@@ -1783,10 +1790,13 @@ extern "C" int grl_bn_bwd_finish(const float* g, const float* z, const float* me
                                  int C, float* gres, int gres_accumulate, void* stream) {
     GRL_REQUIRE(g && z && mean && invstd && dz && slab && coef_ws && rows > 0 && M > 0 && C % 4 == 0, "bn_bwd_finish: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
-    const int64_t total4 = (int64_t)M * C / 4;
     // g is masked already: no activation, no mask recomputation; gres == g (the residual adopts the buffer) needs nothing
     float* const gres2 = gres == g ? nullptr : gres;
+    if (grl_bn_finapply_takes(rows, C))
+        return grl_launch_bn_bwd_finapply(0, slab, rows, C, (double)M, dgamma, dbeta, g, z, nullptr, mean, invstd, gamma, dz, M, gres2,
+                                          gres2 ? gres_accumulate : 0, nullptr, nullptr, nullptr, s);
+    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
+    const int64_t total4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, g, z, (const float*)nullptr, mean, invstd,
                        gamma, coef_ws, dz, C, total4, gres2, gres2 ? gres_accumulate : 0, (const float*)nullptr,
                        (const float*)nullptr, (const uint8_t*)nullptr);

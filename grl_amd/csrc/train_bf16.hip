@@ -616,6 +616,13 @@ extern "C" int grl_bn_bwd_bf16(const void* dy, const void* z, const void* act, c
     hipLaunchKernelGGL(bn_bwd_reduce_b16_kernel, dim3(grl_ceil_div(C, 256), rows), dim3(256), 0, s, CB16(dy), CB16(z),
                        CB16(act), mean, invstd, slab_ws, M, C, mask_scale, mask_beta, lpr_for(C),
                        inplace ? const_cast<__bf16*>(CB16(dy)) : (__bf16*)nullptr, relu_bits);
+    if (grl_bn_finapply_takes(rows, C)) {        // round 6: finalize inside the apply pass (train_bnfuse.hip), bit-identical
+        if (inplace)
+            return grl_launch_bn_bwd_finapply(1, slab_ws, rows, C, (double)M, dgamma, dbeta, dy, z, nullptr, mean, invstd, gamma, dz, M,
+                                              nullptr, 0, nullptr, nullptr, nullptr, s);
+        return grl_launch_bn_bwd_finapply(1, slab_ws, rows, C, (double)M, dgamma, dbeta, dy, z, act, mean, invstd, gamma, dz, M, gres,
+                                          gres_accumulate, mask_scale, mask_beta, relu_bits, s);
+    }
     if (int e = grl_launch_bn_bwd_finalize(slab_ws, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
     const int64_t total8 = (int64_t)M * C / 8;
     if (inplace)
@@ -637,10 +644,13 @@ extern "C" int grl_bn_bwd_finish_bf16(const void* g, const void* z, const float*
     GRL_REQUIRE(g && z && mean && invstd && dz && slab && coef_ws && rows > 0 && M > 0 && C % 8 == 0, "bn_bwd_finish_bf16: bad args");
     GRL_REQUIRE(al16(g) && al16(z) && al16(dz) && al16(gres), "bn_bwd_finish_bf16: 16-byte aligned tensors");
     hipStream_t s = (hipStream_t)stream;
-    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
-    const int64_t total8 = (int64_t)M * C / 8;
     // g is masked already: no activation, no mask recomputation; gres == g (the residual adopts the buffer) needs nothing
     __bf16* const gres2 = gres == g ? nullptr : B16(gres);
+    if (grl_bn_finapply_takes(rows, C))
+        return grl_launch_bn_bwd_finapply(1, slab, rows, C, (double)M, dgamma, dbeta, g, z, nullptr, mean, invstd, gamma, dz, M, gres2,
+                                          gres2 ? gres_accumulate : 0, nullptr, nullptr, nullptr, s);
+    if (int e = grl_launch_bn_bwd_finalize(slab, rows, C, (double)M, dgamma, dbeta, coef_ws, s)) return e;
+    const int64_t total8 = (int64_t)M * C / 8;
     hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3(grid_for(total8)), dim3(256), 0, s, CB16(g), CB16(z), (const __bf16*)nullptr,
                        mean, invstd, gamma, coef_ws, B16(dz), C, total8, gres2, gres2 ? gres_accumulate : 0, (const float*)nullptr,
                        (const float*)nullptr, (const uint8_t*)nullptr);

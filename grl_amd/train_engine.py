@@ -564,6 +564,42 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
+BN_FINAPPLY = os.environ.get('GRL_BN_FINAPPLY', '1') != '0'       # A/B and tests (the C side reads the same variable for the backward)
+
+
+_finapply_state = [None]
+
+
+def _finapply_on():
+    """the library's switch (GRL_BN_FINAPPLY / grl_bn_finalize_apply_mode), read once; set_bn_finapply() changes both sides"""
+    if _finapply_state[0] is None:
+        _finapply_state[0] = bool(_lib.load().grl_bn_finalize_apply_mode(-1))
+    return _finapply_state[0]
+
+
+def set_bn_finapply(on):
+    """tests / A-B: switch the fused BatchNorm finalize + apply form (forward here, backward inside the library); returns
+    the previous setting"""
+    was = bool(_lib.load().grl_bn_finalize_apply_mode(1 if on else 0))
+    _finapply_state[0] = bool(on)
+    return was
+
+
+def bn_finalize_apply(slab, rows, Cc, count, bn, dev, z, res, y, relu, bits=None):
+    """bn_finalize + bn_apply as ONE launch (grl_bn_finalize_apply: every workgroup of the apply pass reduces the slab columns
+    of its own 64 channels) -- for rows <= 64 slab rows and Cc % 64 == 0, bit-identical to the two calls."""
+    st = _BNState()
+    buf = torch.empty((4, Cc), dtype=torch.float32, device=dev)
+    base, row = buf.data_ptr(), Cc * 4
+    st.buf = buf
+    st.mean, st.invstd, st.scale, st.shift = base, base + row, base + 2 * row, base + 3 * row
+    st.beta = bn.bias
+    _call(_k('grl_bn_finalize_apply', z), ptr(slab), rows, Cc, count, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+          ptr(bn.running_var), ptr(bn.num_batches_tracked), C.c_float(bn.momentum), C.c_float(bn.eps), st.mean, st.invstd,
+          st.scale, st.shift, None, ptr(z), ptr(res), ptr(y), count, 1 if relu else 0, ptr(bits))
+    return st
+
+
 def bn_backward(dy, z, act, st, gamma, dgamma, dbeta, M, Cc, gres=None, gres_acc=0, mask_from_z=False, bits=None,
                 out=None):
     """``gres``: gradient buffer of the residual input (gets / accumulates the masked dy in the
@@ -656,14 +692,18 @@ def conv_bn(tp, x, n_img, H, W, conv, bn, relu, res=None, gbias=None, rpg=0, kco
     z = _newl((M, N), x)
     _, slab = gemm(x, wf, z, M, N, K, ldw=ldw or wf.shape[1], gbias=gbias, rows_per_group=rpg,
                    stats=True, conv=geom)
-    st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
     a = _newl((M, N), x) if out is None else out
     # y = relu(bn(z) + res): the backward needs the mask (y > 0); recorded as one bit per output here, it is read
     # back instead of the whole activation (1/16 of the bytes of the widest BatchNorms of the step)
     bits = None
     if relu and res is not None and RELU_BITS:
         bits = torch.empty(M * N // (8 if a.dtype == BF16 else 4), dtype=torch.uint8, device=tp.dev)
-    bn_apply(z, st, res, a, M, N, relu, bits=bits)
+    if BN_FINAPPLY and slab.shape[0] <= 64 and N % 64 == 0 and _finapply_on():
+        # small slab (the TRL memo bottleneck: M = B * 128 pixel rows): the finalize runs inside the apply launch
+        st = bn_finalize_apply(slab, slab.shape[0], N, M, bn, tp.dev, z, res, a, relu, bits=bits)
+    else:
+        st = bn_finalize(slab, slab.shape[0], N, M, bn, tp.dev)
+        bn_apply(z, st, res, a, M, N, relu, bits=bits)
     # (fused BatchNorm-backward reduce, GrlGemm.bn_z: this op is one consumer of x and of res, and `a` gets a record
     # that the data-gradient GEMM completing grad(a) can use)
     _bn_use(tp, x)

@@ -329,6 +329,22 @@ int grl_bn_stats_finalize(const float* slab, int rows, int C, int64_t count, con
 /* step 2: y = relu?(z*scale + shift + res) */
 int grl_bn_apply(const float* z, const float* scale, const float* shift, const float* res,
                  float* y, int64_t M, int C, int relu, void* stream);
+/* BatchNorm finalize INSIDE the apply pass (round 6; train_bnfuse.hip): grl_bn_stats_finalize + grl_bn_apply_centered as ONE
+ * launch for layers whose statistics slab is small (rows <= 64, i.e. M <= 8192 pixel rows -- the TRL memo bottleneck of
+ * grl_model.py:93-128,186-205 --, C % 64 == 0): every workgroup of the apply pass reduces the slab columns of its own 64
+ * channels, in the order of grl_bn_stats_finalize, so mean / invstd / scale / shift / running statistics and y are
+ * bit-identical to the two-launch form.  Arguments: those of the two calls.  The backward entry points (grl_bn_bwd*,
+ * grl_bn_bwd_finish*) take the same form by themselves when the slab allows it.  GRL_BN_FINAPPLY=0: never. */
+int grl_bn_finalize_apply_takes(int rows, int C);      /* 1 if the fused form covers the layer */
+int grl_bn_finalize_apply_mode(int on);                 /* test hook: 0 / 1 = off / on for the process, -1 = query; returns the previous setting */
+int grl_bn_finalize_apply(const float* slab, int rows, int C, int64_t count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                          float* mean, float* invstd, float* scale, float* shift, const float* pivot, const float* z,
+                          const float* res, float* y, int M, int relu, uint8_t* relu_bits, void* stream);
+int grl_bn_finalize_apply_bf16(const float* slab, int rows, int C, int64_t count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                               float* mean, float* invstd, float* scale, float* shift, const float* pivot, const void* z,
+                               const void* res, void* y, int M, int relu, uint8_t* relu_bits, void* stream);
 /* step 2, train-mode form: y = relu?((z - mean)*scale + beta + res), centred before the multiply as
  * torch's training kernel does (F.batch_norm(training=True); resnets1.py:76-91, grl_model.py:222-226):
  * exact where the folded form cancels (BatchNorm1d over a few similar rows).  beta may be NULL. */

@@ -548,3 +548,43 @@ def test_statistics_gemm_on_the_wide_tile_keeps_the_small_tiles_bits(M, N, K, co
         tol = {'f32': 1e-5, 'bf16x3': 1e-4, 'bf16': 2e-2}[math]
         assert float((s[0] - ref.sum(0)).norm() / ref.sum(0).norm()) < tol
         assert float((s[1] - (ref * ref).sum(0)).norm() / (ref * ref).sum(0).norm()) < tol
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16s'])
+def test_bn_finalize_inside_the_apply_pass_is_bit_identical(math):
+    """Round 6 (train_bnfuse.hip): for BatchNorms with <= 64 statistics-slab rows the finalize runs inside the apply launch
+    (forward: grl_bn_finalize_apply; backward: inside grl_bn_bwd* / grl_bn_bwd_finish*), every workgroup reducing the slab
+    columns of its own 64 channels in slab_totals' order.  A whole train step (4 x 4 clips: layers 2-4, GCE and TRL are all
+    eligible, with residuals, mask bits, masks recomputed from z, fused GEMM-epilogue reduces) must give the SAME BITS with
+    the form on and off: outputs, BatchNorm running statistics, every parameter gradient."""
+    from grl_amd import train_engine as TE
+    from grl_amd.reid import models
+    from grl_amd.synthetic import synth_clips_structured, synth_state_dict
+    import contextlib, io
+
+    def run(on):
+        with contextlib.redirect_stdout(io.StringIO()):
+            cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
+        cnn.load_state_dict(synth_state_dict(cnn, seed=0, profile='conditioned'))
+        cnn = cnn.cuda().train()
+        was = TE.set_bn_finapply(on)
+        old = TE.set_math(math)
+        try:
+            xu, xc = cnn(synth_clips_structured(4, 4, seed=3).cuda())
+            g = torch.Generator(device='cpu').manual_seed(1)
+            (xu * torch.randn(xu.shape, generator=g).cuda()).sum().add((xc * torch.randn(xc.shape, generator=g).cuda()).sum()).backward()
+            torch.cuda.synchronize()
+        finally:
+            TE.set_math(old)
+            TE.set_bn_finapply(was)
+        grads = {n: p.grad.clone() for n, p in cnn.named_parameters() if p.grad is not None}
+        stats = {n: b.clone() for n, b in cnn.named_buffers()}
+        return xu.detach().clone(), xc.detach().clone(), grads, stats
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 150
+    bad = [n for n in a[2] if not torch.equal(a[2][n], b[2][n])]
+    assert not bad, bad[:5]
+    bad = [n for n in a[3] if not torch.equal(a[3][n], b[3][n])]
+    assert not bad, bad[:5]

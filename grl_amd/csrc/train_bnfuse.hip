@@ -218,7 +218,11 @@ inline int rows_per_wg_for(int M, int C, int rpp) {
     return per < rpp ? rpp : per;
 }
 
-bool g_finapply_on = [] { const char* e = getenv("GRL_BN_FINAPPLY"); return !e || atoi(e) != 0; }();      // (grl_bn_finalize_apply_mode: tests)
+// OFF by default: measured slower than the separate launches (same box, three pairs: fp32 52.74 -> 53.6-53.85 ms, bf16s 17.52 ->
+// 17.9-18.0): the strip-structured pass streams worse than the flat one (138-148 VGPRs for the fp64 trees, 33 KiB of LDS, a
+// 3-5 us prologue in each of ~1000 workgroups) and that costs more than the 6 us finalize launch it removes -- the same
+// verdict as the gated form of round 3, for another reason.  GRL_BN_FINAPPLY=1 / grl_bn_finalize_apply_mode(1) keep it testable.
+bool g_finapply_on = [] { const char* e = getenv("GRL_BN_FINAPPLY"); return e && atoi(e) != 0; }();
 
 }  // namespace
 

@@ -564,7 +564,7 @@ def bn_finalize(slab, rows, Cc, count, bn, dev, gamma=None, beta=None, rm=None, 
     return st
 
 
-BN_FINAPPLY = os.environ.get('GRL_BN_FINAPPLY', '1') != '0'       # A/B and tests (the C side reads the same variable for the backward)
+BN_FINAPPLY = True       # the library's switch decides (GRL_BN_FINAPPLY=1 / set_bn_finapply: off by default -- measured slower)
 
 
 _finapply_state = [None]

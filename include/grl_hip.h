@@ -334,7 +334,8 @@ int grl_bn_apply(const float* z, const float* scale, const float* shift, const f
  * grl_model.py:93-128,186-205 --, C % 64 == 0): every workgroup of the apply pass reduces the slab columns of its own 64
  * channels, in the order of grl_bn_stats_finalize, so mean / invstd / scale / shift / running statistics and y are
  * bit-identical to the two-launch form.  Arguments: those of the two calls.  The backward entry points (grl_bn_bwd*,
- * grl_bn_bwd_finish*) take the same form by themselves when the slab allows it.  GRL_BN_FINAPPLY=0: never. */
+ * grl_bn_bwd_finish*) take the same form by themselves when the slab allows it.  OFF unless GRL_BN_FINAPPLY=1 (or
+ * grl_bn_finalize_apply_mode(1)): measured 0.4-0.9 ms per step slower than the separate launches (EXPERIMENTS.md round 6). */
 int grl_bn_finalize_apply_takes(int rows, int C);      /* 1 if the fused form covers the layer */
 int grl_bn_finalize_apply_mode(int on);                 /* test hook: 0 / 1 = off / on for the process, -1 = query; returns the previous setting */
 int grl_bn_finalize_apply(const float* slab, int rows, int C, int64_t count, const float* gamma, const float* beta,

@@ -88,7 +88,7 @@ class _PinnedRing(object):
 _rings = {}
 
 
-def decode_jpeg_batch(batch, device, stream=None):
+def decode_jpeg_batch(batch, device):
     """JpegBatch (or a list of bytes) -> uint8 tensor ``batch.shape + (3, H, W)`` on ``device`` (planar RGB, what
     np.asarray(Image.open(f).convert('RGB')).transpose(2, 0, 1) holds for every frame).  All frames must share one
     geometry (size, components, sampling).  Work is enqueued on torch's current stream."""

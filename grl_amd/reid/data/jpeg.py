@@ -38,6 +38,21 @@ class JpegBatch(object):
         if n != len(self.streams):
             raise ValueError('JpegBatch: %d streams for shape %s' % (len(self.streams), self.shape))
 
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        """A slice of the FIRST dimension (clips): what dist.PairShardedBatches takes from a global batch -- with compressed
+        frames a rank then uploads and decodes only its own pair shard."""
+        if not isinstance(key, slice):
+            raise TypeError('JpegBatch supports slicing along the clip dimension only')
+        per = 1
+        for d in self.shape[1:]:
+            per *= d
+        idx = range(self.shape[0])[key]
+        streams = [s for i in idx for s in self.streams[i * per:(i + 1) * per]]
+        return JpegBatch(streams, (len(idx),) + self.shape[1:])
+
     def pack(self, into=None):
         """-> (uint8 host tensor of the concatenated streams padded to a multiple of 8 bytes, (GrlJpegFrame * n) parsed).
         ``into``: a (pinned) uint8 host tensor to build the byte buffer in (a view of it is returned)."""

@@ -84,6 +84,10 @@ def test_device_decode_batches_across_workgroups_and_grey():
         assert np.array_equal(flat[i], _pil_chw(streams[i])), i
     again = decode_jpeg_batch(JpegBatch(streams, (65, 2)), 'cuda')
     assert torch.equal(got, again)
+    rgb = [_encode(_frame(48, 40, rng), keep_rgb=True, quality=q) for q in (60, 92)]          # Adobe transform 0: no colour conversion
+    gr = decode_jpeg_batch(rgb, 'cuda').cpu().numpy()
+    for i, s in enumerate(rgb):
+        assert b'Adobe' in s and np.array_equal(gr[i], _pil_chw(s))
     grey = [_encode(_frame(48, 40, rng, grey=True), quality=q) for q in (50, 90)]
     gg = decode_jpeg_batch(grey, 'cuda').cpu().numpy()
     for i, s in enumerate(grey):

@@ -70,6 +70,10 @@ def test_jpeg_oracle_is_bit_identical_to_pillow_on_a_sweep():
         n += 1
     data = _encode(rng.integers(0, 256, (48, 40, 3), dtype=np.uint8), qtables=[[1] * 64, [3] * 64])
     assert np.array_equal(jpeg_decode(data), _pil(data))
+    for kw in (dict(keep_rgb=True), dict(keep_rgb=True, quality=95), dict(keep_rgb=True, subsampling=0)):
+        data = _encode(_frame(40, 24, rng), **kw)            # Adobe marker, transform 0: the components ARE R, G, B
+        assert b'Adobe' in data and np.array_equal(jpeg_decode(data), _pil(data)), kw
+        n += 1
     assert n > 150
 
 
@@ -241,3 +245,26 @@ def test_damaged_streams_decode_the_same_way_everywhere(tmp_path):
             assert np.array_equal(out, ref), len(s)
             n += 1
     assert n > 200
+
+
+def test_compressed_batches_shard_at_pair_granularity():
+    """dist.PairShardedBatches slices a global batch along the clip dimension; a JpegBatch slices the same way (the rank
+    then uploads and decodes only its own pairs)."""
+    pytest.importorskip('PIL')
+    import torch
+    from grl_amd import dist as D
+    from grl_amd.reid.data.jpeg import JpegBatch
+    rng = np.random.default_rng(4)
+    streams = [_encode(_frame(16, 16, rng), quality=70) + bytes([i]) for i in range(8 * 2)]      # 8 clips x 2 frames, tagged
+    jb = JpegBatch(streams, (8, 2))
+    assert len(jb) == 8 and jb[2:6].shape == (4, 2) and jb[2:6].streams == streams[4:12]
+    with pytest.raises(TypeError):
+        jb[0]
+    pids = torch.arange(8) // 2
+    cams = torch.arange(8) % 2
+    got = []
+    for r in range(2):
+        for b, p, c in D.PairShardedBatches([(jb, pids, cams)], rank=r, world=2):
+            assert isinstance(b, JpegBatch) and b.shape == (4, 2) and len(p) == 4 and int(p[0]) == int(p[1])
+            got += b.streams
+    assert got == streams

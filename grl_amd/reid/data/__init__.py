@@ -77,10 +77,11 @@ class RawVideoDataset(Dataset):
         paths, pid, camid = self.tracklets[index]
         idx = sample_frame_indices(len(paths), self.seq_len, self.sample)
         if self.decode == 'device':
-            if self.sample == 'dense':
-                raise NotImplementedError("decode='device' serves fixed-length clips (rrs_train / rrs_test); dense mode decodes on the host")
             from .jpeg import read_file
-            item = ([read_file(paths[int(i)]) for i in idx], pid, camid)
+            if self.sample == 'dense':          # [n_clips][T] byte strings (test_all.py's mode: video_loader.py:86-123)
+                item = ([[read_file(paths[int(i)]) for i in row] for row in idx], pid, camid)
+            else:
+                item = ([read_file(paths[int(i)]) for i in idx], pid, camid)
             if self.augment:
                 item += (torch.tensor(draw_clip_params(self.seq_len, self.height, self.width), dtype=torch.int32),)
             return item

@@ -138,12 +138,23 @@ def decode_jpeg_batch(batch, device):
 
 
 def jpeg_collate(items):
-    """collate_fn for loaders whose dataset yields (list of T byte strings, pid, camid[, params]):
-    -> (JpegBatch of shape (B, T), pids, camids[, params]) -- the batch is decoded by engine.DevicePrefetcher."""
+    """collate_fn for loaders whose dataset yields (list of T byte strings, pid, camid[, params]) -- or, in dense mode,
+    (list of n_clips lists of T byte strings, pid, camid) --:
+    -> (JpegBatch of shape (B, T) / (B, n_clips, T), pids, camids[, params]); engine.DevicePrefetcher decodes the batch."""
     clips = [it[0] for it in items]
-    t = len(clips[0])
-    streams = [s for c in clips for s in c]
-    out = [JpegBatch(streams, (len(clips), t)), torch.as_tensor([it[1] for it in items]), torch.as_tensor([it[2] for it in items])]
+    dense = len(clips[0]) > 0 and isinstance(clips[0][0], (list, tuple))
+    if dense:
+        n = len(clips[0])
+        if any(len(c) != n for c in clips):
+            raise ValueError('dense tracklets of one batch must have the same number of clips (the reference uses batch size 1)')
+        t = len(clips[0][0])
+        streams = [s for c in clips for row in c for s in row]
+        shape = (len(clips), n, t)
+    else:
+        t = len(clips[0])
+        streams = [s for c in clips for s in c]
+        shape = (len(clips), t)
+    out = [JpegBatch(streams, shape), torch.as_tensor([it[1] for it in items]), torch.as_tensor([it[2] for it in items])]
     for k in range(3, len(items[0])):
         out.append(torch.stack([torch.as_tensor(it[k]) for it in items]))
     return tuple(out)

@@ -181,3 +181,32 @@ def test_device_decode_of_damaged_streams_equals_the_oracle():
         n += 1
     torch.cuda.synchronize()
     assert n > 40
+
+
+def test_dense_mode_evaluator_with_device_decode(tmp_path, gpu_models):
+    """test_all.py's dense mode (attevaluator.py:68-98: every clip of a tracklet, features averaged) fed from JPEG bytes:
+    RawVideoDataset(sample='dense', decode='device') -> jpeg_collate -> ATTEvaluator(only_eval=True).extract_feature equals
+    the host-decoded run bit for bit."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.jpeg import jpeg_collate
+    from grl_amd.reid.evaluator import ATTEvaluator
+    cnn, siam, _ = gpu_models
+    rng = np.random.default_rng(13)
+    tracklets = []
+    for tr in range(3):
+        paths = []
+        for fi in range(9 + tr):
+            p = os.path.join(tmp_path, 'd%d_f%d.jpg' % (tr, fi))
+            Image.fromarray(_frame(256, 128, rng)).save(p, format='JPEG', quality=88)
+            paths.append(p)
+        tracklets.append((paths, tr, tr % 2))
+    ev = ATTEvaluator(cnn, siam, only_eval=True)
+    feats = {}
+    for mode, kw in (('device', dict(collate_fn=jpeg_collate)), ('host', {})):
+        ds = RawVideoDataset(tracklets, seq_len=4, sample='dense', decode=mode)
+        f, pids, cams = ev.extract_feature(DataLoader(ds, batch_size=1, num_workers=0, **kw))
+        feats[mode] = f
+        assert list(pids) == [0, 1, 2] and f.shape == (3, 6144)
+    assert torch.equal(feats['device'], feats['host'])

@@ -197,6 +197,7 @@ _SIGNATURES = {
     # frame decode on the device (jpeg.hip)
     'grl_jpeg_parse': ([_fp, _i64, _i64, C.POINTER(GrlJpegFrame)], C.c_int),
     'grl_jpeg_assign_tables': ([C.POINTER(GrlJpegFrame), C.c_int], C.c_int),
+    'grl_jpeg_parallel_mode': ([C.c_int], C.c_int),
     'grl_jpeg_parse_batch': ([_fp, _fp, C.c_int, C.POINTER(GrlJpegFrame), _fp], C.c_int),
     'grl_jpeg_workspace_bytes': ([C.POINTER(GrlJpegFrame), C.c_int], _i64),
     'grl_jpeg_decode_batch': ([_fp, _fp, C.POINTER(GrlJpegFrame), C.c_int, _fp, _fp, _i64, _fp], C.c_int),

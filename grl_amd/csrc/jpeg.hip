@@ -22,6 +22,7 @@
 #include "common.h"
 #define GRL_HD __host__ __device__
 #include "jpeg_core.h"
+#include "jpeg_par.h"
 
 namespace {
 
@@ -176,6 +177,129 @@ __global__ __launch_bounds__(EW) void jpeg_entropy_kernel(const uint8_t* __restr
     }
 }
 
+// ---- 1b. the same, with intra-frame parallelism: one 256-lane workgroup per frame, self-synchronising subsequences
+//          (jpeg_par.h has the algorithm and the per-lane logic; this is its workgroup form) ------------------------------------
+constexpr int PT = 256;                                  // lanes per frame
+constexpr int PAR_MAX_BLOCKS = 8192;                     // blocks per frame the DC staging array holds
+constexpr int PAR_MAX_SCAN = 32768 - 64;                 // bytes of one scan that fit the LDS stream buffer
+
+struct ParLayout { int lut, exits, ints, part, dc, be, total; };      // byte offsets into the dynamic LDS
+inline ParLayout par_layout(int blocks, int max_dw) {
+    ParLayout l;
+    int o = 128;                                         // nat table
+    l.lut = o; o += GJ_LUT_PER_SET * 2;
+    l.exits = o; o += PT * 16;                           // GjState + block count per lane
+    l.ints = o; o += PT * 4;                             // scan scratch
+    l.part = o; o += PT * 3 * 4;                         // DC partial sums per lane and component
+    l.dc = o; o += ((blocks * 2 + 15) & ~15);
+    l.be = o; o += (max_dw + 2) * 4;
+    l.total = (o + 15) & ~15;
+    return l;
+}
+
+__global__ __launch_bounds__(PT) void jpeg_entropy_par_kernel(const GrlJpegFrame* __restrict__ frames, int16_t* __restrict__ coef,
+                                                              int blocks, int mcus, const uint16_t* __restrict__ lut_g,
+                                                              const uint8_t* __restrict__ clean, const uint32_t* __restrict__ clean_len,
+                                                              ParLayout lay) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    uint8_t* const s_nat = lds;
+    uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + lay.lut);
+    int32_t* const s_exit = reinterpret_cast<int32_t*>(lds + lay.exits);     // [lane][4]: bit, z, k, blocks
+    int32_t* const s_int = reinterpret_cast<int32_t*>(lds + lay.ints);
+    int32_t* const s_part = reinterpret_cast<int32_t*>(lds + lay.part);
+    int16_t* const s_dc = reinterpret_cast<int16_t*>(lds + lay.dc);
+    uint32_t* const s_be = reinterpret_cast<uint32_t*>(lds + lay.be);
+    const int f = blockIdx.x, i = threadIdx.x;
+    const GrlJpegFrame* fr = frames + f;
+    const uint32_t nbytes = clean_len[f];
+    const uint32_t ndw = (nbytes + 3u) >> 2;
+    {   // stage: zigzag table, this frame's look-ahead tables, the clean stream byte-swapped to bit order
+        for (int j = i; j < 80; j += PT) s_nat[j] = kNaturalDev[j];
+        const uint4* src = reinterpret_cast<const uint4*>(lut_g + (int64_t)fr->tabset * LUT_PER_SET);
+        uint4* dst = reinterpret_cast<uint4*>(s_lut);
+        for (int j = i; j < LUT_PER_SET / 8; j += PT) dst[j] = src[j];
+        const uint32_t* cs = reinterpret_cast<const uint32_t*>(clean + ((fr->scan_off + 3u) & ~3u));
+        for (uint32_t j = i; j < ndw + 2; j += PT) s_be[j] = j < ndw ? gj_bswap(cs[j]) : 0u;
+    }
+    __syncthreads();
+    GjParTables T;
+    gj_par_tables(T, fr, s_lut, s_nat);
+    const uint32_t nbits = nbytes * 8u;
+    const uint32_t L = gj_par_seq_bits(nbits, PT);
+    const int S = nbits ? (int)((nbits + L - 1) / L) : 1;
+    const bool active = i < S;
+    const uint32_t end = (uint32_t)(i + 1) * L;
+    GjState entry = {(uint32_t)i * L, 0, 0};
+    int nb = 0;
+    if (active) {
+        GjState st = entry;
+        nb = gj_par_walk(s_be, ndw, T, st, end);
+        s_exit[4 * i] = (int32_t)st.bit; s_exit[4 * i + 1] = st.z; s_exit[4 * i + 2] = st.k;
+    }
+    __syncthreads();
+    // synchronisation rounds: a lane whose left neighbour left in another state than the one it assumed walks again
+    for (int round = 0; round < PT; ++round) {
+        GjState prev = entry;
+        if (active && i > 0) { prev.bit = (uint32_t)s_exit[4 * (i - 1)]; prev.z = s_exit[4 * (i - 1) + 1]; prev.k = s_exit[4 * (i - 1) + 2]; }
+        __syncthreads();                                  // (every lane has read its neighbour before anyone overwrites)
+        int changed = 0;
+        if (active && i > 0 && !gj_same(prev, entry)) {
+            entry = prev;
+            GjState st = entry;
+            nb = gj_par_walk(s_be, ndw, T, st, end);
+            s_exit[4 * i] = (int32_t)st.bit; s_exit[4 * i + 1] = st.z; s_exit[4 * i + 2] = st.k;
+            changed = 1;
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    // exclusive scan of the completed-block counts (Hillis-Steele over the workgroup)
+    s_int[i] = active ? nb : 0;
+    __syncthreads();
+    for (int o = 1; o < PT; o <<= 1) {
+        const int v = i >= o ? s_int[i - o] : 0;
+        __syncthreads();
+        s_int[i] += v;
+        __syncthreads();
+    }
+    int b = s_int[i] - (active ? nb : 0);                 // blocks completed before this lane's entry
+    int16_t* const out = coef + (int64_t)f * blocks * 64;
+    if (active) {
+        GjState st = entry;
+        const bool last = i == S - 1;
+        auto emit = [&](int idx, int v) {
+            if (b < blocks) {
+                if (idx == 0) s_dc[b] = (int16_t)v;       // the DC DIFFERENCE; summed below
+                else out[(int64_t)b * 64 + idx] = (int16_t)v;
+            }
+        };
+        while (st.bit < end || (last && b < blocks))
+            if (gj_par_step(s_be, ndw, T, st, emit)) ++b;
+    }
+    __syncthreads();
+    // DC differences -> DC values: per component a prefix sum in scan order.  A lane owns a run of MCUs.
+    const int mpl = (mcus + PT - 1) / PT, m0 = i * mpl, m1 = min(mcus, m0 + mpl);
+    int part[3] = {0, 0, 0};
+    for (int m = m0; m < m1; ++m)
+        for (int z = 0; z < T.bpm; ++z) part[T.comp[z]] += s_dc[m * T.bpm + z];
+    for (int c = 0; c < 3; ++c) s_part[c * PT + i] = part[c];
+    __syncthreads();
+    for (int o = 1; o < PT; o <<= 1) {
+        int v[3];
+        for (int c = 0; c < 3; ++c) v[c] = i >= o ? s_part[c * PT + i - o] : 0;
+        __syncthreads();
+        for (int c = 0; c < 3; ++c) s_part[c * PT + i] += v[c];
+        __syncthreads();
+    }
+    int pred[3];
+    for (int c = 0; c < 3; ++c) pred[c] = s_part[c * PT + i] - part[c];
+    for (int m = m0; m < m1; ++m)
+        for (int z = 0; z < T.bpm; ++z) {
+            const int bb = m * T.bpm + z, c = T.comp[z];
+            pred[c] += s_dc[bb];
+            out[(int64_t)bb * 64] = (int16_t)pred[c];
+        }
+}
+
 // ---- 2. dequantisation + jidctint.c jpeg_idct_islow ---------------------------------------------------------------------
 #define GJ_CONST_BITS 13
 #define GJ_PASS1_BITS 2
@@ -319,6 +443,16 @@ void build_huff(const uint8_t* bits /*[17]*/, int32_t* maxcode /*[18]*/, int32_t
 }
 
 }  // namespace
+
+static bool g_jpeg_parallel = [] { const char* e = getenv("GRL_JPEG_PARALLEL"); return !e || atoi(e) != 0; }();
+
+// test / A-B hook: 0 / 1 = the one-lane-per-frame entropy decoder / the workgroup-per-frame one (default), -1 = query;
+// returns the previous setting.  Both produce the same coefficients.
+extern "C" int grl_jpeg_parallel_mode(int on) {
+    const int was = g_jpeg_parallel ? 1 : 0;
+    if (on >= 0) g_jpeg_parallel = on != 0;
+    return was;
+}
 
 #define GRL_REQUIRE(cond, msg) do { if (!(cond)) return grl_fail(GRL_EINVAL, msg); } while (0)
 
@@ -568,8 +702,22 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     (void)attr;
     bool any_restart = false;
     for (int i = 0; i < n; ++i) any_restart = any_restart || frames_host[i].restart_interval != 0;
-    if (!any_restart) {
-        // the common case: stuffing and the trailing marker removed by a pre-pass, the decoder reads clean dwords
+    uint32_t max_scan = 0;
+    for (int i = 0; i < n; ++i) max_scan = frames_host[i].scan_len > max_scan ? frames_host[i].scan_len : max_scan;
+    if (!any_restart && g_jpeg_parallel && max_scan <= (uint32_t)PAR_MAX_SCAN && g.blocks <= PAR_MAX_BLOCKS) {
+        // the common case: stuffing removed by a pre-pass, then ONE WORKGROUP PER FRAME decodes self-synchronising subsequences
+        const ParLayout lay = par_layout(g.blocks, (int)((max_scan + 3) / 4));
+        static int attr_bytes = 0;
+        if (lay.total > attr_bytes) {
+            (void)hipFuncSetAttribute((const void*)jpeg_entropy_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lay.total);
+            attr_bytes = lay.total;
+        }
+        if (hipMemsetAsync(coef, 0, (size_t)n * g.blocks * 64 * sizeof(int16_t), s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
+        hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(UT), 0, s, bytes, frames_dev, clean, clean_len);
+        hipLaunchKernelGGL(jpeg_entropy_par_kernel, dim3(n), dim3(PT), (size_t)lay.total, s, frames_dev, coef, g.blocks, g.mcux * g.mcuy, lut,
+                           clean, clean_len, lay);
+    } else if (!any_restart) {
+        // frames too large for the workgroup form: one lane per frame on the clean stream
         hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(UT), 0, s, bytes, frames_dev, clean, clean_len);
         hipLaunchKernelGGL(jpeg_entropy_kernel<0>, dim3(grl_ceil_div(n, EW)), dim3(EW), e_lds, s, bytes, nbytes, frames_dev, n, coef, sg,
                            g.blocks, lut, lds_sets, clean, clean_len);

@@ -697,6 +697,9 @@ typedef struct GrlJpegFrame {      /* one parsed frame: filled on the host by gr
 /* HOST function (no GPU call): parse the headers of ONE JPEG stream `data[0..len)` that will sit at byte `base_off` of
  * the batch buffer.  Returns GRL_OK, GRL_EINVAL (not a JPEG / truncated) or GRL_EUNSUPPORTED. */
 int grl_jpeg_parse(const uint8_t* data, int64_t len, int64_t base_off, GrlJpegFrame* out);
+/* test / A-B hook: 1 (default) = entropy decoding by one 256-lane workgroup per frame (self-synchronising subsequences),
+ * 0 = one lane per frame; -1 = query.  Same coefficients either way.  Returns the previous setting. */
+int grl_jpeg_parallel_mode(int on);
 /* HOST function: number the Huffman table sets of a batch (frames[i].tabset).  Up to 4 distinct sets get shared
  * look-ahead tables in LDS (frames of one encoder share ONE set); beyond that every frame keeps its own.  Returns
  * the number of sets (> 0) or a negative GRL_E* code.  Call after grl_jpeg_parse, before the descriptors are copied. */

@@ -5,6 +5,7 @@
 #include <vector>
 #define GRL_HD
 #include "../grl_amd/csrc/jpeg_core.h"
+#include "../grl_amd/csrc/jpeg_par.h"
 
 static const uint8_t kNat[80] = {
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
@@ -54,4 +55,79 @@ extern "C" int gj_host_decode_clean(const uint8_t* buf, uint32_t nbytes, const G
     gj_clean_init(b, dst, (uint32_t)kept);
     gj_decode_scan(b, fr, lut, kNat, out, g, stage, 2);
     return kept;
+}
+
+// the PARALLEL form (jpeg_par.h), its lanes emulated one after the other: unstuff, subsequences of L bits, walk from a
+// guessed state, re-walk until no lane's entry state changes (Jacobi rounds, as the workgroup does), scan of the block
+// counts, writing walk, DC prefix sums.  `lanes` / `min_bits` as in gj_par_seq_bits (small values stress the
+// synchronisation).  Returns the number of re-walk rounds.
+extern "C" int gj_host_decode_par(const uint8_t* buf, uint32_t nbytes, const GrlJpegFrame* fr, int16_t* out, int lanes, int min_bits) {
+    (void)nbytes;
+    static uint16_t lut[GJ_LUT_PER_SET];
+    GjScanGeo g;
+    setup(fr, lut, g);
+    const uint8_t* src = buf + fr->scan_off;
+    const int len = (int)fr->scan_len;
+    std::vector<uint8_t> clean((size_t)len + 16, 0);
+    int kept = 0;
+    for (int i = 0; i < len; ++i) {
+        const int prev = i > 0 ? src[i - 1] : 0, cur = src[i], next = i + 1 < len ? src[i + 1] : -1;
+        if (gj_marker_starts(cur, next)) break;
+        if (gj_is_data(prev, cur, next)) clean[kept++] = (uint8_t)cur;
+    }
+    const uint32_t ndw = (uint32_t)(kept + 3) / 4;
+    std::vector<uint32_t> be(ndw + 2, 0u);
+    for (uint32_t i = 0; i < ndw; ++i)
+        be[i] = ((uint32_t)clean[4 * i] << 24) | ((uint32_t)clean[4 * i + 1] << 16) | ((uint32_t)clean[4 * i + 2] << 8) | clean[4 * i + 3];
+    GjParTables T;
+    gj_par_tables(T, fr, lut, kNat);
+    int total_blocks = 0;
+    for (int c = 0; c < g.ncomp; ++c) total_blocks += g.nb[c];
+    total_blocks *= g.mcus;
+    const uint32_t nbits = (uint32_t)kept * 8u;
+    const uint32_t L = gj_par_seq_bits(nbits, (uint32_t)lanes, (uint32_t)min_bits);
+    const int S = nbits ? (int)((nbits + L - 1) / L) : 1;
+    std::vector<GjState> entry(S), exit_(S);
+    std::vector<int> nblk(S);
+    for (int i = 0; i < S; ++i) {
+        entry[i] = GjState{(uint32_t)i * L, 0, 0};
+        GjState s = entry[i];
+        nblk[i] = gj_par_walk(be.data(), ndw, T, s, (uint32_t)(i + 1) * L);
+        exit_[i] = s;
+    }
+    int rounds = 0;
+    for (bool changed = true; changed; ++rounds) {
+        changed = false;
+        std::vector<GjState> prev = exit_;                    // Jacobi: every lane reads the previous round's exits
+        for (int i = 1; i < S; ++i)
+            if (!gj_same(prev[i - 1], entry[i])) {
+                entry[i] = prev[i - 1];
+                GjState s = entry[i];
+                nblk[i] = gj_par_walk(be.data(), ndw, T, s, (uint32_t)(i + 1) * L);
+                exit_[i] = s;
+                changed = true;
+            }
+    }
+    // writing walk
+    memset(out, 0, (size_t)total_blocks * 64 * sizeof(int16_t));
+    int first = 0;
+    for (int i = 0; i < S; ++i) {
+        GjState s = entry[i];
+        int b = first;
+        const uint32_t end = (uint32_t)(i + 1) * L;
+        auto emit = [&](int idx, int v) { if (b < total_blocks) out[(size_t)b * 64 + idx] = (int16_t)v; };
+        while (i == S - 1 ? (s.bit < end || b < total_blocks) : s.bit < end) {
+            if (i == S - 1 && s.bit >= end && b >= total_blocks) break;
+            if (gj_par_step(be.data(), ndw, T, s, emit)) ++b;
+        }
+        first += nblk[i];
+    }
+    // DC differences -> DC values, per component in scan order
+    int pred[3] = {0, 0, 0};
+    for (int b = 0; b < total_blocks; ++b) {
+        const int c = T.comp[b % T.bpm];
+        pred[c] += out[(size_t)b * 64];
+        out[(size_t)b * 64] = (int16_t)pred[c];
+    }
+    return rounds;
 }

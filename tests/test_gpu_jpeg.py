@@ -210,3 +210,38 @@ def test_dense_mode_evaluator_with_device_decode(tmp_path, gpu_models):
         feats[mode] = f
         assert list(pids) == [0, 1, 2] and f.shape == (3, 6144)
     assert torch.equal(feats['device'], feats['host'])
+
+
+def test_workgroup_per_frame_and_lane_per_frame_decoders_agree():
+    """grl_jpeg_parallel_mode: the self-synchronising workgroup-per-frame entropy decoder (default) and the one-lane-per-frame
+    decoder give the same pixels -- on a MARS-geometry batch with per-frame qualities, on tiny and odd-sized frames (one
+    subsequence, partial MCUs), on optimised tables, and on damaged streams."""
+    from test_jpeg_cpu import _damaged_streams
+    from grl_amd import _lib
+    from grl_amd.reid.data.jpeg import decode_jpeg_batch
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    batches = [[_encode(_frame(256, 128, rng), quality=int(rng.integers(30, 99))) for _ in range(70)],
+               [_encode(_frame(17, 33, rng), quality=q, subsampling=1, optimize=True) for q in (40, 90)],
+               [_encode(_frame(1, 1, rng), quality=50)],
+               [_encode(rng.integers(0, 256, (64, 48, 3), dtype=np.uint8), quality=100, subsampling=0) for _ in range(3)]]
+    for s in _damaged_streams(np.random.default_rng(17), 30):
+        batches.append([s])
+    n = 0
+    for streams in batches:
+        outs = []
+        for mode in (1, 0):
+            was = lib.grl_jpeg_parallel_mode(mode)
+            try:
+                outs.append(decode_jpeg_batch(streams, 'cuda').cpu())
+            except _lib.GrlHipError:
+                outs.append(None)
+            finally:
+                lib.grl_jpeg_parallel_mode(was)
+        if outs[0] is None or outs[1] is None:
+            assert outs[0] is None and outs[1] is None
+            continue
+        assert torch.equal(outs[0], outs[1]), len(streams[0])
+        n += 1
+    torch.cuda.synchronize()
+    assert n > 20

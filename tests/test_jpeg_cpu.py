@@ -268,3 +268,50 @@ def test_compressed_batches_shard_at_pair_granularity():
             assert isinstance(b, JpegBatch) and b.shape == (4, 2) and len(p) == 4 and int(p[0]) == int(p[1])
             got += b.streams
     assert got == streams
+
+
+def test_parallel_entropy_decoder_emulated_on_the_cpu_matches_the_oracle(tmp_path):
+    """jpeg_par.h (the workgroup-per-frame form: self-synchronising subsequences, block-count scan, DC prefix sums) with its
+    lanes emulated one after the other (tests/jpeg_core_host.cpp: gj_host_decode_par): the oracle's coefficients for intact
+    and damaged streams, for the production geometry (256 lanes, 1024-bit subsequences) and for geometries that stress the
+    synchronisation (32-bit subsequences, 1 / 7 / 64 lanes)."""
+    import os
+    import subprocess
+    pytest.importorskip('PIL')
+    from grl_amd.reid.data.jpeg import JpegBatch
+    from oracle.ref_c import jpeg_coefficients
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tmp_path, 'libgjhost.so')
+    subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', os.path.join(root, 'tests', 'jpeg_core_host.cpp'), '-o', so])
+    lib = C.CDLL(so)
+    lib.gj_host_decode_par.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.gj_host_decode_par.restype = C.c_int
+    rng = np.random.default_rng(0)
+    streams = []
+    for (h, w) in [(256, 128), (17, 33), (1, 1), (31, 2), (64, 48), (100, 77)]:
+        for sub in (0, 1, 2):
+            for q, kw in ((30, {}), (75, dict(optimize=True)), (100, {})):
+                try:
+                    streams.append(_encode(_frame(h, w, rng), quality=q, subsampling=sub, **kw))
+                except OSError:
+                    pass
+    streams.append(_encode(_frame(48, 40, rng, grey=True), quality=80))
+    streams += _damaged_streams(np.random.default_rng(5), 60)
+    n, rounds = 0, []
+    for s in streams:
+        try:
+            ref = jpeg_coefficients(s)
+            host, fr = JpegBatch([s], (1,)).pack()
+        except Exception:                      # noqa: BLE001 (a damaged header either side refuses)
+            continue
+        if fr[0].restart_interval:
+            continue
+        buf = np.ascontiguousarray(np.concatenate([host.numpy(), np.zeros(8, np.uint8)]))
+        for lanes, minb in ((256, 1024), (256, 64), (7, 32), (1, 32), (64, 32)):
+            out = np.full_like(ref, 7)
+            r = lib.gj_host_decode_par(buf.ctypes.data, len(buf) - 8, C.addressof(fr[0]), out.ctypes.data, lanes, minb)
+            assert np.array_equal(out, ref), (len(s), lanes, minb, r)
+            if (lanes, minb) == (256, 1024) and len(s) > 8000:
+                rounds.append(r)
+            n += 1
+    assert n > 400 and rounds and max(rounds) < 256           # (4-6 rounds for quality-90 MARS frames; quality 100 needs up to ~40)

@@ -4,7 +4,7 @@
 //   0. jpeg_unstuff_kernel   0xFF00 stuffing, fill bytes and the trailing marker removed (a workgroup per frame, 4 bytes per
 //                            lane, workgroup scan); jpeg_lut_kernel: look-ahead tables per Huffman table set.
 //   1. jpeg_entropy_par_kernel  Huffman decoding (ITU-T T.81 F.2.2) by ONE 256-LANE WORKGROUP PER FRAME: the clean stream is
-//                            cut into 1024-bit subsequences, every lane decodes one from a guessed state, lanes re-walk until
+//                            cut into 512-bit subsequences, every lane decodes one from a guessed state, lanes re-walk until
 //                            each starts where its left neighbour stopped (Huffman streams re-synchronise: 4-6 rounds for a
 //                            quality-90 MARS frame), a scan of the block counts places every lane, a last walk writes the
 //                            coefficients, a prefix sum per component turns DC differences into DC values (jpeg_par.h).
@@ -206,7 +206,7 @@ inline ParLayout par_layout(int blocks, int max_dw) {
 __global__ __launch_bounds__(PT) void jpeg_entropy_par_kernel(const GrlJpegFrame* __restrict__ frames, int16_t* __restrict__ coef,
                                                               int blocks, int mcus, const uint16_t* __restrict__ lut_g,
                                                               const uint8_t* __restrict__ clean, const uint32_t* __restrict__ clean_len,
-                                                              ParLayout lay) {
+                                                              ParLayout lay, uint32_t min_bits) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t* const s_nat = lds;
     uint16_t* const s_lut = reinterpret_cast<uint16_t*>(lds + lay.lut);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(PT) void jpeg_entropy_par_kernel(const GrlJpegFrame
     GjParTables T;
     gj_par_tables(T, fr, s_lut, s_nat);
     const uint32_t nbits = nbytes * 8u;
-    const uint32_t L = gj_par_seq_bits(nbits, PT);
+    const uint32_t L = gj_par_seq_bits(nbits, PT, min_bits);
     const int S = nbits ? (int)((nbits + L - 1) / L) : 1;
     const bool active = i < S;
     const uint32_t end = (uint32_t)(i + 1) * L;
@@ -278,8 +278,10 @@ __global__ __launch_bounds__(PT) void jpeg_entropy_par_kernel(const GrlJpegFrame
                 else out[(int64_t)b * 64 + idx] = (int16_t)v;
             }
         };
+        GjBeReader rd;
+        gj_be_init(rd, s_be, ndw, st.bit);
         while (st.bit < end || (last && b < blocks))
-            if (gj_par_step(s_be, ndw, T, st, emit)) ++b;
+            if (gj_par_step(rd, T, st, emit)) ++b;
     }
     __syncthreads();
     // DC differences -> DC values: per component a prefix sum in scan order.  A lane owns a run of MCUs.
@@ -720,8 +722,9 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
         }
         if (hipMemsetAsync(coef, 0, (size_t)n * g.blocks * 64 * sizeof(int16_t), s) != hipSuccess) return grl_check_launch("jpeg_decode_batch (memset)");
         hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(UT), 0, s, bytes, frames_dev, clean, clean_len);
+        static const uint32_t seq_bits = [] { const char* e = getenv("GRL_JPEG_SEQ_BITS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 32 ? (v + 31) & ~31 : 512); }();
         hipLaunchKernelGGL(jpeg_entropy_par_kernel, dim3(n), dim3(PT), (size_t)lay.total, s, frames_dev, coef, g.blocks, g.mcux * g.mcuy, lut,
-                           clean, clean_len, lay);
+                           clean, clean_len, lay, seq_bits);
     } else if (!any_restart) {
         // frames too large for the workgroup form: one lane per frame on the clean stream
         hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(UT), 0, s, bytes, frames_dev, clean, clean_len);

@@ -5,7 +5,7 @@
 // arbitrary bit with a wrong state falls into step with the true symbol sequence after a few symbols (Weissenberger & Schmidt,
 // "Massively Parallel Huffman Decoding on GPUs", 2018; for JPEG the state is the bit position plus the place inside the
 // MCU -- block slot z and coefficient index k).  So a frame's clean stream (jpeg_unstuff_kernel) is cut into subsequences of
-// L bits, one per lane of a 256-lane workgroup:
+// L bits (512 for a MARS frame: ~210 of them), one per lane of a 256-lane workgroup:
 //   1. every lane walks its subsequence from a GUESSED state (z = 0, k = 0; lane 0's is the true one) and publishes where
 //      and in which state it left it;
 //   2. a lane whose left neighbour's exit state differs from the entry state it used re-walks from that exit state; repeat
@@ -38,13 +38,6 @@ struct GjParTables {
     int8_t comp[8];        // per block slot: its component
 };
 
-// 31 bits at bit position p of the byte-swapped (big-endian) dword stream `be`; dwords from `ndw` on read as zero
-GRL_HD static inline uint32_t gj_peek31(const uint32_t* be, uint32_t ndw, uint32_t p) {
-    const uint32_t i = p >> 5, o = p & 31u;
-    const uint64_t w = ((uint64_t)(i < ndw ? be[i] : 0u) << 32) | (uint64_t)(i + 1 < ndw ? be[i + 1] : 0u);
-    return (uint32_t)(w >> (33u - o)) & 0x7fffffffu;
-}
-
 // one Huffman symbol from the top 16 bits of a 31-bit window; `len` = code length consumed
 GRL_HD static inline int gj_par_symbol(uint32_t look31, const GjParTables& T, int t, int& len) {
     const uint32_t look = look31 >> 15;
@@ -62,19 +55,43 @@ GRL_HD static inline int gj_par_symbol(uint32_t look31, const GjParTables& T, in
     return 0;
 }
 
+// sequential reader over the byte-swapped stream: 64-bit window, refilled one dword at a time (the refill is not on the
+// symbol's dependent chain -- a walk is a run of ~75 symbols from one bit position on)
+struct GjBeReader {
+    const uint32_t* be;
+    uint32_t ndw, next;      // dwords in the stream, next dword to append
+    uint64_t acc;            // the low `cnt` bits are the unread ones
+    int cnt;
+};
+GRL_HD static inline void gj_be_init(GjBeReader& r, const uint32_t* be, uint32_t ndw, uint32_t bit) {
+    const uint32_t i = bit >> 5, o = bit & 31u;
+    r.be = be; r.ndw = ndw;
+    r.acc = ((uint64_t)(i < ndw ? be[i] : 0u) << 32) | (uint64_t)(i + 1 < ndw ? be[i + 1] : 0u);
+    r.cnt = 64 - (int)o;
+    r.next = i + 2;
+}
+GRL_HD static inline uint32_t gj_be_look31(GjBeReader& r) {            // the next 31 bits (cnt >= 31 after the refill)
+    if (r.cnt <= 32) {
+        r.acc = (r.acc << 32) | (uint64_t)(r.next < r.ndw ? r.be[r.next] : 0u);
+        r.cnt += 32;
+        ++r.next;
+    }
+    return (uint32_t)(r.acc >> (r.cnt - 31)) & 0x7fffffffu;
+}
+
 // One symbol of the serial decoder's state machine (jpeg_core.h gj_decode_scan, same rules: run / size, EOB, ZRL, the guard
-// entries of `nat` for runs that leave the block).  emit(coefficient index in natural order, value) is called for a
-// coefficient; returns true when the symbol completed a block.
+// entries of `nat` for runs that leave the block) applied to the 31-bit window `look31` at s.bit.  emit(coefficient index
+// in natural order, value) is called for a coefficient; `used` = bits consumed; returns true when the symbol completed a
+// block.
 template <class Emit>
-GRL_HD static inline bool gj_par_step(const uint32_t* be, uint32_t ndw, const GjParTables& T, GjState& s, Emit&& emit) {
-    const uint32_t look31 = gj_peek31(be, ndw, s.bit);
+GRL_HD static inline bool gj_par_apply(uint32_t look31, const GjParTables& T, GjState& s, int& used, Emit&& emit) {
     int len;
     if (s.k == 0) {
         const int sz = gj_par_symbol(look31, T, T.td[s.z], len) & 15;
         int diff = 0;
         if (sz) diff = gj_extend((int)((look31 >> (31 - len - sz)) & ((1u << sz) - 1u)), sz);
         emit(0, diff);
-        s.bit += (uint32_t)(len + sz);
+        used = len + sz;
         s.k = 1;
         return false;
     }
@@ -84,11 +101,11 @@ GRL_HD static inline bool gj_par_step(const uint32_t* be, uint32_t ndw, const Gj
     if (sz) {
         const int kk = s.k + r;
         emit((int)T.nat[kk], gj_extend((int)((look31 >> (31 - len - sz)) & ((1u << sz) - 1u)), sz));
-        s.bit += (uint32_t)(len + sz);
+        used = len + sz;
         s.k = kk + 1;
         done = s.k >= 64;
     } else {
-        s.bit += (uint32_t)len;
+        used = len;
         if (r != 15) {
             done = true;
         } else {
@@ -103,16 +120,29 @@ GRL_HD static inline bool gj_par_step(const uint32_t* be, uint32_t ndw, const Gj
     return done;
 }
 
+// one symbol through the reader
+template <class Emit>
+GRL_HD static inline bool gj_par_step(GjBeReader& r, const GjParTables& T, GjState& s, Emit&& emit) {
+    int used;
+    const bool done = gj_par_apply(gj_be_look31(r), T, s, used, emit);
+    r.cnt -= used;
+    s.bit += (uint32_t)used;
+    return done;
+}
+
 // walk [s.bit, end_bit): every symbol that STARTS before end_bit; returns the number of blocks completed
 GRL_HD static inline int gj_par_walk(const uint32_t* be, uint32_t ndw, const GjParTables& T, GjState& s, uint32_t end_bit) {
+    GjBeReader r;
+    gj_be_init(r, be, ndw, s.bit);
     int blocks = 0;
     while (s.bit < end_bit)
-        if (gj_par_step(be, ndw, T, s, [](int, int) {})) ++blocks;
+        if (gj_par_step(r, T, s, [](int, int) {})) ++blocks;
     return blocks;
 }
 
-// subsequence length in bits for a stream of nbits and at most `lanes` lanes: >= 1024, a multiple of 32
-GRL_HD static inline uint32_t gj_par_seq_bits(uint32_t nbits, uint32_t lanes, uint32_t min_bits = 1024u) {
+// subsequence length in bits for a stream of nbits and at most `lanes` lanes: >= 512 (measured: 1024 / 768 / 512 / 384 / 256
+// bits -> 1.04 / 0.90 / 0.86 / 0.87 / 0.88 ms per 128-frame batch), a multiple of 32
+GRL_HD static inline uint32_t gj_par_seq_bits(uint32_t nbits, uint32_t lanes, uint32_t min_bits = 512u) {
     uint32_t L = (nbits + lanes - 1) / lanes;
     L = (L + 31u) & ~31u;
     return L < min_bits ? min_bits : L;       // (any multiple of 32 >= 32 is correct: a symbol is at most 31 bits long)

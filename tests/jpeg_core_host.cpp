@@ -116,10 +116,10 @@ extern "C" int gj_host_decode_par(const uint8_t* buf, uint32_t nbytes, const Grl
         int b = first;
         const uint32_t end = (uint32_t)(i + 1) * L;
         auto emit = [&](int idx, int v) { if (b < total_blocks) out[(size_t)b * 64 + idx] = (int16_t)v; };
-        while (i == S - 1 ? (s.bit < end || b < total_blocks) : s.bit < end) {
-            if (i == S - 1 && s.bit >= end && b >= total_blocks) break;
-            if (gj_par_step(be.data(), ndw, T, s, emit)) ++b;
-        }
+        GjBeReader r;
+        gj_be_init(r, be.data(), ndw, s.bit);
+        while (s.bit < end || (i == S - 1 && b < total_blocks))
+            if (gj_par_step(r, T, s, emit)) ++b;
         first += nblk[i];
     }
     // DC differences -> DC values, per component in scan order

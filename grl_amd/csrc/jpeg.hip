@@ -410,26 +410,49 @@ __device__ __forceinline__ int up_sample(const uint8_t* __restrict__ p, int stri
 
 __device__ __forceinline__ uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, const GrlJpegFrame* __restrict__ frames,
-                                                         int n, uint8_t* __restrict__ out, Geo g) {
-    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t hw = (int64_t)g.width * g.height;
-    if (gid >= n * hw) return;
-    const int f = (int)(gid / hw);
-    const int y = (int)((gid % hw) / g.width), x = (int)(gid % g.width);
-    const uint8_t* pl = planes + (int64_t)f * g.plane_bytes;
+__device__ __forceinline__ void color_px(const uint8_t* __restrict__ pl, const Geo& g, int rgb, int x, int y, uint32_t (&o)[3]) {
     const int Y = pl[g.poff[0] + (int64_t)y * g.pw[0] + x];
-    uint8_t* o = out + (int64_t)f * 3 * hw + (int64_t)y * g.width + x;
-    if (g.ncomp == 1) { o[0] = o[hw] = o[2 * hw] = (uint8_t)Y; return; }
+    if (g.ncomp == 1) { o[0] = o[1] = o[2] = (uint32_t)Y; return; }
     const int h2 = g.hmax == 2, v2 = g.vmax == 2;
     const int cbv = up_sample(pl + g.poff[1], g.pw[1], g.cw[1], g.ch[1], h2, v2, x, y);
     const int crv = up_sample(pl + g.poff[2], g.pw[2], g.cw[2], g.ch[2], h2, v2, x, y);
-    if (frames[f].rgb) { o[0] = (uint8_t)Y; o[hw] = (uint8_t)cbv; o[2 * hw] = (uint8_t)crv; return; }
+    if (rgb) { o[0] = (uint32_t)Y; o[1] = (uint32_t)cbv; o[2] = (uint32_t)crv; return; }
     const int cb = cbv - 128, cr = crv - 128;
     // jdcolor.c build_ycc_rgb_table: FIX(x) = (int)(x * 65536 + 0.5), ONE_HALF = 32768, arithmetic right shifts
     o[0] = clamp8(Y + ((91881 * cr + 32768) >> 16));
-    o[hw] = clamp8(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16));
-    o[2 * hw] = clamp8(Y + ((116130 * cb + 32768) >> 16));
+    o[1] = clamp8(Y + ((-22554 * cb - 46802 * cr + 32768) >> 16));
+    o[2] = clamp8(Y + ((116130 * cb + 32768) >> 16));
+}
+
+// PX pixels of a row per lane: 4 (one 4-byte store per colour plane) when the width is a multiple of 4, else 1
+template <int PX>
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, const GrlJpegFrame* __restrict__ frames,
+                                                         int n, uint8_t* __restrict__ out, Geo g) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t hw = (int64_t)g.width * g.height, groups = hw / PX;
+    if (gid >= n * groups) return;
+    const int f = (int)(gid / groups);
+    const int64_t p0 = (gid % groups) * PX;
+    const int y = (int)(p0 / g.width), x0 = (int)(p0 % g.width);
+    const uint8_t* pl = planes + (int64_t)f * g.plane_bytes;
+    const int rgb = frames[f].rgb;
+    uint8_t* o = out + (int64_t)f * 3 * hw + p0;
+    if constexpr (PX == 1) {
+        uint32_t c[3];
+        color_px(pl, g, rgb, x0, y, c);
+        o[0] = (uint8_t)c[0]; o[hw] = (uint8_t)c[1]; o[2 * hw] = (uint8_t)c[2];
+    } else {
+        uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            uint32_t c[3];
+            color_px(pl, g, rgb, x0 + e, y, c);
+            w[0] |= c[0] << (8 * e); w[1] |= c[1] << (8 * e); w[2] |= c[2] << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(o) = w[0];
+        *reinterpret_cast<uint32_t*>(o + hw) = w[1];
+        *reinterpret_cast<uint32_t*>(o + 2 * hw) = w[2];
+    }
 }
 
 // ---- host: header parser ---------------------------------------------------------------------------------------------------
@@ -737,6 +760,9 @@ extern "C" int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* f
     const int64_t nblk = (int64_t)n * g.blocks;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, coef, frames_dev, n, planes, g);
     const int64_t npix = (int64_t)n * g.width * g.height;
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, planes, frames_dev, n, out, g);
+    if (g.width % 4 == 0 && ((uintptr_t)out & 3) == 0)
+        hipLaunchKernelGGL(jpeg_color_kernel<4>, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, s, planes, frames_dev, n, out, g);
+    else
+        hipLaunchKernelGGL(jpeg_color_kernel<1>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, planes, frames_dev, n, out, g);
     return grl_check_launch("grl_jpeg_decode_batch");
 }

@@ -5,10 +5,10 @@
 //                            lane, workgroup scan); jpeg_lut_kernel: look-ahead tables per Huffman table set.
 //   1. jpeg_entropy_par_kernel  Huffman decoding (ITU-T T.81 F.2.2) by ONE 256-LANE WORKGROUP PER FRAME: the clean stream is
 //                            cut into 512-bit subsequences, every lane decodes one from a guessed state, lanes re-walk until
-//                            each starts where its left neighbour stopped (Huffman streams re-synchronise: 4-6 rounds for a
+//                            each starts where its left neighbour stopped (Huffman streams re-synchronise: 7-12 rounds for a
 //                            quality-90 MARS frame), a scan of the block counts places every lane, a last walk writes the
 //                            coefficients, a prefix sum per component turns DC differences into DC values (jpeg_par.h).
-//                            Stream, look-ahead tables and DC values sit in LDS.  128 frames: 1.06 ms (the one-lane-per-frame
+//                            Stream, look-ahead tables and DC values sit in LDS.  128 frames: 0.79 ms (the one-lane-per-frame
 //                            form below: 10.3 ms for ANY batch size -- it stays for frames that do not fit the workgroup form
 //                            and for scans with restart intervals; jpeg_core.h).
 //   1'. jpeg_entropy_kernel  the same with a lane per frame (64 frames per workgroup): clean reader with the next dword loaded

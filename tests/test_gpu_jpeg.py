@@ -245,3 +245,38 @@ def test_workgroup_per_frame_and_lane_per_frame_decoders_agree():
         n += 1
     torch.cuda.synchronize()
     assert n > 20
+
+
+def test_trainer_input_from_jpeg_bytes_with_device_augmentation(tmp_path):
+    """The TRAINING input path with nothing but file reads on the host: tracklets of JPEG files ->
+    RawVideoDataset(decode='device', augment=True) -> jpeg_collate -> engine.DevicePrefetcher (device decode) ->
+    SEQTrainer._parse_data (flip / erase / ToTensor / Normalize on the device) gives exactly the float clips of the
+    host-decoded (Pillow) path with the same augmentation draws."""
+    import random
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from grl_amd import engine
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.jpeg import jpeg_collate
+    from grl_amd.reid.train.trainer import SEQTrainer
+    rng = np.random.default_rng(19)
+    tracklets = []
+    for tr in range(4):
+        paths = []
+        for fi in range(5):
+            p = os.path.join(tmp_path, 'a%d_f%d.jpg' % (tr, fi))
+            Image.fromarray(_frame(256, 128, rng)).save(p, format='JPEG', quality=90)
+            paths.append(p)
+        tracklets.append((paths, tr // 2, tr % 2))
+    tr_obj = SEQTrainer.__new__(SEQTrainer)
+    tr_obj.device = torch.device('cuda', 0)
+    outs = {}
+    for mode, kw in (('device', dict(collate_fn=jpeg_collate)), ('host', {})):
+        random.seed(5); np.random.seed(5)                      # the same frame picks and augmentation draws for both runs
+        ds = RawVideoDataset(tracklets, seq_len=4, sample='rrs_train', augment=True, decode=mode)
+        batch = next(iter(engine.DevicePrefetcher(DataLoader(ds, batch_size=4, num_workers=0, **kw), 'cuda')))
+        assert len(batch) == 4 and batch[0].dtype == torch.uint8 and batch[0].shape == (4, 4, 3, 256, 128)
+        (imgs,), pids = tr_obj._parse_data(batch)
+        outs[mode] = (imgs.clone(), pids.clone(), batch[3].clone())
+    assert torch.equal(outs['device'][2], outs['host'][2]) and torch.equal(outs['device'][1], outs['host'][1])
+    assert outs['device'][0].dtype == torch.float32 and torch.equal(outs['device'][0], outs['host'][0])

@@ -66,6 +66,7 @@ class GrlJpegFrame(C.Structure):
                 ('maxcode', (C.c_int32 * 18) * 4), ('valoff', (C.c_int32 * 18) * 4), ('vals', (C.c_uint8 * 256) * 4)]
 
 
+GRL_EINVAL = -1
 GRL_EUNSUPPORTED = -3
 
 _SIGNATURES = {

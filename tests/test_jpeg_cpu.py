@@ -134,6 +134,57 @@ def test_host_header_parser_fills_the_frame_descriptor(golden):
     assert lib.grl_jpeg_decode_batch(None, None, fr, 2, None, None, 0, None) == -1             # argument checks need no GPU
 
 
+def test_host_header_parser_survives_mutated_and_truncated_headers(golden):
+    """grl_jpeg_parse on ~6000 damaged HEADERS (random byte edits before the scan, every truncation length of one stream):
+    it returns a GRL code -- never reads outside the buffer, never accepts a descriptor the kernels' launch rules do not
+    cover.  Every stream ends at an inaccessible guard page, so a read past its end is a fault, not luck."""
+    from grl_amd import _lib
+    lib = _lib.load()
+    g = golden('jpeg_frames.npz')
+    streams = [g[k].tobytes() for k in g.files if k.startswith('jpeg.')]
+    rng = np.random.default_rng(11)
+    fr = _lib.GrlJpegFrame()
+    codes = {}
+
+    # a mapping whose last page is inaccessible: a stream is placed so that it ENDS at the guard page
+    import mmap
+    page = mmap.PAGESIZE
+    room = 8 * page
+    region = mmap.mmap(-1, room + page)
+    base = C.addressof(C.c_char.from_buffer(region))
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    assert libc.mprotect(base + room, page, 0) == 0, C.get_errno()
+
+    def parse(b):
+        assert len(b) <= room
+        at = room - len(b)
+        region[at:room] = b
+        rc = lib.grl_jpeg_parse(C.cast(base + at, C.POINTER(C.c_uint8)), len(b), 0, C.byref(fr))
+        codes[rc] = codes.get(rc, 0) + 1
+        assert rc in (0, _lib.GRL_EINVAL, _lib.GRL_EUNSUPPORTED), rc
+        if rc == 0:
+            assert fr.scan_off <= len(b) and fr.scan_off + fr.scan_len == len(b)
+            assert fr.ncomp in (1, 3) and fr.width and fr.height and fr.hmax in (1, 2) and fr.vmax in (1, 2)
+            for c in range(fr.ncomp):
+                assert 1 <= fr.hs[c] <= 2 and 1 <= fr.vs[c] <= 2 and fr.tq[c] <= 3 and fr.td[c] <= 1 and fr.ta[c] <= 1
+        return rc
+
+    for s in streams:
+        assert parse(s) == 0
+        head = fr.scan_off
+        for _ in range(600):
+            b = bytearray(s)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(2, head))] = int(rng.integers(0, 256))
+            parse(bytes(b))
+    s = streams[0]
+    assert parse(s) == 0
+    for cut in range(4, fr.scan_off + 8):
+        parse(s[:cut])
+    assert codes.get(0, 0) > 100 and codes.get(_lib.GRL_EINVAL, 0) > 100 and codes.get(_lib.GRL_EUNSUPPORTED, 0) > 10, codes
+
+
 def test_device_entropy_core_on_the_cpu_matches_the_oracle_coefficients(tmp_path):
     """grl_amd/csrc/jpeg_core.h is the per-lane logic of jpeg_entropy_kernel and compiles as plain C++
     (tests/jpeg_core_host.cpp, g++): the quantised coefficients it leaves equal the oracle's for every stream of a sweep

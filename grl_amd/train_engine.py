@@ -773,7 +773,7 @@ def conv_param_and_input_grads(tp, dz, x, conv, n_img, H, W, Ho, Wo, cin, N, k, 
     else:                                   # first kcols columns of a wider weight
         tmp = torch.empty(N, kcols, dtype=torch.float32, device=tp.dev)
         wgrad(dz, x, tmp, M, N, K, accumulate=0)
-        tp.pgrad(w).view(N, -1)[:, :kcols] += tmp
+        tp.pgrad(w).view(N, -1)[:, :kcols].add_(tmp)        # (`view[...] += t` would copy the slice onto itself afterwards)
     if id(x) in tp.no_grad:
         return
     Min = n_img * H * W
@@ -1059,7 +1059,7 @@ def gce_train(tp, model, x4, b, t):
         _call(_k('grl_group_mean', dz1), ptr(dz1), ptr(dgb), b, rpc, 1024, 1024, C.c_float(float(rpc)), 0)
         tmp = torch.empty(1024, 1024, dtype=torch.float32, device=tp.dev)
         wgrad(dgb, glo, tmp, b, 1024, 1024, accumulate=0)
-        tp.pgrad(conv0.weight).view(1024, 3072)[:, 2048:] += tmp
+        tp.pgrad(conv0.weight).view(1024, 3072)[:, 2048:].add_(tmp)
         dglo = _new((b, 1024), x4)
         gemm(dgb, tp.w_t(w0[:, 2048:], ('wg', id(conv0.weight)), ld=3072), dglo, b, 1024, 1024)
         tp.add_grad(glo, dglo)
@@ -1076,11 +1076,13 @@ def gce_train(tp, model, x4, b, t):
     w5[0] = conv5.weight.detach().view(256)
     z3 = _newl((M, PW), x4)
     _, slab = gemm(h2, tp.w16(w5), z3, M, PW, 256, stats=True)
-    g32, b32 = _pad32(bn6.weight, n=PW), _pad32(bn6.bias, n=PW)
-    rm32, rv32 = _pad32(bn6.running_mean, n=PW), _pad32(bn6.running_var, 1.0, n=PW)
+    # gamma | beta | running mean | running var of the ONE real channel in column 0 of a zero (4, PW) block (three
+    # launches instead of the eight of four padded vectors; the padding channels' statistics are never read)
+    pad4 = torch.zeros(4, PW, dtype=torch.float32, device=tp.dev)
+    pad4[:, 0] = torch.cat((bn6.weight.detach(), bn6.bias.detach(), bn6.running_mean, bn6.running_var))
+    g32, b32, rm32, rv32 = pad4[0], pad4[1], pad4[2], pad4[3]
     st = bn_finalize(slab, slab.shape[0], PW, M, bn6, tp.dev, gamma=g32, beta=b32, rm=rm32, rv=rv32)
-    bn6.running_mean.copy_(rm32[:1])
-    bn6.running_var.copy_(rv32[:1])
+    torch._foreach_copy_([bn6.running_mean, bn6.running_var], [rm32[:1], rv32[:1]])
     y3 = _newl((M, PW), x4)
     bn_apply(z3, st, None, y3, M, PW, False)
     cmap = _new((M,), x4)
@@ -1102,13 +1104,13 @@ def gce_train(tp, model, x4, b, t):
         else:
             acc = 1
         _call(_k('grl_gate_bwd', x4), ptr(dxc), ptr(dxu), ptr(x4), ptr(cmap), ptr(cur), acc, ptr(dy3), PW, M, 2048)
-        dg32, db32 = torch.zeros(PW, device=tp.dev), torch.zeros(PW, device=tp.dev)
+        dgb = torch.zeros(2, PW, device=tp.dev)
+        dg32, db32 = dgb[0], dgb[1]
         dz3 = bn_backward(dy3, z3, None, st, g32, dg32, db32, M, PW)
-        tp.pgrad(bn6.weight).add_(dg32[:1])
-        tp.pgrad(bn6.bias).add_(db32[:1])
         dw5 = torch.empty(PW, 256, dtype=torch.float32, device=tp.dev)
         wgrad(dz3, h2, dw5, M, PW, 256, accumulate=0)
-        tp.pgrad(conv5.weight).view(1, 256).add_(dw5[:1])
+        torch._foreach_add_([tp.pgrad(bn6.weight), tp.pgrad(bn6.bias), tp.pgrad(conv5.weight).view(1, 256)],
+                            [dg32[:1], db32[:1], dw5[:1]])
         dh2 = _newl((M, 256), x4)
         gemm(dz3, tp.w_t(w5, ('w5', id(conv5.weight)), like=dz3), dh2, M, 256, PW)
         tp.add_grad(h2, dh2)
@@ -1424,7 +1426,9 @@ def attn_train(tp, siam, x, b, t):
     cat4 = _new((4, 2 * D), x)
     both = _BNState()
     both.mean, both.invstd, both.scale = cat4[0], cat4[1], cat4[2]
-    both.beta = torch.cat((siam.featQ_bn.bias.detach(), siam.featK_bn.bias.detach()))
+    gb = torch.cat((siam.featQ_bn.weight.detach(), siam.featK_bn.weight.detach(),
+                    siam.featQ_bn.bias.detach(), siam.featK_bn.bias.detach())).view(2, 2 * D)    # gamma | beta
+    both.beta = gb[1]
     for h, bn in enumerate((siam.featQ_bn, siam.featK_bn)):
         slab = _new((rows, 2, D), x)
         zh = z[:, h * D:]
@@ -1448,17 +1452,19 @@ def attn_train(tp, siam, x, b, t):
             acc = 0
         _call('grl_siamese_attn_bwd', ptr(qk), ptr(x), ptr(out), Cc, ptr(dout), Cc, ptr(dqk), ptr(cur), acc,
               b, t, D, Cc)
-        gamma = torch.cat((siam.featQ_bn.weight.detach(), siam.featK_bn.weight.detach()))
-        dg, db = torch.zeros(2 * D, device=tp.dev), torch.zeros(2 * D, device=tp.dev)
+        gamma = gb[0]                                           # (the optimizer steps after the backward)
+        acc3 = torch.zeros(3, 2 * D, device=tp.dev)          # dgamma | dbeta | dbias of the Q|K halves: one fill
+        dg, db, dbias = acc3[0], acc3[1], acc3[2]
         dz = bn_backward(dqk, z, None, both, gamma, dg, db, M, 2 * D)
-        tp.pgrad(siam.featQ_bn.weight).add_(dg[:D]); tp.pgrad(siam.featK_bn.weight).add_(dg[D:])
-        tp.pgrad(siam.featQ_bn.bias).add_(db[:D]); tp.pgrad(siam.featK_bn.bias).add_(db[D:])
-        dbias = torch.zeros(2 * D, device=tp.dev)
         colsum_into(dz, M, 2 * D, dbias)
-        tp.pgrad(siam.featQ.bias).add_(dbias[:D]); tp.pgrad(siam.featK.bias).add_(dbias[D:])
         dw = torch.empty(2 * D, Cc, dtype=torch.float32, device=tp.dev)
         wgrad(dz, x, dw, M, 2 * D, Cc, accumulate=0)
-        tp.pgrad(siam.featQ.weight).add_(dw[:D]); tp.pgrad(siam.featK.weight).add_(dw[D:])
+        # the eight parameter-gradient accumulations as ONE multi-tensor launch (the same fp32 adds)
+        torch._foreach_add_(
+            [tp.pgrad(siam.featQ_bn.weight), tp.pgrad(siam.featK_bn.weight), tp.pgrad(siam.featQ_bn.bias),
+             tp.pgrad(siam.featK_bn.bias), tp.pgrad(siam.featQ.bias), tp.pgrad(siam.featK.bias),
+             tp.pgrad(siam.featQ.weight), tp.pgrad(siam.featK.weight)],
+            [dg[:D], dg[D:], db[:D], db[D:], dbias[:D], dbias[D:], dw[:D], dw[D:]])
         dx = _new((M, Cc), x)
         gemm(dz, tp.w_t(wqk, ('wqk', id(siam.featQ.weight))), dx, M, Cc, 2 * D)
         tp.add_grad(x, dx.view(tuple(x.shape)))
@@ -1496,10 +1502,9 @@ def verify_train(tp, head, probe, gallery):
         d32[:, :ncls] = dcls.reshape(P, ncls)
         db = torch.zeros(32, device=tp.dev)
         colsum_into(d32, P, 32, db)
-        tp.pgrad(lin.bias).add_(db[:ncls])
         dw = torch.empty(32, K, dtype=torch.float32, device=tp.dev)
         wgrad(d32, dn, dw, P, 32, K, accumulate=0)
-        tp.pgrad(lin.weight).add_(dw[:ncls])
+        torch._foreach_add_([tp.pgrad(lin.bias), tp.pgrad(lin.weight)], [db[:ncls], dw[:ncls]])
         ddn = _new((P, K), probe)
         gemm(d32, tp.w_t(wpad, ('wcls', id(lin.weight))), ddn, P, K, 32)
         dd = bn_backward(ddn, diff, None, st, bn.weight, tp.pgrad(bn.weight), tp.pgrad(bn.bias), P, K)
@@ -1585,8 +1590,8 @@ class _VerifyTrainFn(torch.autograd.Function):
         if gg is not None:
             dx[:, 1] = gg
         if dout is not None:
-            dx[:, 0] += dout[:half]
-            dx[:, 1] += dout[half:]
+            dx[:, 0].add_(dout[:half])
+            dx[:, 1].add_(dout[half:])
         tp.flush()
         grads = [tp.pg[id(p)][1] if id(p) in tp.pg else None for p in ctx.params]
         ctx.tape = None

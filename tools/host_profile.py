@@ -27,7 +27,6 @@ def main():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--top', type=int, default=45)
     ap.add_argument('--sort', default='tottime')
-    ap.add_argument('--aten', action='store_true', help='list the aten ops that launch device work in ONE step, by call site')
     a = ap.parse_args()
     import contextlib
     from grl_amd.reid import models
@@ -68,8 +67,6 @@ def main():
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     print('unprofiled: issue %.2f ms / step, wall %.2f ms / step' % (t_issue / a.steps * 1e3, t_all / a.steps * 1e3))
-    if a.aten:
-        return aten_ops(step, train_engine)
     # the backward closures run on the autograd engine's device thread, which a profiler enabled here does not see:
     # Tape.backward is wrapped so that it profiles itself on whatever thread calls it
     bw = cProfile.Profile()
@@ -105,49 +102,6 @@ def main():
     s = io.StringIO()
     pstats.Stats(pr, stream=s).strip_dirs().sort_stats('cumulative').print_stats(35)
     print(s.getvalue())
-
-
-def aten_ops(step, train_engine):
-    """Every aten op of ONE train step that touches device memory (torch-launched kernels / copies: each costs the host
-    more than a ctypes launch), counted by op and by the first call site outside torch."""
-    import collections
-    import traceback
-    from torch.utils._python_dispatch import TorchDispatchMode
-    quiet = ('aten.view', 'aten.detach', 'aten.empty', 'aten._unsafe_view', 'aten.as_strided', 'aten.slice', 'aten.select',
-             'aten.t.', 'aten.transpose', 'aten.permute', 'aten.unsqueeze', 'aten.squeeze', 'aten.expand', 'aten.alias',
-             'aten.reshape', 'aten.split', 'aten.unbind', 'aten.narrow', 'aten.is_', 'aten.sym_', 'aten.stride', 'aten.size',
-             'aten._local_scalar_dense', 'aten.new_empty', 'aten.empty_like', 'aten.lift_fresh', 'aten.resize_')
-    ops, sites = collections.Counter(), collections.Counter()
-
-    class Count(TorchDispatchMode):
-        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-            name = str(func)
-            if not name.startswith(quiet):
-                ops[name] += 1
-                for fr in reversed(traceback.extract_stack()[:-1]):
-                    if '/torch/' not in fr.filename and 'host_profile' not in fr.filename:
-                        sites['%-28s %s:%d %s' % (name, os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)] += 1
-                        break
-                else:
-                    sites['%-28s (torch internal: optimizer / autograd)' % name] += 1
-            return func(*args, **(kwargs or {}))
-
-    orig_bw = train_engine.Tape.backward
-
-    def counted_backward(self):
-        with Count():
-            return orig_bw(self)
-    train_engine.Tape.backward = counted_backward
-    with Count():
-        step()
-    torch.cuda.synchronize()
-    train_engine.Tape.backward = orig_bw
-    print('==== aten ops of one step that are not views: %d ====' % sum(ops.values()))
-    for k, v in ops.most_common():
-        print('%5d  %s' % (v, k))
-    print('==== by call site ====')
-    for k, v in sites.most_common(70):
-        print('%5d  %s' % (v, k))
 
 
 if __name__ == '__main__':

@@ -72,5 +72,32 @@ a, b = run_trainer(), run_trainer()
 n = sum(0 if torch.equal(x, y) else 1 for x, y in zip(a, b))
 print('trainer, %d steps twice: %d/%d state tensors differ' % (nst, n, len(a)))
 bad += n
+# (d) round 6: the compressed-input pipeline -- engine.DevicePrefetcher decodes JPEG batches two ahead on its own
+# high-priority streams (pinned ring, H2D, unstuff / entropy / IDCT / colour kernels) while the previous batches' eval
+# steps run on the main and TRL streams.  DIFFERENT batches in flight at once (a race between a decode and a consumer
+# would mix them up): every batch's features must equal those of the same frames decoded serially and fed as a tensor.
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+import decode_rate
+from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+cnn.eval(); siam.eval()
+nb = 6
+frames = decode_rate.make_frames(nb * 8 * 4)
+batches = [JpegBatch(frames[i * 32:(i + 1) * 32], (8, 4)) for i in range(nb)]
+want = []
+with engine.math_mode('f32'):
+    for jb in batches:
+        px = decode_jpeg_batch(jb, dev)
+        torch.cuda.synchronize()
+        want.append(engine.extract_features(cnn, siam, px).clone())
+    torch.cuda.synchronize()
+    n = tot = 0
+    for _ in range(max(5, reps // 10)):
+        for k, (d_, _, _) in enumerate(engine.DevicePrefetcher(((jb, None, None) for jb in batches), dev)):
+            tot += 1
+            if not torch.equal(engine.extract_features(cnn, siam, d_), want[k]):
+                n += 1
+    torch.cuda.synchronize()
+print('jpeg-fed eval through the prefetcher: %d/%d batches differ from the serial decode' % (n, tot))
+bad += n
 print('SOAK', 'FAILED' if bad else 'ok')
 sys.exit(1 if bad else 0)

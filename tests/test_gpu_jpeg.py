@@ -141,6 +141,23 @@ def test_loader_to_features_with_device_decode(tmp_path, gpu_models):
     assert torch.equal(feats['device'], feats['host'])
 
 
+@pytest.mark.parametrize('h,w,q', [(128, 64, 90), (144, 56, 85), (321, 150, 95)])
+def test_device_decode_then_rect_scale_equals_pillow_on_other_frame_sizes(h, w, q):
+    """Datasets whose frames are not 256 x 128 (iLIDS-VID / PRID 2011: 128 x 64; detector crops: anything): the reference
+    opens the file and resizes the PIL image (video_loader.py:124-141 -> seqtransforms.py:30-47 RectScale, BILINEAR).
+    Device: grl_jpeg_decode_batch -> engine.rect_scale_u8, both on uint8 -- the composition equals Pillow's bit for bit."""
+    from PIL import Image
+    from grl_amd import engine
+    from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch
+    rng = np.random.default_rng(h * 7 + w)
+    streams = [_encode(_frame(h, w, rng), quality=q) for _ in range(6)]
+    want = np.stack([np.asarray(Image.open(io.BytesIO(s)).convert('RGB').resize((128, 256), Image.BILINEAR)).transpose(2, 0, 1)
+                     for s in streams])
+    got = engine.rect_scale_u8(decode_jpeg_batch(JpegBatch(streams, (2, 3)), 'cuda'))
+    assert got.shape == (2, 3, 3, 256, 128) and got.dtype == torch.uint8
+    assert np.array_equal(got.cpu().numpy().reshape(6, 3, 256, 128), want)
+
+
 def test_device_decode_with_per_frame_huffman_tables():
     """More than eight distinct Huffman table sets in one batch (every frame encoded with optimised tables): the
     look-ahead tables are per frame and read through the L2 instead of LDS; mixed batches (default + optimised) use the

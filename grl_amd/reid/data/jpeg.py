@@ -23,8 +23,15 @@ class JpegUnsupported(GrlHipError):
 
 
 def read_file(path):
+    """The bytes of one frame file.  A file whose scan is not closed by an EOI marker raises OSError like the reference's
+    `Image.open(path).convert('RGB')` does ("image file is truncated": Pillow runs libjpeg with a suspending source,
+    which never reaches the end of such an image) -- the device decoder itself follows libjpeg's rule for damaged data
+    (zero bits past the end) and would return a partly grey frame without a word."""
     with open(path, 'rb') as fh:
-        return fh.read()
+        data = fh.read()
+    if data[:2] == b'\xff\xd8' and data.rfind(b'\xff\xd9') < data.rfind(b'\xff\xda'):
+        raise OSError('image file is truncated (no EOI marker behind the scan): %s' % path)
+    return data
 
 
 class JpegBatch(object):

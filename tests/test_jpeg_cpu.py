@@ -298,6 +298,38 @@ def test_damaged_streams_decode_the_same_way_everywhere(tmp_path):
     assert n > 200
 
 
+def test_read_file_refuses_a_truncated_frame_like_pillow(tmp_path):
+    """video_loader.py:124-141 raises OSError on a truncated file (Pillow does not load truncated images unless told to);
+    the device loader's read_file raises too, and accepts what Pillow accepts: bytes behind the EOI marker, an embedded
+    thumbnail with its own EOI in front of the main image."""
+    import os
+    from PIL import Image
+    from grl_amd.reid.data.jpeg import read_file
+    rng = np.random.default_rng(2)
+    base = _encode(_frame(64, 32, rng), quality=85)
+    thumb = _encode(_frame(16, 8, rng), quality=60)
+    app1 = b'\xff\xe1' + (len(thumb) + 8).to_bytes(2, 'big') + b'Exif\0\0' + thumb
+    with_thumb = base[:2] + app1 + base[2:]
+    cases = {'whole': (base, True), 'tail': (base + b'\x00\x01garbage' * 9, True), 'thumb': (with_thumb, True),
+             'no_eoi': (base[:-2], False), 'cut': (base[:len(base) * 2 // 3], False),
+             'thumb_cut': (with_thumb[:len(with_thumb) - len(base) // 3], False)}
+    for name, (data, ok) in cases.items():
+        path = os.path.join(tmp_path, name + '.jpg')
+        with open(path, 'wb') as fh:
+            fh.write(data)
+        try:
+            Image.open(path).convert('RGB')
+            pil_ok = True
+        except OSError:
+            pil_ok = False
+        assert pil_ok == ok, name
+        if ok:
+            assert read_file(path) == data
+        else:
+            with pytest.raises(OSError, match='truncated'):
+                read_file(path)
+
+
 def test_compressed_batches_shard_at_pair_granularity():
     """dist.PairShardedBatches slices a global batch along the clip dimension; a JpegBatch slices the same way (the rank
     then uploads and decodes only its own pairs)."""

@@ -78,6 +78,10 @@ class JpegBatch(object):
         rc = lib.grl_jpeg_parse_batch(buf.ctypes.data, offs.ctypes.data, n, frames, C.addressof(bad))   # headers + table sets: one call
         if rc:
             msg = lib.grl_last_error().decode('utf-8', 'replace')
+            if 0 <= bad.value < n and self.streams[bad.value][:8] == b'\x89PNG\r\n\x1a\n':
+                # iLIDS-VID / PRID 2011 ship PNG frames (ilidsvidsequence.py:113): inflate is not on the device
+                raise JpegUnsupported("frame %d is a PNG file: the device decoder covers baseline JPEG (MARS, DukeMTMC-"
+                                      "VideoReID); load this dataset with RawVideoDataset(decode='host')" % bad.value)
             raise (JpegUnsupported if rc == _lib.GRL_EUNSUPPORTED else GrlHipError)('frame %d: %s' % (bad.value, msg))
         return host, frames
 

@@ -93,6 +93,11 @@ def test_jpeg_oracle_and_parser_refuse_what_is_out_of_scope(golden):
         JpegBatch([b'\x00\x01 not a jpeg at all'], (1,)).pack()
     with pytest.raises(_lib.GrlHipError):                                   # truncated inside the headers
         JpegBatch([g_bytes(golden)[:200]], (1,)).pack()
+    from PIL import Image                                                   # iLIDS-VID / PRID frames are PNG files
+    png = io.BytesIO()
+    Image.fromarray(np.zeros((16, 8, 3), np.uint8)).save(png, format='PNG')
+    with pytest.raises(JpegUnsupported, match="PNG.*decode='host'"):
+        JpegBatch([g_bytes(golden), png.getvalue()], (2,)).pack()
 
 
 def g_bytes(golden):

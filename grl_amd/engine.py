@@ -1104,10 +1104,12 @@ class DevicePrefetcher(object):
     them, a quarter of the PCIe bytes); anything else is made float32 on the host, as
     `imgs.to(device)` upstream (attevaluator.py:70,76)."""
 
-    def __init__(self, loader, device, depth=None):
+    def __init__(self, loader, device, depth=None, jpeg_size=(256, 128)):
         """``depth``: batches prepared ahead, each on its own side stream (default 1; 2 for loaders that hand over
-        compressed frames: a 512-frame batch decodes in ~10.5 ms, about what the bf16-storage eval step takes)."""
+        compressed frames).  ``jpeg_size``: the RectScale target (dataloader.py:53,68) that a compressed batch of MIXED
+        frame sizes is brought to while it is decoded (jpeg.decode_jpeg_batch ``size``)."""
         import collections
+        self.jpeg_size = jpeg_size
         self.it = iter(loader)
         self.dev = torch.device(device)
         self.depth = depth
@@ -1150,7 +1152,7 @@ class DevicePrefetcher(object):
             if not self._compressed:
                 self._compressed, self.streams = True, []
             with torch.cuda.stream(self._stream()) as _:
-                d = decode_jpeg_batch(imgs, self.dev)
+                d = decode_jpeg_batch(imgs, self.dev, size=self.jpeg_size)
                 ev = torch.cuda.Event()
                 ev.record()
             self.queue.append((d, pids, cams, ev, None, extra))

@@ -50,27 +50,35 @@ class RawVideoDataset(Dataset):
     (reid/dataset/mars.py); ``sample``: 'rrs_train' | 'rrs_test' | 'dense' with the reference's frame
     selection (``augment.sample_frame_indices``).  Items: (uint8 [T,3,H,W], pid, camid) -- 'dense':
     [n_clips,T,3,H,W] -- plus, with ``augment=True`` (training), the int32 block of
-    ``augment.draw_clip_params`` that SEQTrainer hands to grl_augment_normalize_u8.  All frames of a
-    batch must share one size (MARS crops are 256 x 128; other sizes are RectScale'd on the device)."""
+    ``augment.draw_clip_params`` that SEQTrainer hands to grl_augment_normalize_u8.  MARS crops are all
+    256 x 128; another uniform size is RectScale'd on the device; frames of DIFFERENT sizes (DukeMTMC-VideoReID):
+    see ``host_rect_scale`` below."""
 
-    def __init__(self, tracklets, seq_len=4, sample='rrs_train', augment=False, height=256, width=128, decode='host'):
+    def __init__(self, tracklets, seq_len=4, sample='rrs_train', augment=False, height=256, width=128, decode='host',
+                 host_rect_scale=False):
         """``decode``: 'host' -- the worker decodes with Pillow (items carry uint8 tensors); 'device' -- the worker only
         reads the files, items carry the JPEG byte strings, the loader uses ``jpeg.jpeg_collate`` and
-        engine.DevicePrefetcher decodes the batch on the GPU (grl_jpeg_decode_batch, bit-identical to Pillow)."""
+        engine.DevicePrefetcher decodes the batch on the GPU (grl_jpeg_decode_batch, bit-identical to Pillow).
+        ``host_rect_scale``: datasets whose frames DIFFER in size (DukeMTMC-VideoReID) cannot be stacked raw: with
+        decode='host' the worker then applies RectScale(height, width) itself (PIL BILINEAR, as the reference); with
+        decode='device' nothing is needed -- the prefetcher decodes per size and resizes on the GPU, the same bits."""
         if decode not in ('host', 'device'):
             raise ValueError("decode must be 'host' or 'device'")
         self.tracklets, self.seq_len, self.sample = list(tracklets), seq_len, sample
         self.augment, self.height, self.width, self.decode = augment, height, width, decode
+        self.host_rect_scale = host_rect_scale
 
     def __len__(self):
         return len(self.tracklets)
 
-    @staticmethod
-    def _decode(path):
+    def _decode(self, path):
         import numpy as np
         from PIL import Image
         with Image.open(path) as im:
-            return torch.from_numpy(np.ascontiguousarray(np.asarray(im.convert('RGB')).transpose(2, 0, 1)))
+            im = im.convert('RGB')
+            if self.host_rect_scale and im.size != (self.width, self.height):
+                im = im.resize((self.width, self.height), Image.BILINEAR)          # seqtransforms.py:30-47
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(im).transpose(2, 0, 1)))
 
     def __getitem__(self, index):
         from .augment import draw_clip_params, sample_frame_indices

@@ -114,10 +114,20 @@ class _PinnedRing(object):
 _rings = {}
 
 
-def decode_jpeg_batch(batch, device):
+def _geometry(f):
+    return (int(f.width), int(f.height), int(f.ncomp), int(f.hmax), int(f.vmax))
+
+
+def decode_jpeg_batch(batch, device, size=None):
     """JpegBatch (or a list of bytes) -> uint8 tensor ``batch.shape + (3, H, W)`` on ``device`` (planar RGB, what
-    np.asarray(Image.open(f).convert('RGB')).transpose(2, 0, 1) holds for every frame).  All frames must share one
-    geometry (size, components, sampling).  Work is enqueued on torch's current stream."""
+    np.asarray(Image.open(f).convert('RGB')).transpose(2, 0, 1) holds for every frame).  Work is enqueued on torch's
+    current stream.
+
+    ``size`` = None: all frames must share one geometry (size, components, sampling) -- MARS.  ``size`` = (H, W): a
+    batch whose frames differ in geometry (DukeMTMC-VideoReID's crops) is decoded per geometry group and every group is
+    brought to H x W with engine.rect_scale_u8 -- the reference's `RectScale` on the opened image (seqtransforms.py:30-47),
+    bit-identical to PIL's BILINEAR -- so the result is ``batch.shape + (3, H, W)``; a batch of ONE geometry is returned
+    at its native size (the caller's RectScale is then the same single device pass)."""
     if not isinstance(batch, JpegBatch):
         batch = JpegBatch(batch, (len(batch),))
     device = torch.device(device)
@@ -129,6 +139,19 @@ def decode_jpeg_batch(batch, device):
     ring_b, ring_f = _rings.setdefault(key, (_PinnedRing(), _PinnedRing()))
     ib, pinned = ring_b.get(sum(len(s) for s in batch.streams) + 16)
     host, frames = batch.pack(into=pinned)
+    if size is not None:
+        groups = {}
+        for i in range(n):
+            groups.setdefault(_geometry(frames[i]), []).append(i)
+        if len(groups) > 1:
+            from grl_amd import engine
+            ring_b.mark(ib)                       # (the slot was not used for a copy; hand it back in order)
+            H, W = int(size[0]), int(size[1])
+            out = torch.empty((n, 3, H, W), dtype=torch.uint8, device=device)
+            for idx in groups.values():
+                part = decode_jpeg_batch(JpegBatch([batch.streams[i] for i in idx], (len(idx),)), device)
+                out[torch.tensor(idx, device=device)] = engine.rect_scale_u8(part, H, W)
+            return out.view(batch.shape + (3, H, W))
     f0 = frames[0]
     H, W = int(f0.height), int(f0.width)
     dbytes = host.to(device, non_blocking=True)

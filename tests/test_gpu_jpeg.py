@@ -158,6 +158,52 @@ def test_device_decode_then_rect_scale_equals_pillow_on_other_frame_sizes(h, w, 
     assert np.array_equal(got.cpu().numpy().reshape(6, 3, 256, 128), want)
 
 
+def test_mixed_frame_sizes_decode_per_geometry_and_rect_scale(tmp_path, gpu_models):
+    """DukeMTMC-VideoReID's crops differ in size from tracklet to tracklet (duke.py:124-145): decode_jpeg_batch(size=)
+    decodes per geometry group and RectScales on the device -- every frame equals Pillow's open + convert + resize
+    (video_loader.py:124-141, seqtransforms.py:30-47); the loader path (decode='device', nothing else to set) gives the
+    features of the host path with host_rect_scale=True bit for bit.  Without `size` a mixed batch stays an error."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from grl_amd import engine, _lib
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.jpeg import JpegBatch, decode_jpeg_batch, jpeg_collate
+    rng = np.random.default_rng(23)
+    sizes = [(256, 128), (171, 74), (256, 128), (300, 131), (171, 74), (96, 40)]
+    streams = [_encode(_frame(h, w, rng, grey=(k == 3)), quality=88, subsampling=0 if k == 5 else 2) if k != 3 else
+               _encode(_frame(h, w, rng, grey=True), quality=88) for k, (h, w) in enumerate(sizes)]
+    want = np.stack([np.asarray(Image.open(io.BytesIO(s)).convert('RGB').resize((128, 256), Image.BILINEAR)).transpose(2, 0, 1)
+                     if hw != (256, 128) else np.asarray(Image.open(io.BytesIO(s)).convert('RGB')).transpose(2, 0, 1)
+                     for s, hw in zip(streams, sizes)])
+    got = decode_jpeg_batch(JpegBatch(streams, (3, 2)), 'cuda', size=(256, 128))
+    assert got.shape == (3, 2, 3, 256, 128)
+    assert np.array_equal(got.cpu().numpy().reshape(6, 3, 256, 128), want)
+    with pytest.raises(_lib.GrlHipError, match='another geometry'):
+        decode_jpeg_batch(JpegBatch(streams, (3, 2)), 'cuda')
+    # the loader path
+    cnn, siam, _ = gpu_models
+    tracklets = []
+    for tr, (h, w) in enumerate([(256, 128), (210, 90), (140, 61), (256, 128)]):
+        paths = []
+        for fi in range(5):
+            p = os.path.join(tmp_path, 'm%d_f%d.jpg' % (tr, fi))
+            Image.fromarray(_frame(h, w, rng)).save(p, format='JPEG', quality=90)
+            paths.append(p)
+        tracklets.append((paths, tr, tr % 2))
+    dev_loader = DataLoader(RawVideoDataset(tracklets, seq_len=4, sample='rrs_test', decode='device'), batch_size=2,
+                            collate_fn=jpeg_collate, num_workers=0)
+    host_loader = DataLoader(RawVideoDataset(tracklets, seq_len=4, sample='rrs_test', decode='host', host_rect_scale=True),
+                             batch_size=2, num_workers=0)
+    feats = {}
+    for name, loader in (('device', dev_loader), ('host', host_loader)):
+        rows = []
+        for clips, pids, cams in engine.DevicePrefetcher(loader, 'cuda'):
+            assert clips.dtype == torch.uint8 and clips.shape == (2, 4, 3, 256, 128)
+            rows.append(engine.extract_features(cnn, siam, clips))
+        feats[name] = torch.cat(rows)
+    assert torch.equal(feats['device'], feats['host'])
+
+
 def test_device_decode_with_per_frame_huffman_tables():
     """More than eight distinct Huffman table sets in one batch (every frame encoded with optimised tables): the
     look-ahead tables are per frame and read through the L2 instead of LDS; mixed batches (default + optimised) use the

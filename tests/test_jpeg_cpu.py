@@ -335,6 +335,34 @@ def test_read_file_refuses_a_truncated_frame_like_pillow(tmp_path):
                 read_file(path)
 
 
+def test_compressed_batches_cross_loader_worker_processes(tmp_path):
+    """INTEGRATION.md's loader: RawVideoDataset(decode='device') under DataLoader(num_workers=2, collate_fn=jpeg_collate)
+    -- the workers read files, JpegBatch objects are pickled back, the headers parse in the parent (no GPU call)."""
+    import os
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from grl_amd.reid.data import RawVideoDataset
+    from grl_amd.reid.data.jpeg import JpegBatch, jpeg_collate
+    rng = np.random.default_rng(0)
+    tracklets = []
+    for t in range(6):
+        paths = []
+        for f in range(5):
+            p = os.path.join(tmp_path, 't%d_%d.jpg' % (t, f))
+            Image.fromarray(_frame(64, 32, rng)).save(p, format='JPEG', quality=80)
+            paths.append(p)
+        tracklets.append((paths, t, t % 2))
+    loader = DataLoader(RawVideoDataset(tracklets, seq_len=4, sample='rrs_test', decode='device'), batch_size=2,
+                        collate_fn=jpeg_collate, num_workers=2)
+    seen = []
+    for jb, pids, cams in loader:
+        assert isinstance(jb, JpegBatch) and jb.shape == (2, 4)
+        _, fr = jb.pack()
+        assert all((f.width, f.height) == (32, 64) for f in fr)
+        seen += pids.tolist()
+    assert seen == list(range(6))
+
+
 def test_compressed_batches_shard_at_pair_granularity():
     """dist.PairShardedBatches slices a global batch along the clip dimension; a JpegBatch slices the same way (the rank
     then uploads and decodes only its own pairs)."""

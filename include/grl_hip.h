@@ -669,8 +669,10 @@ int grl_bottleneck_tail_f32_supported(int P, int C4, int Pn);
  * Frame decode on the device (round 6).  Replaces the per-frame
  * `Image.open(img_path).convert('RGB')` of reid/data/video_loader.py:124-141 (and :91-96, :108-113): baseline JPEG
  * -> uint8 RGB, BIT-IDENTICAL to Pillow / libjpeg-turbo with libjpeg's defaults (ISLOW integer IDCT, fancy
- * upsampling): Huffman decoding (one lane per frame: a scan is a serial bit stream), dequantisation + jidctint's
- * integer IDCT (one lane per 8 x 8 block), triangle-filter chroma upsampling + YCbCr -> RGB (one lane per pixel).
+ * upsampling): 0xFF00 unstuffing, Huffman decoding (one 256-lane workgroup per frame over self-synchronising
+ * subsequences of the bit stream; one lane per frame for scans with restart intervals or frames too large for the
+ * workgroup form), dequantisation + jidctint's integer IDCT (one lane per 8 x 8 block), triangle-filter chroma
+ * upsampling + YCbCr -> RGB (one lane per pixel).
  * Scope: 8-bit baseline / extended-sequential Huffman, one interleaved scan, 1 or 3 components, luma sampling 1x1,
  * 2x1 or 2x2 (4:4:4, 4:2:2, 4:2:0 -- MARS' frames are 256 x 128 4:2:0), table ids 0..1, restart intervals.
  * Anything else is refused by the parser with GRL_EUNSUPPORTED: the caller (grl_amd/reid/data/jpeg.py) says so
@@ -712,7 +714,9 @@ int grl_jpeg_parse_batch(const uint8_t* buf, const int64_t* offsets, int n, GrlJ
 int64_t grl_jpeg_workspace_bytes(const GrlJpegFrame* frames_host, int n);
 /* n frames of ONE geometry (width, height, components, sampling: as frames[0]; frames_host is checked) ->
  * out uint8 [n][3][height][width] (planar RGB: the layout the clip tensors [B][T][3][H][W] have).
- * bytes: the concatenated streams (device); frames_dev: the n parsed descriptors (device copy of frames_host). */
+ * bytes: the concatenated streams (device) -- the buffer grl_jpeg_parse's base_off values refer to: it must hold
+ * every frames[i].scan_off + scan_len (like every pointer of this ABI its extent is the caller's contract; the kernels
+ * read no byte outside the scans); frames_dev: the n parsed descriptors (device copy of frames_host). */
 int grl_jpeg_decode_batch(const uint8_t* bytes, const GrlJpegFrame* frames_dev, const GrlJpegFrame* frames_host, int n,
                           uint8_t* out, void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -415,6 +415,12 @@ def train_series(dev, math, steps=20, warmup=5, b=32, t=4, rank=0, world=1, dist
             step = lambda: gstep()[0]
         for _ in range(warmup):
             loss = step()
+        if warmup > 0:
+            # what the product's training loop does after its first step (reid/train/trainer.py: gc.freeze(), off with
+            # GRL_GC_FREEZE=0): the long-lived objects leave the cyclic collector's sight -- its pauses are step time on
+            # a host-bound step
+            from grl_amd.reid.train.trainer import _freeze_collector_once
+            _freeze_collector_once()
         barrier()
         del waits[:]
         # a HIP event on the launch stream after every step (read after the timed region: nothing blocks the host):

@@ -1122,13 +1122,15 @@ class DevicePrefetcher(object):
     def _stream(self):
         want = self.depth or 1
         while len(self.streams) < want:
-            # HIGH priority: not to jump the queue, but because the runtime gives priority levels their own hardware queues.
-            # Streams of one level share GPU_MAX_HW_QUEUES (4) in-order hardware queues; the eval step already uses the
-            # default stream + the TRL side streams, so a 10 ms decode kernel on a normal-priority prefetch stream landed in
-            # front of compute kernels in the SAME hardware queue: decode and compute ran back to back (24.8 ms per step =
-            # 14.5 + 10.3; 18.3 with GPU_MAX_HW_QUEUES=8; tools/jpegfeed_ab.sh).
-            # (plain host -> device copies stay at normal priority: at high priority they cost the step 3 %)
-            pr = int(os.environ.get('GRL_PREFETCH_PRIORITY', '-1')) if self._compressed else 0
+            # NORMAL priority (GRL_PREFETCH_PRIORITY=-1: high, for A/B).  History: streams of one priority level share
+            # GPU_MAX_HW_QUEUES (4) in-order hardware queues, and the first decoder's 10 ms entropy kernel on a normal-priority
+            # prefetch stream sat in front of compute kernels of the SAME hardware queue (24.8 ms per eval step = 14.5 + 10.3);
+            # high-priority streams have hardware queues of their own, which fixed that.  With the 0.8 ms decoder the
+            # interference is gone -- and high priority has a cliff: a stream gets its hardware queue at FIRST USE, and when the
+            # high-priority prefetch streams are used before the engine's side streams (a loader built before the first step:
+            # the normal order), the normal-priority streams used afterwards serialise: bf16-storage train step 17.8 -> 32 ms,
+            # fp32 53 -> 68, configs[2] eval 9.8 -> 12.2 (tools/jpeg_feed_order.py, profiles/r06_jpeg_feed_order.txt).
+            pr = int(os.environ.get('GRL_PREFETCH_PRIORITY', '0')) if self._compressed else 0
             self.streams.append(torch.cuda.Stream(self.dev, priority=pr))
         self._k += 1
         return self.streams[self._k % want]

@@ -1110,6 +1110,7 @@ class DevicePrefetcher(object):
         frame sizes is brought to while it is decoded (jpeg.decode_jpeg_batch ``size``)."""
         import collections
         self.jpeg_size = jpeg_size
+        self._ring = None
         self.it = iter(loader)
         self.dev = torch.device(device)
         self.depth = depth
@@ -1165,10 +1166,28 @@ class DevicePrefetcher(object):
             self.queue.append((imgs, pids, cams, None, None, extra))
             return True
         host = imgs.contiguous()
-        host = host if host.is_pinned() else host.pin_memory()
         st = self._stream()
         with torch.cuda.stream(st):
-            d = host.to(self.dev, non_blocking=True)
+            if host.is_pinned():                         # a loader with pin_memory=True (the reference's: dataloader.py:37-79)
+                d = host.to(self.dev, non_blocking=True)
+            else:
+                # pageable batch: staged through a ring of reusable pinned buffers.  `host.pin_memory()` per batch is a fresh
+                # pinned allocation each time (the host allocator cannot hand a block back while its copy is in flight) and
+                # hipHostMalloc stalls the device: the bf16-storage training loop ran at 34.7 ms per iteration on unpinned
+                # uint8 batches against 19.4 on pinned ones (tools/train_loop_rate.py)
+                from grl_amd.reid.data.jpeg import _PinnedRing
+                if self._ring is None:
+                    self._ring = _PinnedRing()
+                nbytes = host.numel() * host.element_size()
+                slot, buf = self._ring.get(nbytes)
+                stage = buf[:nbytes].view(host.dtype).view(host.shape)
+                # ONE thread copies: `stage.copy_(host)` fans out over every OpenMP thread torch has (128 on the test boxes),
+                # whose spin-waiting afterwards takes the cores from the thread that issues the step's ~1500 launches
+                # (34.8 ms per bf16-storage iteration with copy_, the copy itself being 0.03 ms)
+                C.memmove(stage.data_ptr(), host.data_ptr(), nbytes)
+                d = stage.to(self.dev, non_blocking=True)
+                self._ring.mark(slot)
+                host = None
         ev = torch.cuda.Event()
         ev.record(st)
         self.queue.append((d, pids, cams, ev, host, extra))  # `host` kept alive until the copy is consumed

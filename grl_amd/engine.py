@@ -1174,7 +1174,7 @@ class DevicePrefetcher(object):
                 # pageable batch: staged through a ring of reusable pinned buffers.  `host.pin_memory()` per batch is a fresh
                 # pinned allocation each time (the host allocator cannot hand a block back while its copy is in flight) and
                 # hipHostMalloc stalls the device: the bf16-storage training loop ran at 34.7 ms per iteration on unpinned
-                # uint8 batches against 19.4 on pinned ones (tools/train_loop_rate.py)
+                # uint8 batches against 19.4 on pinned ones (tools/loop_rate.py)
                 from grl_amd.reid.data.jpeg import _PinnedRing
                 if self._ring is None:
                     self._ring = _PinnedRing()

@@ -5,7 +5,9 @@ step -- fed three ways: float clips from the host (what the reference's loader y
 clips + augmentation draws (device augmentation), JPEG bytes + draws (device decode + augmentation).
 ms per iteration = (time of 70 iterations - time of 10) / 60.
 
-  python tools/train_loop_rate.py [--math bf16s] [--clips 32]
+`--mode eval`: ATTEvaluator.extract_feature(loader) -- the evaluator's own loop -- over 60 batches, clip-features/s.
+
+  python tools/loop_rate.py [--mode train|eval] [--math bf16s] [--clips 32] [--seq-len 4]
 """
 import argparse
 import contextlib
@@ -40,7 +42,9 @@ class Batches(object):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', default='train', choices=['train', 'eval'])
     ap.add_argument('--math', default='bf16s')
+    ap.add_argument('--seq-len', type=int, default=4)
     ap.add_argument('--clips', type=int, default=32)
     a = ap.parse_args()
     import decode_rate
@@ -52,7 +56,7 @@ def main():
     from grl_amd.reid.train import SEQTrainer
     from grl_amd.synthetic import synth_clips, synth_state_dict
     dev = torch.device('cuda', 0)
-    B, T = a.clips, 4
+    B, T = a.clips, a.seq_len
     with contextlib.redirect_stdout(io.StringIO()):
         cnn = models.create('resnet50_grl', num_features=2048, dropout=0, numclasses=625, pretrained=False)
     siam = models.create('siamese', input_num=2048, output_num=512, class_num=2)
@@ -79,7 +83,26 @@ def main():
         "uint8 clips + draws, PAGEABLE batches (a loader without pin_memory)": [(u, pids, pids, d) for u, d in zip(unpinned, draws)],
         "jpeg bytes + draws (device decode + augmentation)": [(JpegBatch(frames, (B, T)), pids, pids, d) for d in draws],
     }
-    out = {"math": a.math, "clips": B, "frames_per_clip": T, "loop": "SEQTrainer.train (loss.item() per step as upstream)"}
+    if a.mode == 'eval':
+        from grl_amd import engine
+        from grl_amd.reid.evaluator import ATTEvaluator
+        engine.set_math(a.math)
+        ev = ATTEvaluator(mods[0].eval(), mods[1].eval(), False)
+        out = {"mode": "eval", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "ATTEvaluator.extract_feature"}
+        feeds = {k: [r[:3] for r in rows] for k, rows in feeds.items()}
+        for name, rows in feeds.items():
+            def run(n):
+                t0 = time.perf_counter()
+                f, _, _ = ev.extract_feature(Batches(rows, n))
+                torch.cuda.synchronize()
+                assert f.shape == (n * B, 6144)
+                return time.perf_counter() - t0
+            run(10)
+            t10, t70 = run(10), run(70)
+            out[name.replace(' + draws', '').replace(' (device augmentation)', '').replace(' + augmentation)', ')') + ": clip-features/s"] = round(60 * B / (t70 - t10), 1)
+        print(json.dumps(out))
+        return
+    out = {"mode": "train", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "SEQTrainer.train (loss.item() per step as upstream)"}
     for name, rows in feeds.items():
         def run(n):
             with contextlib.redirect_stdout(io.StringIO()):

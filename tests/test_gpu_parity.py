@@ -417,6 +417,46 @@ def test_trainer_steps_run_on_hip():
     assert bool(torch.isfinite(feat).all())
 
 
+def test_trainer_meters_read_one_step_late_hold_the_same_values(capsys):
+    """SEQTrainer.train reads the step's loss / precisions one step late from a pinned buffer (no `loss.item()` stall
+    behind the forward); the meters, the writer's scalars and the trained parameters are those of the upstream order
+    (GRL_LAZY_METERS=0: trainer.py:70-77), value for value."""
+    from grl_amd.reid.train import trainer as T
+    from grl_amd.reid.loss import OIMLoss, PairLoss
+    from grl_amd.reid.data import SyntheticPairs
+    from torch.utils.data import DataLoader
+    dev = torch.device('cuda:0')
+
+    class Writer(object):
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, val, it):
+            self.rows.append((tag, float(val), int(it)))
+
+    runs = {}
+    for lazy in (True, False):
+        T.LAZY_METERS = lazy
+        try:
+            cnn, siam, siamv = _fresh_models()
+            crit_c, crit_u = OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev), OIMLoss(2048, 625, scalar=30, momentum=0.5).to(dev)
+            tr = T.SEQTrainer(cnn, siam, siamv, PairLoss().to(dev), crit_c, crit_u, None)
+            tr.writer = Writer()
+            opt = torch.optim.SGD([p for m in (cnn, siam, siamv) for p in m.parameters()], lr=1e-3, momentum=0.9,
+                                  weight_decay=5e-4, nesterov=True)
+            loader = DataLoader(SyntheticPairs(12, 2), batch_size=4, shuffle=False, drop_last=True)
+            tr.train(1, loader, opt)
+        finally:
+            T.LAZY_METERS = True
+        m = tr.meters
+        runs[lazy] = ([(k, float(v.val), float(v.avg), int(v.count)) for k, v in sorted(m.items())], tr.writer.rows,
+                      cnn.backbone.base[0].weight.detach().clone(), crit_c.lut.clone())
+    assert runs[True][0] == runs[False][0] and runs[True][0][0][3] == 24            # 6 steps x 4 clips... per meter
+    assert runs[True][1] == runs[False][1] and len(runs[True][1]) == 2 * 6
+    assert [r[2] for r in runs[True][1][::2]] == [6 + i for i in range(6)]          # num_iter = len(loader) * epoch + i
+    assert torch.equal(runs[True][2], runs[False][2]) and torch.equal(runs[True][3], runs[False][3])
+
+
 @pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16', 5e-2), ('bf16s', 2e-2)])
 def test_eval_forward_alternative_math_modes(golden, gpu_models, mode, tol):
     """The opt-in bf16 datapaths against the reference golden: split-bf16 stays inside the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The product's training loop as a user runs it -- SEQTrainer.train(epoch, loader, optimizer): DevicePrefetcher,
-_parse_data, the 5-term step, `loss.item()` per step as upstream (trainer.py:63-97), meters, gc.freeze() after the first
-step -- fed three ways: float clips from the host (what the reference's loader yields: 50 MB per 32 x 4 batch), raw uint8
+_parse_data, the 5-term step, the loss / precision meters of trainer.py:63-97 (read one step late), gc.freeze() after the
+first step -- fed three ways: float clips from the host (what the reference's loader yields: 50 MB per 32 x 4 batch), raw uint8
 clips + augmentation draws (device augmentation), JPEG bytes + draws (device decode + augmentation).
 ms per iteration = (time of 70 iterations - time of 10) / 60.
 
@@ -102,7 +102,7 @@ def main():
             out[name.replace(' + draws', '').replace(' (device augmentation)', '').replace(' + augmentation)', ')') + ": clip-features/s"] = round(60 * B / (t70 - t10), 1)
         print(json.dumps(out))
         return
-    out = {"mode": "train", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "SEQTrainer.train (loss.item() per step as upstream)"}
+    out = {"mode": "train", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "SEQTrainer.train (meters read one step late; GRL_LAZY_METERS=0: loss.item() per step as upstream)"}
     for name, rows in feeds.items():
         def run(n):
             with contextlib.redirect_stdout(io.StringIO()):

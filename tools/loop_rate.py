@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--mode', default='train', choices=['train', 'eval'])
     ap.add_argument('--math', default='bf16s')
     ap.add_argument('--seq-len', type=int, default=4)
+    ap.add_argument('--dense', type=int, default=0, help='--mode eval: dense mode (test_all.py), this many clips per tracklet, one tracklet per batch')
     ap.add_argument('--clips', type=int, default=32)
     a = ap.parse_args()
     import decode_rate
@@ -90,16 +91,28 @@ def main():
         ev = ATTEvaluator(mods[0].eval(), mods[1].eval(), False)
         out = {"mode": "eval", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "ATTEvaluator.extract_feature"}
         feeds = {k: [r[:3] for r in rows] for k, rows in feeds.items()}
+        per_batch = B
+        if a.dense:
+            # one tracklet of `dense` clips per loader item, as the reference's dense loaders (batch size 1)
+            ev = ATTEvaluator(mods[0], mods[1], True)
+            per_batch = a.dense
+            out["loop"] += " (dense mode: %d clips per tracklet, clip features averaged per tracklet)" % a.dense
+            d_float = [synth_clips(a.dense, T, seed=s)[None].pin_memory() for s in range(4)]
+            d_u8 = [(f * 40 + 128).clamp_(0, 255).to(torch.uint8).pin_memory() for f in d_float]
+            d_frames = decode_rate.make_frames(a.dense * T)
+            feeds = {"float tracklets (pinned)": [(f, pids[:1], pids[:1]) for f in d_float],
+                     "uint8 tracklets (pinned)": [(u, pids[:1], pids[:1]) for u in d_u8],
+                     "jpeg bytes (device decode)": [(JpegBatch(d_frames, (1, a.dense, T)), pids[:1], pids[:1])]}
         for name, rows in feeds.items():
             def run(n):
                 t0 = time.perf_counter()
                 f, _, _ = ev.extract_feature(Batches(rows, n))
                 torch.cuda.synchronize()
-                assert f.shape == (n * B, 6144)
+                assert f.shape == (n if a.dense else n * B, 6144)
                 return time.perf_counter() - t0
             run(10)
             t10, t70 = run(10), run(70)
-            out[name.replace(' + draws', '').replace(' (device augmentation)', '').replace(' + augmentation)', ')') + ": clip-features/s"] = round(60 * B / (t70 - t10), 1)
+            out[name.replace(' + draws', '').replace(' (device augmentation)', '').replace(' + augmentation)', ')') + ": clip-features/s"] = round(60 * per_batch / (t70 - t10), 1)
         print(json.dumps(out))
         return
     out = {"mode": "train", "math": a.math, "clips": B, "frames_per_clip": T, "loop": "SEQTrainer.train (meters read one step late; GRL_LAZY_METERS=0: loss.item() per step as upstream)"}

@@ -453,27 +453,29 @@ RELU_BITS = os.environ.get('GRL_RELU_BITS', '1') != '0'                 # A/B an
 STEM_TAIL_FUSED = os.environ.get('GRL_STEM_TAIL_FUSED', '1') != '0'     # A/B and tests only
 
 
+_NO_CONV = (0,) * 9
+_wgrad_ws = {}
+
+
 def wgrad(dz, x, dw, M, N, K, ldz=None, ldx=None, conv=None, k_out=0, accumulate=1, math=None, stream=None):
     """dw[N][K] (+)= dz^T . X  through grl_conv_wgrad_f32 (datapath: the training math mode).  ``stream``: a raw
     hipStream_t to launch on instead of torch's current stream (wgrad_async); returns the workspace tensor (the caller of
     a side-stream launch keeps it alive until the streams join)."""
-    d = GrlWgrad()
-    d.math = _train_math[0] if math is None else math
-    d.dz, d.x, d.dw = ptr(dz), ptr(x), ptr(dw)
-    d.M, d.N, d.K = M, N, K
-    d.ldz = ldz or N
-    d.ldx = ldx or K
-    d.k_out = k_out
-    d.accumulate = accumulate
-    if dz.dtype == BF16:                   # bf16-storage operands (both): plain bf16 products, fp32 dW
-        if x.dtype != BF16:
-            raise _lib.GrlHipError('wgrad: dz is bf16 but x is %s' % x.dtype)
-        d.in_bf16 = 1
-    if conv is not None:
-        d.conv = 1
-        (d.H, d.W, d.C, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.pad) = conv
+    mth = _train_math[0] if math is None else math
+    b16 = dz.dtype == BF16                  # bf16-storage operands (both): plain bf16 products, fp32 dW
+    if b16 and x.dtype != BF16:
+        raise _lib.GrlHipError('wgrad: dz is bf16 but x is %s' % x.dtype)
+    cv = conv if conv is not None else _NO_CONV
+    # one positional constructor call (field order of GrlWgrad: include/grl_hip.h) instead of ~20 attribute stores, and the
+    # workspace size of a shape asked once: ~65 weight gradients per step on a step the host barely keeps ahead of
+    d = GrlWgrad(ptr(dz), ptr(x), ptr(dw), None, M, N, K, ldz or N, ldx or K, k_out, accumulate, 1 if conv is not None else 0,
+                 cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7], cv[8], mth, 1 if b16 else 0)
     lib = _lib.load()
-    ws = torch.empty(lib.grl_wgrad_workspace_floats(C.byref(d)), dtype=torch.float32, device=dz.device)
+    key = (M, N, K, d.ldz, d.ldx, k_out, conv, mth, b16)
+    nws = _wgrad_ws.get(key)
+    if nws is None:
+        nws = _wgrad_ws[key] = int(lib.grl_wgrad_workspace_floats(C.byref(d)))
+    ws = torch.empty(nws, dtype=torch.float32, device=dz.device)
     d.workspace = ptr(ws)
     check(lib.grl_conv_wgrad_f32(C.byref(d), _lib.stream() if stream is None else stream), 'grl_conv_wgrad_f32')
     if engine._DEBUG_SYNC:

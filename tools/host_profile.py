@@ -59,6 +59,8 @@ def main():
     train_engine.set_math(a.math)
     for _ in range(4):
         step()
+    from grl_amd.reid.train.trainer import _freeze_collector_once
+    _freeze_collector_once()                 # as the product's loop does after its first step (the collector's pauses are step time)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):

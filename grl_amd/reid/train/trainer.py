@@ -154,7 +154,8 @@ class BaseTrainer(object):
             loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame = \
                 self._forward(inputs, targets, i, epoch)
             num_iter = len(data_loader) * epoch + i
-            four = torch.stack([torch.as_tensor(v, dtype=torch.float32, device=loss.device).detach().reshape(())
+            four = torch.stack([v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
+                                else torch.tensor(float(v), dtype=torch.float32, device=loss.device)
                                 for v in (loss, uncorr_prec_id_vid, corr_prec_id_vid, corr_prec_id_frame)])
             settle()                                      # the previous step's values
             if lazy:

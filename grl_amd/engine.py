@@ -1171,10 +1171,9 @@ class DevicePrefetcher(object):
             if host.is_pinned():                         # a loader with pin_memory=True (the reference's: dataloader.py:37-79)
                 d = host.to(self.dev, non_blocking=True)
             else:
-                # pageable batch: staged through a ring of reusable pinned buffers.  `host.pin_memory()` per batch is a fresh
-                # pinned allocation each time (the host allocator cannot hand a block back while its copy is in flight) and
-                # hipHostMalloc stalls the device: the bf16-storage training loop ran at 34.7 ms per iteration on unpinned
-                # uint8 batches against 19.4 on pinned ones (tools/loop_rate.py)
+                # pageable batch: staged through a ring of reusable pinned buffers (no pinned allocation per batch) by ONE
+                # host thread (below).  With `host.pin_memory()` here the bf16-storage training loop ran at 34.7 ms per
+                # iteration on unpinned uint8 batches against 19.4 on pinned ones (tools/loop_rate.py)
                 from grl_amd.reid.data.jpeg import _PinnedRing
                 if self._ring is None:
                     self._ring = _PinnedRing()

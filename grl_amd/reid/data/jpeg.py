@@ -90,7 +90,9 @@ class _PinnedRing(object):
     """A few reusable pinned staging buffers.  `tensor.pin_memory()` per batch allocates pinned host memory again and
     again (the caching host allocator cannot hand a block back while its copy is in flight) and hipHostMalloc stalls the
     device: the eval step fed from JPEG bytes ran decode and compute back to back (24.8 ms = 14.5 + 10.3) instead of side
-    by side.  A slot is reused only after the event recorded behind its last copy has completed."""
+    by side.  (Found later on the tensor path: `pin_memory()` / `copy_` also fan the copy out over torch's OpenMP pool, whose
+    spin-wait takes the cores from the issue thread -- engine.DevicePrefetcher; the ring's single-threaded copy avoids both.)
+    A slot is reused only after the event recorded behind its last copy has completed."""
 
     def __init__(self, slots=4):
         self.bufs, self.events, self.i = [None] * slots, [None] * slots, 0
